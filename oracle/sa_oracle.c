@@ -1,0 +1,1518 @@
+/*
+ * sa_oracle.c -- CPU restatement of signalAlign's banded pair-HMM forward/backward/posterior path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see sa_oracle.h).  Plain C11, IEEE double, compiled with
+ * -ffp-contract=off so that every sum/product rounds exactly as the reference's x86-64 -O3 build.
+ *
+ * Parity pinning.  The upstream tree cannot be compiled in this image (its container/IO layer,
+ * sonLib, is an empty un-vendored submodule and htslib is absent), so this restatement is pinned by
+ * the reference's OWN known-answer tests, re-run against it in tests/test_oracle_kats.py:
+ *   tests/signalPairwiseAlignerTest.c:115-125  test_logAdd
+ *   tests/signalPairwiseAlignerTest.c:363-432  test_getSplitPoints (all rectangles)
+ *   tests/signalPairwiseAlignerTest.c:434-497  test_bands (every diagonal)
+ *   tests/signalPairwiseAlignerTest.c:499-541  test_diagonal (parity exception)
+ *   tests/signalPairwiseAlignerTest.c:543-568  test_hdCellConstruct[WorstCase] (9 / 729 paths)
+ *   tests/stateMachineTests.c:441-565          test_sm3_diagonalDPCalculations (14 pairs, set, totals)
+ *   tests/stateMachineTests.c:567-698          test_sm3_5merDiagonalDPCalculations (7 pairs)
+ *   tests/nanoporeHdpTests.c:102-108           test_kmer_id
+ * The whole-read pair-count tests (1076 / 3441 / 12784 ...) need lastz anchors and reference blobs
+ * that are missing from the tree; they are NOT reproduced.
+ *
+ * Layout of a DP row (one anti-diagonal xay = x + y): cells in ascending xmy = x - y, two apart;
+ * cell i sits at x = (xay + xmyL + 2i)/2; a cell holds P(x) paths (k-mer variants of ambiguous
+ * positions) of 3 doubles each [match, gapX, gapY].
+ */
+#define _GNU_SOURCE
+#include "sa_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define LOG_ZERO (-INFINITY)
+#define PAIR_ALIGNMENT_PROB_1 10000000
+#define MODEL_PARAMS 5
+#define ST_MATCH 0
+#define ST_GAPX 1
+#define ST_GAPY 2
+
+void sao_free(void *p) { free(p); }
+
+/* ------------------------------------------------------------------------------------------------
+ * logAdd: impl/pairwiseAligner.c:298-318.  NB float-typed literals, promoted to double.
+ * ---------------------------------------------------------------------------------------------- */
+static inline double lookup(double x) {
+    if (x <= 1.00f)
+        return ((-0.009350833524763f * x + 0.130659527668286f) * x + 0.498799810682272f) * x + 0.693203116424741f;
+    if (x <= 2.50f)
+        return ((-0.014532321752540f * x + 0.139942324101744f) * x + 0.495635523139337f) * x + 0.692140569840976f;
+    if (x <= 4.50f)
+        return ((-0.004605031767994f * x + 0.063427417320019f) * x + 0.695956496475118f) * x + 0.514272634594009f;
+    return ((-0.000458661602210f * x + 0.009695946122598f) * x + 0.930734667215156f) * x + 0.168037164329057f;
+}
+
+static inline double log_add(double x, double y) {
+    if (x < y)
+        return (x == LOG_ZERO || y - x >= 7.5) ? y : lookup(y - x) + x;
+    return (y == LOG_ZERO || x - y >= 7.5) ? x : lookup(x - y) + y;
+}
+
+double sao_log_add(double x, double y) { return log_add(x, y); }
+
+/* ------------------------------------------------------------------------------------------------
+ * kmer_id: impl/nanopore_hdp.c:371-410 (base-A number, first character most significant).
+ * ---------------------------------------------------------------------------------------------- */
+int64_t sao_kmer_id(const char *kmer, const char *alphabet, int n_alpha, int k) {
+    int64_t id = 0;
+    for (int i = 0; i < k; i++) {
+        int j = 0;
+        while (j < n_alpha && kmer[i] != alphabet[j]) j++;
+        if (j == n_alpha) return -1; /* the reference exits here */
+        id = id * n_alpha + j;
+    }
+    return id;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Band: impl/pairwiseAligner.c:98-246.
+ * ---------------------------------------------------------------------------------------------- */
+static inline int64_t diag_x(int64_t xay, int64_t xmy) { return (xay + xmy) / 2; }
+static inline int64_t diag_y(int64_t xay, int64_t xmy) { return (xay - xmy) / 2; }
+
+static int64_t avoid_off_by_one(int64_t xay, int64_t xmy) { return (xay + xmy) % 2 == 0 ? xmy : xmy + 1; }
+static void set_diag_p(int64_t *xmy, int64_t i, int64_t j, int64_t k) {
+    if (i < j) *xmy += 2 * (j - i) * k;
+}
+static int64_t bound_coord(int64_t z, int64_t lZ) { return z < 0 ? 0 : (z > lZ ? lZ : z); }
+
+/* returns -1 on the condition for which diagonal_construct throws (:99-103) */
+static int set_current_diagonal(int64_t xay, int64_t xL, int64_t yL, int64_t xU, int64_t yU, int64_t *oL,
+                                int64_t *oR) {
+    int64_t xmyL = xL - yL, xmyR = xU - yU;
+    xmyL = avoid_off_by_one(xay, xmyL);
+    xmyR = avoid_off_by_one(xay, xmyR);
+    set_diag_p(&xmyL, diag_x(xay, xmyL), xL, 1);
+    set_diag_p(&xmyL, yL, diag_y(xay, xmyL), 1);
+    set_diag_p(&xmyR, xU, diag_x(xay, xmyR), -1);
+    set_diag_p(&xmyR, diag_y(xay, xmyR), yU, -1);
+    if ((xay + xmyL) % 2 != 0 || (xay + xmyR) % 2 != 0 || xmyL > xmyR) return -1;
+    *oL = xmyL;
+    *oR = xmyR;
+    return 0;
+}
+
+/* diagonal_construct: impl/pairwiseAligner.c:98-111 (returns -1 where the reference throws) */
+int sao_diagonal_check(int64_t xay, int64_t xmyL, int64_t xmyR) {
+    if ((xay + xmyL) % 2 != 0 || (xay + xmyR) % 2 != 0 || xmyL > xmyR) return -1;
+    return (int) ((xmyR - xmyL) / 2 + 1); /* diagonal_getWidth :125-127 */
+}
+
+int sao_band(const int64_t *ax, const int64_t *ay, int64_t n_anchors, int64_t lX, int64_t lY, int64_t expansion,
+             int64_t *xmyL, int64_t *xmyR) {
+    int64_t idx = 0, xay = 0, pxay = 0, pxmy = 0, nxay = 0, nxmy = 0;
+    int64_t xL = 0, yL = 0, xU = 0, yU = 0;
+    int64_t lXalY = lX + lY;
+    while (xay <= lXalY) {
+        if (set_current_diagonal(xay, xL, yL, xU, yU, &xmyL[xay], &xmyR[xay]) != 0) return -1;
+        if (nxay == xay++) {
+            pxay = nxay;
+            pxmy = nxmy;
+            int64_t x = lX, y = lY;
+            if (idx < n_anchors) {
+                x = ax[idx] + 1;
+                y = ay[idx] + 1;
+                idx++;
+            }
+            nxay = x + y;
+            nxmy = x - y;
+            xL = bound_coord(diag_x(pxay, pxmy - expansion), lX);
+            yL = bound_coord(diag_y(nxay, nxmy - expansion), lY);
+            xU = bound_coord(diag_x(nxay, nxmy + expansion), lX);
+            yU = bound_coord(diag_y(pxay, pxmy + expansion), lY);
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Split points: impl/pairwiseAligner.c:1886-1937.
+ * ---------------------------------------------------------------------------------------------- */
+static int split_p(int64_t *x1, int64_t *y1, int64_t x2, int64_t y2, int64_t x3, int64_t y3, int64_t *out4,
+                   int64_t *n, int64_t bigger, int skip) {
+    int64_t lX2 = x3 - x2, lY2 = y3 - y2;
+    int64_t matrixSize = lX2 * lY2;
+    if (matrixSize > bigger) {
+        int64_t maxLen = (int64_t) sqrt((double) bigger);
+        int64_t hX = lX2 / 2 > maxLen ? maxLen : lX2 / 2;
+        int64_t hY = lY2 / 2 > maxLen ? maxLen : lY2 / 2;
+        if (!skip) {
+            out4[4 * *n + 0] = *x1;
+            out4[4 * *n + 1] = *y1;
+            out4[4 * *n + 2] = x2 + hX;
+            out4[4 * *n + 3] = y2 + hY;
+            (*n)++;
+        }
+        *x1 = x3 - hX;
+        *y1 = y3 - hY;
+        return 1;
+    }
+    return 0;
+}
+
+int64_t sao_split_points(const int64_t *ax, const int64_t *ay, int64_t n_anchors, int64_t lX, int64_t lY,
+                         int64_t bigger, int ragged_left, int ragged_right, int64_t *out4) {
+    int64_t x1 = 0, y1 = 0, x2 = 0, y2 = 0, n = 0;
+    for (int64_t i = 0; i < n_anchors; i++) {
+        int64_t x3 = ax[i], y3 = ay[i];
+        split_p(&x1, &y1, x2, y2, x3, y3, out4, &n, bigger, ragged_left && i == 0);
+        x2 = x3 + 1;
+        y2 = y3 + 1;
+    }
+    if (!split_p(&x1, &y1, x2, y2, lX, lY, out4, &n, bigger, ragged_left && n_anchors == 0) || !ragged_right) {
+        out4[4 * n + 0] = x1;
+        out4[4 * n + 1] = y1;
+        out4[4 * n + 2] = lX;
+        out4[4 * n + 3] = lY;
+        n++;
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * HDP: only what the alignment path reads.
+ * ---------------------------------------------------------------------------------------------- */
+static char *read_line(FILE *f) { /* stFile_getLineFromFile semantics: NULL at EOF, newline stripped */
+    size_t cap = 1 << 16, n = 0;
+    char *s = malloc(cap);
+    int c;
+    int any = 0;
+    while ((c = fgetc(f)) != EOF) {
+        any = 1;
+        if (c == '\n') break;
+        if (n + 2 > cap) {
+            cap *= 2;
+            s = realloc(s, cap);
+        }
+        s[n++] = (char) c;
+    }
+    if (!any) {
+        free(s);
+        return NULL;
+    }
+    s[n] = 0;
+    return s;
+}
+
+/* counts/returns whitespace-separated tokens (stString_split) */
+static int64_t split_ws(char *line, char ***toks_out) {
+    int64_t cap = 1024, n = 0;
+    char **t = malloc(cap * sizeof(char *));
+    char *p = line;
+    while (*p) {
+        while (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n') p++;
+        if (!*p) break;
+        if (n == cap) {
+            cap *= 2;
+            t = realloc(t, cap * sizeof(char *));
+        }
+        t[n++] = p;
+        while (*p && !(*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n')) p++;
+        if (*p) *p++ = 0;
+    }
+    *toks_out = t;
+    return n;
+}
+
+/* impl/hdp_math_utils.c:497-510 */
+static double *linspace(double start, double stop, int64_t length) {
+    double *lin = malloc(sizeof(double) * length);
+    int64_t n = length - 1;
+    double dx = (stop - start) / ((double) n);
+    for (int64_t i = 0; i < n; i++) lin[i] = start + i * dx;
+    lin[n] = stop;
+    return lin;
+}
+
+/* impl/nanopore_hdp.c:1088-1115 + impl/hdp.c:3052-3253 (factor tree lines are ignored: alignment never reads them) */
+sao_hdp_t *sao_hdp_load(const char *path, char *alphabet_out64, int *n_alpha_out, int *k_out) {
+    FILE *in = fopen(path, "r");
+    if (!in) return NULL;
+    char *line;
+    char **tok;
+    int64_t nt;
+    line = read_line(in);
+    int64_t alphabet_size = strtol(line, NULL, 10);
+    free(line);
+    line = read_line(in);
+    sscanf(line, "%63s", alphabet_out64);
+    free(line);
+    line = read_line(in);
+    int64_t kmer_length = strtol(line, NULL, 10);
+    free(line);
+    *n_alpha_out = (int) alphabet_size;
+    *k_out = (int) kmer_length;
+    /* sort the alphabet as package_nanopore_hdp does (impl/nanopore_hdp.c:34-76) */
+    for (int i = 0; i < alphabet_size; i++)
+        for (int j = i + 1; j < alphabet_size; j++)
+            if (alphabet_out64[j] < alphabet_out64[i]) {
+                char c = alphabet_out64[i];
+                alphabet_out64[i] = alphabet_out64[j];
+                alphabet_out64[j] = c;
+            }
+
+    line = read_line(in);
+    int splines_finalized = strtol(line, NULL, 10) != 0;
+    free(line);
+    line = read_line(in);
+    int has_data = strtol(line, NULL, 10) != 0;
+    free(line);
+    line = read_line(in);
+    int sample_gamma = strtol(line, NULL, 10) != 0;
+    free(line);
+    line = read_line(in);
+    int64_t num_dps = strtol(line, NULL, 10);
+    free(line);
+
+    int64_t data_length = 0;
+    int64_t *dp_ids = NULL;
+    if (has_data) {
+        line = read_line(in); /* data values: unused by alignment */
+        free(line);
+        line = read_line(in);
+        nt = split_ws(line, &tok);
+        data_length = nt;
+        dp_ids = malloc(sizeof(int64_t) * (nt > 0 ? nt : 1));
+        for (int64_t i = 0; i < nt; i++) dp_ids[i] = strtoll(tok[i], NULL, 10);
+        free(tok);
+        free(line);
+    }
+    line = read_line(in); /* mu nu alpha beta */
+    free(line);
+    line = read_line(in);
+    double grid_start, grid_stop;
+    long long grid_length_ll;
+    sscanf(line, "%lg\t%lg\t%lld", &grid_start, &grid_stop, &grid_length_ll);
+    int64_t grid_length = grid_length_ll;
+    free(line);
+    line = read_line(in); /* gamma */
+    free(line);
+    if (sample_gamma) {
+        for (int i = 0; i < 4; i++) {
+            line = read_line(in);
+            free(line);
+        }
+    }
+    sao_hdp_t *h = calloc(1, sizeof(*h));
+    h->num_dps = num_dps;
+    h->grid_length = grid_length;
+    h->grid = linspace(grid_start, grid_stop, grid_length);
+    h->parent = malloc(sizeof(int64_t) * num_dps);
+    h->observed = calloc(num_dps, 1);
+    h->post_pred = calloc(num_dps, sizeof(double *));
+    h->slopes = calloc(num_dps, sizeof(double *));
+    for (int64_t id = 0; id < num_dps; id++) {
+        line = read_line(in);
+        if (line[0] != '-') {
+            long long parent_id, nfc;
+            sscanf(line, "%lld\t%lld", &parent_id, &nfc);
+            h->parent[id] = parent_id;
+        } else {
+            h->parent[id] = -1;
+        }
+        free(line);
+    }
+    if (has_data) {
+        /* mark_observed_dps: impl/hdp.c:1132-1160 */
+        for (int64_t i = 0; i < data_length; i++) {
+            int64_t id = dp_ids[i];
+            while (id >= 0) {
+                if (h->observed[id]) break;
+                h->observed[id] = 1;
+                h->post_pred[id] = calloc(grid_length, sizeof(double));
+                id = h->parent[id];
+            }
+        }
+        for (int64_t id = 0; id < num_dps; id++) {
+            line = read_line(in);
+            nt = split_ws(line, &tok);
+            if (nt != 0) {
+                free(h->post_pred[id]);
+                h->post_pred[id] = malloc(sizeof(double) * grid_length);
+                for (int64_t i = 0; i < grid_length; i++) h->post_pred[id][i] = strtod(tok[i], NULL);
+            }
+            free(tok);
+            free(line);
+        }
+    }
+    if (splines_finalized) {
+        for (int64_t id = 0; id < num_dps; id++) {
+            line = read_line(in);
+            nt = split_ws(line, &tok);
+            if (nt != 0) {
+                h->slopes[id] = malloc(sizeof(double) * grid_length);
+                for (int64_t i = 0; i < grid_length; i++) h->slopes[id][i] = strtod(tok[i], NULL);
+            }
+            free(tok);
+            free(line);
+        }
+    }
+    free(dp_ids);
+    fclose(in);
+    return h;
+}
+
+void sao_hdp_free(sao_hdp_t *h) {
+    if (!h) return;
+    for (int64_t i = 0; i < h->num_dps; i++) {
+        free(h->post_pred[i]);
+        free(h->slopes[i]);
+    }
+    free(h->post_pred);
+    free(h->slopes);
+    free(h->grid);
+    free(h->parent);
+    free(h->observed);
+    free(h);
+}
+
+/* impl/hdp_math_utils.c:471-495 */
+static double grid_spline_interp(double query_x, const double *x, const double *y, const double *slope,
+                                 int64_t length) {
+    if (query_x <= x[0]) {
+        return y[0] - slope[0] * (x[0] - query_x);
+    } else if (query_x >= x[length - 1]) {
+        int64_t n = length - 1;
+        return y[n] + slope[n] * (query_x - x[n]);
+    } else {
+        double dx = x[1] - x[0];
+        int64_t idx_left = (int64_t) ((query_x - x[0]) / dx);
+        int64_t idx_right = idx_left + 1;
+        double dy = y[idx_right] - y[idx_left];
+        double a = slope[idx_left] * dx - dy;
+        double b = dy - slope[idx_right] * dx;
+        double t_left = (query_x - x[idx_left]) / dx;
+        double t_right = 1.0 - t_left;
+        return t_right * y[idx_left] + t_left * y[idx_right] + t_left * t_right * (a * t_right + b * t_left);
+    }
+}
+
+/* impl/hdp.c:2588-2612 */
+double sao_hdp_density(const sao_hdp_t *h, double x, int64_t dp_id) {
+    int64_t id = dp_id;
+    while (!h->observed[id]) id = h->parent[id];
+    double interp = grid_spline_interp(x, h->grid, h->post_pred[id], h->slopes[id], h->grid_length);
+    return interp > 0.0 ? interp : 0.0;
+}
+
+/* impl/hdp.c:2777-2806 */
+static double hdp_expected_val(const sao_hdp_t *h, int64_t dp_id) {
+    const double *grid = h->grid, *distr = h->post_pred[dp_id];
+    double ev = 0.0;
+    for (int64_t i = 1; i < h->grid_length; i++) {
+        double dx = grid[i] - grid[i - 1];
+        ev += grid[i] * distr[i] * dx;
+    }
+    return ev;
+}
+static double hdp_variance(const sao_hdp_t *h, int64_t dp_id) {
+    const double *grid = h->grid, *distr = h->post_pred[dp_id];
+    double ev = hdp_expected_val(h, dp_id), variance = 0.0;
+    for (int64_t i = 1; i < h->grid_length; i++) {
+        double dx = grid[i] - grid[i - 1];
+        double dev = grid[i] - ev;
+        variance += dev * dev * distr[i] * dx;
+    }
+    return variance;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Model: impl/stateMachine.c:1189-1258, :1440-1538, :1540-1589; impl/pairwiseAligner.c:366-395.
+ * ---------------------------------------------------------------------------------------------- */
+sao_model_t *sao_model_new(const char *alphabet, int n_alpha, int k, const double *t10, const double *table5,
+                           int emission) {
+    sao_model_t *m = calloc(1, sizeof(*m));
+    m->n_alpha = n_alpha;
+    m->k = k;
+    memcpy(m->alphabet, alphabet, n_alpha);
+    m->alphabet[n_alpha] = 0;
+    for (int i = 0; i < n_alpha; i++) /* sequence_prepareAlphabet: selection sort */
+        for (int j = i + 1; j < n_alpha; j++)
+            if (m->alphabet[j] < m->alphabet[i]) {
+                char c = m->alphabet[i];
+                m->alphabet[i] = m->alphabet[j];
+                m->alphabet[j] = c;
+            }
+    m->n_kmers = 1;
+    for (int i = 0; i < k; i++) m->n_kmers *= n_alpha;
+    /* defaults first (:1189-1200) then the file's tokens (:1202-1258): token 5 skipped, token 7 -> SWITCH_TO_Y */
+    m->t_gap_switch_to_x = LOG_ZERO;
+    m->t_gap_switch_to_y = LOG_ZERO;
+    m->t_match_continue = log(t10[0]);
+    m->t_gap_open_x = log(t10[1]);
+    m->t_gap_open_y = log(t10[2]);
+    m->t_match_from_gapx = log(t10[3]);
+    m->t_gap_extend_x = log(t10[4]);
+    m->t_match_from_gapy = log(t10[6]);
+    m->t_gap_switch_to_y = log(t10[7]);
+    m->t_gap_extend_y = log(t10[8]);
+    m->match5 = malloc(sizeof(double) * 5 * m->n_kmers);
+    m->gapy5 = malloc(sizeof(double) * 5 * m->n_kmers);
+    memcpy(m->match5, table5, sizeof(double) * 5 * m->n_kmers);
+    memcpy(m->gapy5, table5, sizeof(double) * 5 * m->n_kmers);
+    for (int64_t i = 1; i < m->n_kmers * MODEL_PARAMS; i += MODEL_PARAMS) m->gapy5[i] *= 1.75;
+    m->scale = 1.0;
+    m->shift = 0.0;
+    m->var = 1.0;
+    m->emission = emission;
+    return m;
+}
+
+void sao_model_free(sao_model_t *m) {
+    if (!m) return;
+    free(m->match5);
+    free(m->gapy5);
+    free(m);
+}
+
+void sao_model_set_read_params(sao_model_t *m, double scale, double shift, double var) {
+    m->scale = scale;
+    m->shift = shift;
+    m->var = var;
+}
+
+double *sao_model_match_table(sao_model_t *m) { return m->match5; }
+
+/* impl/stateMachine.c:721-741 (NB the GAP_Y sd uses the MATCH lambda: line 738-739) */
+void sao_model_scale_noise(sao_model_t *m, double scale_sd, double var_sd) {
+    for (int64_t i = 0; i < m->n_kmers * MODEL_PARAMS; i += MODEL_PARAMS) {
+        m->match5[i + 2] = m->match5[i + 2] * scale_sd;
+        m->match5[i + 4] = m->match5[i + 4] * var_sd;
+        m->match5[i + 3] = sqrt(pow(m->match5[i + 2], 3.0) / m->match5[i + 4]);
+        m->gapy5[i + 2] = m->gapy5[i + 2] * scale_sd;
+        m->gapy5[i + 4] = m->gapy5[i + 4] * var_sd;
+        m->gapy5[i + 3] = sqrt(pow(m->gapy5[i + 2], 3.0) / m->match5[i + 4]);
+    }
+}
+
+int sao_model_set_hdp(sao_model_t *m, sao_hdp_t *hdp) {
+    m->hdp = hdp;
+    m->emission = SAO_EM_HDP;
+    return 0;
+}
+
+/* impl/stateMachine.c:1275-1304: iterates over all k-mers; kmer index == dp id */
+void sao_model_set_to_hdp_expected_values(sao_model_t *m) {
+    for (int64_t id = 0; id < m->n_kmers; id++) {
+        if (m->hdp->observed[id]) {
+            m->match5[id * MODEL_PARAMS] = hdp_expected_val(m->hdp, id);
+            m->match5[id * MODEL_PARAMS + 1] = sqrt(hdp_variance(m->hdp, id));
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Emissions: impl/stateMachine.c:285-348, :527-701.
+ * ---------------------------------------------------------------------------------------------- */
+static inline double log_gauss_pdf(double x, double mu, double sigma) {
+    if (sigma == 0.0) return LOG_ZERO;
+    double log_inv_sqrt_2pi = -0.91893853320467267;
+    double l_sigma = log(sigma);
+    double a = (x - mu) / sigma;
+    return log_inv_sqrt_2pi - l_sigma + (-0.5 * a * a);
+}
+static inline double log_inv_gauss_pdf(double eventNoise, double modelNoiseMean, double modelNoiseLambda) {
+    double l_twoPi = 1.8378770664093453;
+    double l_eventNoise = log(eventNoise);
+    double a = (eventNoise - modelNoiseMean) / modelNoiseMean;
+    double l_lambda = log(modelNoiseLambda);
+    return (l_lambda - l_twoPi - 3 * l_eventNoise - modelNoiseLambda * a * a / eventNoise) / 2;
+}
+static inline double descale(double scaledEvent, double levelMean, double scale, double shift, double var) {
+    return (scaledEvent + var * levelMean - scale * levelMean - shift) / var;
+}
+
+/* match==1: EMISSION_MATCH_MATRIX, match==0: EMISSION_GAP_Y_MATRIX. id < 0 is the NULL k-mer. */
+static double emit(const sao_model_t *m, int32_t id, const double *ev, int match) {
+    if (id < 0) return LOG_ZERO;
+    const double *tab = match ? m->match5 : m->gapy5;
+    double eventMean = ev[0];
+    switch (m->emission) {
+        case SAO_EM_MEANONLY_DESCALED: {
+            double levelMean = tab[id * MODEL_PARAMS], levelSd = tab[id * MODEL_PARAMS + 1];
+            eventMean = descale(eventMean, levelMean, m->scale, m->shift, m->var);
+            double l = log_gauss_pdf(eventMean, levelMean, levelSd);
+            return log((1 / m->var)) + l;
+        }
+        case SAO_EM_TWODIST: {
+            double levelMean = tab[id * MODEL_PARAMS], levelSd = tab[id * MODEL_PARAMS + 1];
+            double noiseMean = tab[id * MODEL_PARAMS + 2], lambda = tab[id * MODEL_PARAMS + 4];
+            double l1 = log_gauss_pdf(eventMean, levelMean, levelSd);
+            double l2 = log_inv_gauss_pdf(ev[1], noiseMean, lambda);
+            return l1 + l2;
+        }
+        case SAO_EM_TWODIST_DESCALED: {
+            double eventNoise = ev[1];
+            if (eventNoise == 0) eventNoise = 0.000000001;
+            double levelMean = tab[id * MODEL_PARAMS], levelSd = tab[id * MODEL_PARAMS + 1];
+            eventMean = descale(eventMean, levelMean, m->scale, m->shift, m->var);
+            double noiseMean = tab[id * MODEL_PARAMS + 2], lambda = tab[id * MODEL_PARAMS + 4];
+            double l1 = log_gauss_pdf(eventMean, levelMean, levelSd);
+            double l2 = log_inv_gauss_pdf(eventNoise, noiseMean, lambda);
+            return l1 + l2;
+        }
+        case SAO_EM_HDP: {
+            double levelMean = m->match5[id * MODEL_PARAMS];
+            double normed = descale(eventMean, levelMean, m->scale, m->shift, m->var);
+            double density = (1 / m->var) * sao_hdp_density(m->hdp, normed, id);
+            return log(density);
+        }
+    }
+    return LOG_ZERO;
+}
+
+/* impl/stateMachine.c:208-225 (Gaussian) / :1394 (HDP literal) */
+static inline double emit_gapx(const sao_model_t *m, int32_t id) {
+    if (m->emission == SAO_EM_HDP) return -2.3025850929940455;
+    return id < 0 ? LOG_ZERO : -2.3025850929940455;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Ambiguity: impl/pairwiseAligner.c:32-65, :723-801.
+ * ---------------------------------------------------------------------------------------------- */
+void sao_default_ambig(const char **map) {
+    for (int i = 0; i < 256; i++) map[i] = NULL;
+    map['R'] = "AG"; map['Y'] = "CT"; map['S'] = "CG"; map['W'] = "AT"; map['K'] = "GT"; map['M'] = "AC";
+    map['B'] = "CGT"; map['D'] = "AGT"; map['H'] = "ACT"; map['V'] = "ACG"; map['X'] = "ACGT";
+    map['L'] = "CEO"; map['P'] = "CE"; map['Q'] = "AI"; map['f'] = "AF"; map['U'] = "ACEGOT"; map['Z'] = "JT";
+    map['j'] = "Tp"; map['k'] = "Gb"; map['l'] = "Gd"; map['m'] = "Ce"; map['n'] = "Th"; map['o'] = "Ai";
+}
+
+/* hdCell_construct2: left-to-right over positions, each ambiguous position multiplies the list,
+ * inner loop over replacement letters.  Returns number of paths, ids (or -1 for chars outside the
+ * alphabet) written up to cap.  Returns -2 if a path k-mer has a character outside the alphabet. */
+int64_t sao_expand_paths(const sao_model_t *m, const char *kmer_ptr, const char *const *ambig, int32_t *ids,
+                         int64_t cap) {
+    int k = m->k;
+    int64_t n = 1;
+    /* list of k-mers as strings, built exactly in the reference's order */
+    int64_t lcap = 16;
+    char *list = malloc(lcap * (k + 1));
+    memcpy(list, kmer_ptr, k);
+    list[k] = 0;
+    for (int i = 0; i < k; i++) {
+        const char *rep = ambig ? ambig[(unsigned char) kmer_ptr[i]] : NULL;
+        if (rep != NULL) {
+            int nr = (int) strlen(rep);
+            int64_t nn = n * nr;
+            char *nl = malloc((nn > 0 ? nn : 1) * (k + 1));
+            for (int64_t j = 0; j < n; j++)
+                for (int r = 0; r < nr; r++) {
+                    char *dst = nl + (j * nr + r) * (k + 1);
+                    memcpy(dst, list + j * (k + 1), k + 1);
+                    dst[i] = rep[r];
+                }
+            free(list);
+            list = nl;
+            n = nn;
+        }
+    }
+    int bad = 0;
+    for (int64_t j = 0; j < n && j < cap; j++) {
+        ids[j] = (int32_t) sao_kmer_id(list + j * (k + 1), m->alphabet, m->n_alpha, k);
+        if (ids[j] < 0) bad = 1;
+    }
+    free(list);
+    return bad ? -2 : n;
+}
+
+/* per-region view of the reference: P(x) and path k-mer ids for x = 0..lX (matrix coordinates).
+ * x == 0 is the NULL k-mer cell (one path, id -1): impl/pairwiseAligner.c:1021, :501-507, :741. */
+typedef struct {
+    int64_t lX;
+    int64_t *poff; /* lX + 2 */
+    int32_t *pid;
+    int64_t pow_km1; /* A^(k-1) */
+    int n_alpha;
+} xpaths_t;
+
+static int xpaths_build(xpaths_t *xp, const sao_model_t *m, const char *ref, int64_t lX,
+                        const char *const *ambig) {
+    xp->lX = lX;
+    xp->n_alpha = m->n_alpha;
+    xp->pow_km1 = 1;
+    for (int i = 0; i < m->k - 1; i++) xp->pow_km1 *= m->n_alpha;
+    xp->poff = malloc(sizeof(int64_t) * (lX + 2));
+    int64_t cap = lX + 16, n = 0;
+    xp->pid = malloc(sizeof(int32_t) * cap);
+    xp->poff[0] = 0;
+    xp->pid[n++] = -1;
+    xp->poff[1] = n;
+    int32_t *tmp = NULL;
+    int64_t tmpcap = 0;
+    for (int64_t x = 1; x <= lX; x++) {
+        int64_t np = 1;
+        for (int i = 0; i < m->k; i++) {
+            const char *rep = ambig ? ambig[(unsigned char) ref[x - 1 + i]] : NULL;
+            if (rep) np *= (int64_t) strlen(rep);
+        }
+        if (np > tmpcap) {
+            tmpcap = np;
+            tmp = realloc(tmp, sizeof(int32_t) * tmpcap);
+        }
+        int64_t got = sao_expand_paths(m, ref + x - 1, ambig, tmp, tmpcap);
+        if (got < 0) {
+            free(tmp);
+            free(xp->poff);
+            free(xp->pid);
+            return -1;
+        }
+        if (n + got > cap) {
+            cap = (n + got) * 2;
+            xp->pid = realloc(xp->pid, sizeof(int32_t) * cap);
+        }
+        memcpy(xp->pid + n, tmp, sizeof(int32_t) * got);
+        n += got;
+        xp->poff[x + 1] = n;
+    }
+    free(tmp);
+    return 0;
+}
+static void xpaths_free(xpaths_t *xp) {
+    free(xp->poff);
+    free(xp->pid);
+}
+static inline int64_t xp_n(const xpaths_t *xp, int64_t x) { return xp->poff[x + 1] - xp->poff[x]; }
+static inline const int32_t *xp_ids(const xpaths_t *xp, int64_t x) { return xp->pid + xp->poff[x]; }
+
+/* path_checkLegal: impl/pairwiseAligner.c:595-621 (from.kmer[1:] == to.kmer[:k-1], NULL always legal) */
+static inline int legal(const xpaths_t *xp, int32_t from, int32_t to) {
+    if (from < 0 || to < 0) return 1;
+    return (from % xp->pow_km1) == (to / xp->n_alpha);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * DP rows: impl/pairwiseAligner.c:988-1259.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t xay, xmyL, xmyR, width;
+    int64_t *coff; /* width + 1 : path offsets */
+    double *v;     /* 3 * coff[width] */
+} row_t;
+
+static row_t *row_new(int64_t xay, int64_t xmyL, int64_t xmyR, const xpaths_t *xp) {
+    row_t *r = malloc(sizeof(*r));
+    r->xay = xay;
+    r->xmyL = xmyL;
+    r->xmyR = xmyR;
+    r->width = (xmyR - xmyL) / 2 + 1;
+    r->coff = malloc(sizeof(int64_t) * (r->width + 1));
+    int64_t n = 0;
+    for (int64_t i = 0; i < r->width; i++) {
+        r->coff[i] = n;
+        n += xp_n(xp, diag_x(xay, xmyL + 2 * i));
+    }
+    r->coff[r->width] = n;
+    r->v = malloc(sizeof(double) * 3 * (n > 0 ? n : 1));
+    return r;
+}
+static void row_free(row_t *r) {
+    if (!r) return;
+    free(r->coff);
+    free(r->v);
+    free(r);
+}
+static void row_zero(row_t *r) {
+    int64_t n = 3 * r->coff[r->width];
+    for (int64_t i = 0; i < n; i++) r->v[i] = LOG_ZERO;
+}
+static void row_init(row_t *r, const double s[3]) {
+    int64_t n = r->coff[r->width];
+    for (int64_t i = 0; i < n; i++) {
+        r->v[3 * i] = s[0];
+        r->v[3 * i + 1] = s[1];
+        r->v[3 * i + 2] = s[2];
+    }
+}
+/* dpDiagonal_getCell :1114-1120: NULL outside [xmyL, xmyR] */
+static inline double *row_cell(const row_t *r, int64_t xmy) {
+    if (!r || xmy < r->xmyL || xmy > r->xmyR) return NULL;
+    return r->v + 3 * r->coff[(xmy - r->xmyL) / 2];
+}
+
+/* state vectors: impl/stateMachine.c:1134-1173 */
+static void state_start(const sao_model_t *m, int ragged, double s[3]) {
+    (void) m;
+    if (ragged) {
+        s[0] = LOG_ZERO; s[1] = 0; s[2] = 0;
+    } else {
+        s[0] = 0; s[1] = LOG_ZERO; s[2] = LOG_ZERO;
+    }
+}
+static void state_end(const sao_model_t *m, int ragged, double s[3]) {
+    if (ragged) {
+        s[0] = (m->t_gap_open_x + m->t_gap_open_y) / 2.0;
+        s[1] = m->t_gap_extend_x;
+        s[2] = m->t_gap_extend_y;
+    } else {
+        s[0] = m->t_match_continue;
+        s[1] = m->t_match_from_gapx;
+        s[2] = m->t_match_from_gapy;
+    }
+}
+
+/* what doTransition does */
+enum { MODE_FWD = 0, MODE_BWD = 1, MODE_EXPECT = 2 };
+
+typedef struct {
+    double total;          /* MODE_EXPECT */
+    double *trans9;        /* MODE_EXPECT */
+    double threshold;      /* MODE_EXPECT, HDP assignments */
+    int collect_assign;
+    int64_t ref_pos;       /* position in the caller's reference string of the current cell's cX pointer */
+    double ev_mean;
+    int64_t **assign_kmer;
+    double **assign_event;
+    int64_t *n_assign, *cap_assign;
+} expect_t;
+
+static inline void do_transition(int mode, double *fromCells, double *toCells, int from, int to, double eP,
+                                 double tP, expect_t *ex) {
+    if (mode == MODE_FWD) { /* :852-858 */
+        toCells[to] = log_add(toCells[to], fromCells[from] + (eP + tP));
+    } else if (mode == MODE_BWD) { /* :866-871 */
+        fromCells[from] = log_add(fromCells[from], toCells[to] + (eP + tP));
+    } else { /* :914-968 */
+        double p = exp(fromCells[from] + toCells[to] + (eP + tP) - ex->total);
+        ex->trans9[from * 3 + to] += p;
+        if (ex->collect_assign && (to == ST_MATCH) && (p >= ex->threshold)) {
+            if (*ex->n_assign == *ex->cap_assign) {
+                *ex->cap_assign = *ex->cap_assign ? *ex->cap_assign * 2 : 1024;
+                *ex->assign_kmer = realloc(*ex->assign_kmer, sizeof(int64_t) * *ex->cap_assign);
+                *ex->assign_event = realloc(*ex->assign_event, sizeof(double) * *ex->cap_assign);
+            }
+            (*ex->assign_kmer)[*ex->n_assign] = ex->ref_pos;
+            (*ex->assign_event)[*ex->n_assign] = ex->ev_mean;
+            (*ex->n_assign)++;
+        }
+    }
+}
+
+/* stateMachine3_cellCalculate / stateMachine3HDP_cellCalculate: impl/stateMachine.c:1306-1437.
+ * cur/low/mid/up point at the first path of the cell (or NULL); xc is the x of the current cell. */
+static void cell_calculate(const sao_model_t *m, const xpaths_t *xp, int mode, int64_t xc, double *cur,
+                           double *low, double *mid, double *up, const double *ev, expect_t *ex) {
+    int64_t nc = xp_n(xp, xc);
+    const int32_t *idc = xp_ids(xp, xc);
+    if (low != NULL) {
+        int64_t nl = xp_n(xp, xc - 1);
+        const int32_t *idl = xp_ids(xp, xc - 1);
+        for (int64_t p = 0; p < nc; p++)
+            for (int64_t q = 0; q < nl; q++)
+                if (legal(xp, idl[q], idc[p])) {
+                    double eP = emit_gapx(m, idc[p]);
+                    do_transition(mode, low + 3 * q, cur + 3 * p, ST_MATCH, ST_GAPX, eP, m->t_gap_open_x, ex);
+                    do_transition(mode, low + 3 * q, cur + 3 * p, ST_GAPX, ST_GAPX, eP, m->t_gap_extend_x, ex);
+                    do_transition(mode, low + 3 * q, cur + 3 * p, ST_GAPY, ST_GAPX, eP, m->t_gap_switch_to_x, ex);
+                }
+    }
+    if (mid != NULL) {
+        int64_t nm = xp_n(xp, xc - 1);
+        const int32_t *idm = xp_ids(xp, xc - 1);
+        for (int64_t p = 0; p < nc; p++) {
+            double eP = 0;
+            int have = 0;
+            for (int64_t q = 0; q < nm; q++)
+                if (legal(xp, idm[q], idc[p])) {
+                    if (!have) {
+                        eP = emit(m, idc[p], ev, 1);
+                        have = 1;
+                    }
+                    do_transition(mode, mid + 3 * q, cur + 3 * p, ST_MATCH, ST_MATCH, eP, m->t_match_continue, ex);
+                    do_transition(mode, mid + 3 * q, cur + 3 * p, ST_GAPX, ST_MATCH, eP, m->t_match_from_gapx, ex);
+                    do_transition(mode, mid + 3 * q, cur + 3 * p, ST_GAPY, ST_MATCH, eP, m->t_match_from_gapy, ex);
+                }
+        }
+    }
+    if (up != NULL) {
+        /* same x: identical path lists, stString_eq picks q == p (NULL == NULL at x == 0) */
+        for (int64_t p = 0; p < nc; p++) {
+            double eP = emit(m, idc[p], ev, m->emission == SAO_EM_HDP ? 1 : 0);
+            do_transition(mode, up + 3 * p, cur + 3 * p, ST_MATCH, ST_GAPY, eP, m->t_gap_open_y, ex);
+            do_transition(mode, up + 3 * p, cur + 3 * p, ST_GAPY, ST_GAPY, eP, m->t_gap_extend_y, ex);
+        }
+    }
+}
+
+static const double NULLEVENT[4] = {-INFINITY, 0, 0, 0}; /* impl/pairwiseAligner.c:325, :509-512 */
+
+typedef struct {
+    const sao_model_t *m;
+    const xpaths_t *xp;
+    int64_t ref_off; /* offset of this region in the caller's reference (expectation assignments) */
+    const double *events;
+    int64_t stride, lX, lY;
+} ctx_t;
+
+static inline const double *get_event(const ctx_t *c, int64_t indexY) {
+    return indexY >= 0 ? c->events + indexY * c->stride : NULLEVENT;
+}
+
+/* diagonalCalculation: impl/pairwiseAligner.c:1280-1311 */
+static void diagonal_calculation(const ctx_t *c, int mode, row_t *d, row_t *m1, row_t *m2, expect_t *ex) {
+    for (int64_t xmy = d->xmyL; xmy <= d->xmyR; xmy += 2) {
+        int64_t x = diag_x(d->xay, xmy), y = diag_y(d->xay, xmy);
+        const double *ev = get_event(c, y - 1);
+        double *cur = row_cell(d, xmy);
+        double *low = m1 ? row_cell(m1, xmy - 1) : NULL;
+        double *mid = m2 ? row_cell(m2, xmy) : NULL;
+        double *up = m1 ? row_cell(m1, xmy + 1) : NULL;
+        if (ex) {
+            /* cX = sX->get(elements, x-1): for x-1 < 0 sequence_getKmer returns element 0 (:497-499) */
+            int64_t ix = x - 1 < 0 ? 0 : x - 1;
+            ex->ref_pos = c->ref_off + ix;
+            ex->ev_mean = ev[0];
+        }
+        cell_calculate(c->m, c->xp, mode, x, cur, low, mid, up, ev, ex);
+    }
+}
+
+/* cell_dotProduct :879-885, hdCell_totalProbability :828-843, dpDiagonal_dotProduct :1167-1180 */
+static double row_dot(const row_t *a, const row_t *b) {
+    double total = LOG_ZERO;
+    for (int64_t i = 0; i < a->width; i++) {
+        double cellTotal = LOG_ZERO;
+        int64_t np = a->coff[i + 1] - a->coff[i];
+        const double *ca = a->v + 3 * a->coff[i], *cb = b->v + 3 * b->coff[i];
+        for (int64_t p = 0; p < np; p++) { /* equal k-mers <=> equal path index */
+            double t = ca[3 * p] + cb[3 * p];
+            t = log_add(t, ca[3 * p + 1] + cb[3 * p + 1]);
+            t = log_add(t, ca[3 * p + 2] + cb[3 * p + 2]);
+            cellTotal = log_add(cellTotal, t);
+        }
+        total = log_add(total, cellTotal);
+    }
+    return total;
+}
+
+/* sparse matrix of live rows */
+typedef struct {
+    row_t **rows;
+    int64_t n;
+} mat_t;
+static mat_t mat_new(int64_t n) {
+    mat_t m;
+    m.n = n;
+    m.rows = calloc(n + 1, sizeof(row_t *));
+    return m;
+}
+static inline row_t *mat_get(const mat_t *m, int64_t xay) { return (xay < 0 || xay > m->n) ? NULL : m->rows[xay]; }
+static void mat_del(mat_t *m, int64_t xay) {
+    if (xay < 0 || xay > m->n) return;
+    row_free(m->rows[xay]);
+    m->rows[xay] = NULL;
+}
+static void mat_free(mat_t *m) {
+    for (int64_t i = 0; i <= m->n; i++) row_free(m->rows[i]);
+    free(m->rows);
+}
+
+/* diagonalCalculationTotalProbability: impl/pairwiseAligner.c:1335-1353 */
+static double total_probability(const ctx_t *c, int64_t xay, mat_t *F, mat_t *B) {
+    double total = row_dot(mat_get(F, xay), mat_get(B, xay));
+    row_t *f1 = mat_get(F, xay - 1), *b1 = mat_get(B, xay + 1);
+    if (b1 != NULL && f1 != NULL) {
+        row_t *md = row_new(b1->xay, b1->xmyL, b1->xmyR, c->xp);
+        row_zero(md);
+        diagonal_calculation(c, MODE_FWD, md, NULL, f1, NULL);
+        total = log_add(total, row_dot(md, b1));
+        row_free(md);
+    }
+    return total;
+}
+
+typedef struct {
+    sao_pair_t *a;
+    int64_t n, cap;
+} pairlist_t;
+static void pl_push(pairlist_t *l, sao_pair_t p) {
+    if (l->n == l->cap) {
+        l->cap = l->cap ? l->cap * 2 : 4096;
+        l->a = realloc(l->a, sizeof(sao_pair_t) * l->cap);
+    }
+    l->a[l->n++] = p;
+}
+
+/* diagonalCalculationPosteriorMatchProbs: impl/pairwiseAligner.c:1355-1421 */
+static void posterior_match_probs(const ctx_t *c, int64_t xay, mat_t *F, mat_t *B, double total, double threshold,
+                                  pairlist_t *out) {
+    row_t *f = mat_get(F, xay), *b = mat_get(B, xay);
+    for (int64_t i = 0; i < f->width; i++) {
+        int64_t xmy = f->xmyL + 2 * i;
+        int64_t x = diag_x(xay, xmy), y = diag_y(xay, xmy);
+        if (x > 0 && y > 0) {
+            int64_t np = f->coff[i + 1] - f->coff[i];
+            const double *cf = f->v + 3 * f->coff[i], *cb = b->v + 3 * b->coff[i];
+            const int32_t *ids = xp_ids(c->xp, x);
+            for (int64_t p = 0; p < np; p++) {
+                double pp = exp((cf[3 * p] + cb[3 * p]) - total);
+                if (pp >= threshold) {
+                    if (pp > 1.0) pp = 1.0;
+                    pp = floor(pp * PAIR_ALIGNMENT_PROB_1);
+                    sao_pair_t pr = {(int64_t) pp, x - 1, y - 1, (int32_t) p, ids[p]};
+                    pl_push(out, pr);
+                }
+            }
+        }
+    }
+}
+
+/* getPosteriorProbsWithBanding: impl/pairwiseAligner.c:1450-1590.
+ * mode_expect == 0: posteriors appended to `out`; == 1: expectations accumulated through ex. */
+static int banded(const ctx_t *c, const int64_t *ax, const int64_t *ay, int64_t n_anchors, const sao_params_t *p,
+                  int raggedL, int raggedR, int mode_expect, pairlist_t *out, expect_t *ex, double *likelihood,
+                  sao_stats_t *st) {
+    int64_t N = c->lX + c->lY;
+    if (N == 0) return 0;
+    int64_t *bL = malloc(sizeof(int64_t) * (N + 1)), *bR = malloc(sizeof(int64_t) * (N + 1));
+    if (sao_band(ax, ay, n_anchors, c->lX, c->lY, p->diagonal_expansion, bL, bR) != 0) {
+        free(bL);
+        free(bR);
+        return -1;
+    }
+    mat_t F = mat_new(N), B = mat_new(N);
+    double s[3];
+    F.rows[0] = row_new(0, bL[0], bR[0], c->xp);
+    state_start(c->m, raggedL, s);
+    row_init(F.rows[0], s);
+
+    int64_t tracedBackTo = 0;
+    int64_t idx = 1; /* forward band iterator: next diagonal handed out */
+    while (1) {
+        int64_t d = idx > N ? N : idx;
+        if (idx <= N) idx++;
+        F.rows[d] = row_new(d, bL[d], bR[d], c->xp);
+        row_zero(F.rows[d]);
+        diagonal_calculation(c, MODE_FWD, F.rows[d], mat_get(&F, d - 1), mat_get(&F, d - 2), NULL);
+        if (st) st->cells_forward += (double) F.rows[d]->coff[F.rows[d]->width];
+
+        int atEnd = d == N;
+        int tracebackPoint = d >= tracedBackTo + p->min_diags_between_trace_back &&
+                             F.rows[d]->width <= p->diagonal_expansion * 2 + 1;
+        if (atEnd || tracebackPoint) {
+            if (st) st->n_tracebacks++;
+            B.rows[d] = row_new(d, bL[d], bR[d], c->xp);
+            state_end(c->m, atEnd && raggedR, s);
+            row_init(B.rows[d], s);
+            if (d > tracedBackTo + 1) {
+                B.rows[d - 1] = row_new(d - 1, bL[d - 1], bR[d - 1], c->xp);
+                row_zero(B.rows[d - 1]);
+            }
+            int64_t d2 = d; /* bandIterator_getPrevious on a clone of the forward iterator */
+            int64_t tracedBackFrom = d - (atEnd ? 0 : p->trace_back_diagonals + 1);
+            double total = LOG_ZERO;
+            int64_t nThis = 0;
+            while (d2 > tracedBackTo) {
+                if (d2 > tracedBackTo + 2) {
+                    B.rows[d2 - 2] = row_new(d2 - 2, bL[d2 - 2], bR[d2 - 2], c->xp);
+                    row_zero(B.rows[d2 - 2]);
+                }
+                if (d2 > tracedBackTo + 1) {
+                    diagonal_calculation(c, MODE_BWD, B.rows[d2], mat_get(&B, d2 - 1), mat_get(&B, d2 - 2), NULL);
+                    if (st) st->cells_backward += (double) B.rows[d2]->coff[B.rows[d2]->width];
+                }
+                if (d2 <= tracedBackFrom) {
+                    if (nThis++ % 10 == 0) {
+                        total = total_probability(c, d2, &F, &B);
+                        if (st) st->n_total_prob++;
+                    }
+                    if (st) st->last_total_prob = total;
+                    if (!mode_expect) {
+                        posterior_match_probs(c, d2, &F, &B, total, p->threshold, out);
+                    } else {
+                        /* diagonalCalculation_Expectations :1423-1443 */
+                        *likelihood += total;
+                        ex->total = total;
+                        diagonal_calculation(c, MODE_EXPECT, B.rows[d2], mat_get(&F, d2 - 1), mat_get(&F, d2 - 2), ex);
+                    }
+                    if (d2 < tracedBackFrom || atEnd) mat_del(&F, d2);
+                }
+                if (d2 + 1 <= N) mat_del(&B, d2 + 1);
+                d2--; /* getPrevious */
+            }
+            tracedBackTo = tracedBackFrom;
+            mat_del(&B, d2 + 1);
+            mat_del(&F, d2);
+        }
+        if (atEnd) break;
+    }
+    mat_free(&F);
+    mat_free(&B);
+    free(bL);
+    free(bR);
+    return 0;
+}
+
+/* getPosteriorProbsWithBandingSplittingAlignmentsByLargeGaps: impl/pairwiseAligner.c:1953-2016
+ * + alignedPairCoordinateCorrectionFn :2043-2050 (shift, then pop => reverse). */
+static int split_and_align(const sao_model_t *m, const char *ref, int64_t lX, const double *events, int64_t stride,
+                           int64_t lY, const int64_t *ax, const int64_t *ay, int64_t n_anchors,
+                           const sao_params_t *p, const char *const *ambig, int raggedL, int raggedR, int mode_expect,
+                           pairlist_t *aligned, expect_t *ex, double *likelihood, sao_stats_t *st) {
+    int64_t *sp = malloc(sizeof(int64_t) * 4 * (n_anchors + 2));
+    int64_t nsp = sao_split_points(ax, ay, n_anchors, lX, lY, p->split_matrix_bigger_than_this, raggedL, raggedR, sp);
+    int64_t j = 0;
+    int rc = 0;
+    for (int64_t i = 0; i < nsp && rc == 0; i++) {
+        int64_t x1 = sp[4 * i], y1 = sp[4 * i + 1], x2 = sp[4 * i + 2], y2 = sp[4 * i + 3];
+        int64_t j0 = j;
+        while (j < n_anchors) {
+            if (ax[j] + ay[j] >= x2 + y2) break;
+            j++;
+        }
+        int64_t ns = j - j0;
+        int64_t *sx = malloc(sizeof(int64_t) * (ns + 1)), *sy = malloc(sizeof(int64_t) * (ns + 1));
+        for (int64_t t = 0; t < ns; t++) {
+            sx[t] = ax[j0 + t] - x1;
+            sy[t] = ay[j0 + t] - y1;
+        }
+        xpaths_t xp;
+        if (xpaths_build(&xp, m, ref + x1, x2 - x1, ambig) != 0) {
+            free(sx);
+            free(sy);
+            rc = -2;
+            break;
+        }
+        ctx_t c = {m, &xp, x1, events + y1 * stride, stride, x2 - x1, y2 - y1};
+        pairlist_t sub = {0};
+        rc = banded(&c, sx, sy, ns, p, raggedL || i > 0, raggedR || i < nsp - 1, mode_expect, &sub, ex, likelihood, st);
+        if (!mode_expect) {
+            for (int64_t t = sub.n - 1; t >= 0; t--) { /* pop => reverse */
+                sao_pair_t pr = sub.a[t];
+                pr.x += x1;
+                pr.y += y1;
+                pl_push(aligned, pr);
+            }
+        }
+        free(sub.a);
+        xpaths_free(&xp);
+        free(sx);
+        free(sy);
+    }
+    free(sp);
+    return rc;
+}
+
+/* stable merge sort by x + y (glibc qsort is a merge sort: impl/signalMachine.c:872, impl/pairwiseAligner.c:1604) */
+static void stable_sort_xay(sao_pair_t *a, int64_t n) {
+    if (n < 2) return;
+    sao_pair_t *tmp = malloc(sizeof(sao_pair_t) * n);
+    for (int64_t w = 1; w < n; w *= 2) {
+        for (int64_t lo = 0; lo < n; lo += 2 * w) {
+            int64_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+            int64_t i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) {
+                if (a[j].x + a[j].y < a[i].x + a[i].y) tmp[k++] = a[j++];
+                else tmp[k++] = a[i++];
+            }
+            while (i < mid) tmp[k++] = a[i++];
+            while (j < hi) tmp[k++] = a[j++];
+        }
+        memcpy(a, tmp, sizeof(sao_pair_t) * n);
+    }
+    free(tmp);
+}
+
+int64_t sao_align(const sao_model_t *m, const char *ref, int64_t lX, const double *events, int64_t stride, int64_t lY,
+                  const int64_t *ax, const int64_t *ay, int64_t n_anchors, const sao_params_t *p,
+                  const char *const *ambig, int raggedL, int raggedR, int sort_output, sao_pair_t **pairs_out,
+                  sao_stats_t *stats) {
+    pairlist_t aligned = {0};
+    if (stats) memset(stats, 0, sizeof(*stats));
+    int rc = split_and_align(m, ref, lX, events, stride, lY, ax, ay, n_anchors, p, ambig, raggedL, raggedR, 0,
+                             &aligned, NULL, NULL, stats);
+    if (rc != 0) {
+        free(aligned.a);
+        return rc;
+    }
+    if (sort_output) stable_sort_xay(aligned.a, aligned.n);
+    *pairs_out = aligned.a;
+    return aligned.n;
+}
+
+int64_t sao_expectations(const sao_model_t *m, const char *ref, int64_t lX, const double *events, int64_t stride,
+                         int64_t lY, const int64_t *ax, const int64_t *ay, int64_t n_anchors, const sao_params_t *p,
+                         const char *const *ambig, double *trans9, double *likelihood, int64_t **assign_kmer,
+                         double **assign_event, sao_stats_t *stats) {
+    int64_t n_assign = 0, cap_assign = 0;
+    expect_t ex;
+    memset(&ex, 0, sizeof(ex));
+    ex.trans9 = trans9;
+    ex.threshold = p->threshold;
+    ex.collect_assign = (m->emission == SAO_EM_HDP) && assign_kmer != NULL;
+    int64_t *ak = NULL;
+    double *ae = NULL;
+    ex.assign_kmer = &ak;
+    ex.assign_event = &ae;
+    ex.n_assign = &n_assign;
+    ex.cap_assign = &cap_assign;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    int rc = split_and_align(m, ref, lX, events, stride, lY, ax, ay, n_anchors, p, ambig, 1, 1, 1, NULL, &ex,
+                             likelihood, stats);
+    if (assign_kmer) *assign_kmer = ak; else free(ak);
+    if (assign_event) *assign_event = ae; else free(ae);
+    return rc != 0 ? rc : n_assign;
+}
+
+/* tests/stateMachineTests.c:441-565 */
+int64_t sao_kat_unbanded(const sao_model_t *m, const char *ref, int64_t lX, const double *events, int64_t stride,
+                         int64_t lY, double threshold, const char *const *ambig, double *total_forward,
+                         double *total_backward, double *diag_totals, sao_pair_t **pairs_out) {
+    xpaths_t xp;
+    if (xpaths_build(&xp, m, ref, lX, ambig) != 0) return -2;
+    ctx_t c = {m, &xp, 0, events, stride, lX, lY};
+    int64_t N = lX + lY;
+    int64_t *bL = malloc(sizeof(int64_t) * (N + 1)), *bR = malloc(sizeof(int64_t) * (N + 1));
+    sao_band(NULL, NULL, 0, lX, lY, 2, bL, bR);
+    mat_t F = mat_new(N), B = mat_new(N);
+    for (int64_t i = 0; i <= N; i++) {
+        F.rows[i] = row_new(i, bL[i], bR[i], &xp);
+        row_zero(F.rows[i]);
+        B.rows[i] = row_new(i, bL[i], bR[i], &xp);
+        row_zero(B.rows[i]);
+    }
+    double s[3], e[3];
+    state_start(m, 0, s);
+    row_init(F.rows[0], s);
+    state_end(m, 0, e);
+    row_init(B.rows[N], e);
+    for (int64_t i = 1; i <= N; i++) diagonal_calculation(&c, MODE_FWD, F.rows[i], mat_get(&F, i - 1), mat_get(&F, i - 2), NULL);
+    for (int64_t i = N; i > 0; i--) diagonal_calculation(&c, MODE_BWD, B.rows[i], mat_get(&B, i - 1), mat_get(&B, i - 2), NULL);
+    /* cell_dotProduct2 :887-893 over the paths of the corner cells */
+    double tF = LOG_ZERO;
+    {
+        double *cell = row_cell(F.rows[N], lX - lY);
+        int64_t np = xp_n(&xp, lX);
+        for (int64_t q = 0; q < np; q++) {
+            double t = cell[3 * q] + e[0];
+            t = log_add(t, cell[3 * q + 1] + e[1]);
+            t = log_add(t, cell[3 * q + 2] + e[2]);
+            tF = log_add(tF, t);
+        }
+    }
+    double tB = LOG_ZERO;
+    {
+        double *cell = row_cell(B.rows[0], 0);
+        double t = cell[0] + s[0];
+        t = log_add(t, cell[1] + s[1]);
+        t = log_add(t, cell[2] + s[2]);
+        tB = log_add(tB, t);
+    }
+    *total_forward = tF;
+    *total_backward = tB;
+    for (int64_t i = 0; i <= N; i++) diag_totals[i] = total_probability(&c, i, &F, &B);
+    pairlist_t out = {0};
+    for (int64_t i = 1; i <= N; i++) posterior_match_probs(&c, i, &F, &B, tF, threshold, &out);
+    *pairs_out = out.a;
+    mat_free(&F);
+    mat_free(&B);
+    free(bL);
+    free(bR);
+    xpaths_free(&xp);
+    return out.n;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Host-side preparation.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { int64_t x, y; } xy_t;
+static int cmp_xy(const void *a, const void *b) { /* stIntTuple_cmpFn: lexicographic */
+    const xy_t *p = a, *q = b;
+    if (p->x != q->x) return p->x < q->x ? -1 : 1;
+    if (p->y != q->y) return p->y < q->y ? -1 : 1;
+    return 0;
+}
+
+/* filterToRemoveOverlap: impl/pairwiseAligner.c:1755-1796.  Input must be sorted. */
+int64_t sao_filter_overlap(const int64_t *ax, const int64_t *ay, int64_t n, int64_t *ox, int64_t *oy) {
+    uint8_t *keep = calloc(n > 0 ? n : 1, 1);
+    int64_t pX = INT64_MAX, pY = INT64_MAX;
+    for (int64_t i = n - 1; i >= 0; i--) {
+        int64_t x = ax[i], y = ay[i];
+        if (x < pX && y < pY) keep[i] = 1; /* a set of VALUES in the reference: duplicates handled below */
+        pX = x < pX ? x : pX;
+        pY = y < pY ? y : pY;
+    }
+    /* the reference's set is keyed by value: a later duplicate that was inserted makes an earlier equal pair "found" */
+    for (int64_t i = n - 2; i >= 0; i--)
+        if (!keep[i] && ax[i] == ax[i + 1] && ay[i] == ay[i + 1] && keep[i + 1]) keep[i] = 1;
+    int64_t m = 0;
+    pX = INT64_MIN;
+    pY = INT64_MIN;
+    for (int64_t i = 0; i < n; i++) {
+        int64_t x = ax[i], y = ay[i];
+        if (x > pX && y > pY && keep[i]) {
+            ox[m] = x;
+            oy[m] = y;
+            m++;
+        }
+        pX = x > pX ? x : pX;
+        pY = y > pY ? y : pY;
+    }
+    free(keep);
+    return m;
+}
+
+int64_t sao_guide_to_anchors(int64_t start1, int64_t end1, int strand1, int64_t start2, const int32_t *op_type,
+                             const int64_t *op_len, int64_t n_ops, int64_t trim, int64_t *ax, int64_t *ay,
+                             int64_t cap) {
+    /* signalUtils_rebasePairwiseAlignmentCoordinates: impl/signalMachineUtils.c:130-151 */
+    int64_t shift = strand1 ? start1 : end1;
+    int64_t s1 = start1 - shift, e1 = end1 - shift;
+    if (!strand1) {
+        int64_t t = e1;
+        e1 = s1;
+        s1 = t;
+    }
+    /* convertPairwiseForwardStrandAlignmentToAnchorPairs: impl/pairwiseAligner.c:1624-1658 */
+    int64_t n = 0, j = s1, k = start2;
+    xy_t *tmp = malloc(sizeof(xy_t) * (cap > 0 ? cap : 1));
+    for (int64_t i = 0; i < n_ops; i++) {
+        if (op_type[i] == 0) {
+            for (int64_t l = trim; l < op_len[i] - trim; l++)
+                if (e1 >= j + l + 6 && n < cap) {
+                    tmp[n].x = j + l;
+                    tmp[n].y = k + l;
+                    n++;
+                }
+        }
+        if (op_type[i] != 2) j += op_len[i];
+        if (op_type[i] != 1) k += op_len[i];
+    }
+    qsort(tmp, n, sizeof(xy_t), cmp_xy);
+    int64_t *tx = malloc(sizeof(int64_t) * (n + 1)), *ty = malloc(sizeof(int64_t) * (n + 1));
+    for (int64_t i = 0; i < n; i++) {
+        tx[i] = tmp[i].x;
+        ty[i] = tmp[i].y;
+    }
+    int64_t m = sao_filter_overlap(tx, ty, n, ax, ay);
+    free(tmp);
+    free(tx);
+    free(ty);
+    return m;
+}
+
+int64_t sao_remap_anchors(const int64_t *ax, const int64_t *ay, int64_t n, const int64_t *event_map,
+                          int64_t map_offset, int64_t *ox, int64_t *oy) {
+    int64_t *tx = malloc(sizeof(int64_t) * (n + 1)), *ty = malloc(sizeof(int64_t) * (n + 1));
+    for (int64_t i = 0; i < n; i++) {
+        tx[i] = ax[i];
+        ty[i] = event_map[ay[i]] - event_map[map_offset];
+    }
+    int64_t m = sao_filter_overlap(tx, ty, n, ox, oy);
+    free(tx);
+    free(ty);
+    return m;
+}
+
+/* nanopore_lineq_solve: impl/nanopore.c:692-753 (including its swap quirk) */
+#define MACHEP 1.11022302462515654042E-16
+static void lineq_solve(const double *A, const double *b, double *x_out, int64_t n) {
+    double *aux = malloc(sizeof(double) * n * n);
+    for (int64_t i = 0; i < n; i++) {
+        x_out[i] = b[i];
+        for (int64_t j = 0; j < n; j++) aux[i * n + j] = A[i * n + j];
+    }
+    double factor;
+    for (int64_t i = 0; i < n; i++) {
+        if (fabs(aux[i * n + i]) < MACHEP) {
+            int64_t swap = i + 1;
+            while (aux[swap * n + i] < MACHEP) {
+                swap++;
+                if (swap >= n) {
+                    fprintf(stderr, "Matrix is not invertible.\n");
+                    exit(EXIT_FAILURE);
+                }
+            }
+            double temp;
+            for (int64_t j = 0; j < n; j++) {
+                temp = aux[i * n + j];
+                aux[i * n + j] = aux[swap * n + j];
+                aux[swap * n + j] = temp;
+            }
+            temp = x_out[i];
+            x_out[i] = x_out[swap];
+            x_out[swap] = x_out[i];
+            (void) temp;
+        }
+        factor = 1.0 / aux[i * n + i];
+        x_out[i] *= factor;
+        for (int64_t j = 0; j < n; j++) aux[i * n + j] *= factor;
+        for (int64_t sub = i + 1; sub < n; sub++) {
+            factor = aux[sub * n + i];
+            x_out[sub] -= factor * x_out[i];
+            for (int64_t j = 0; j < n; j++) aux[sub * n + j] -= factor * aux[i * n + j];
+        }
+    }
+    for (int64_t i = n - 1; i >= 0; i--)
+        for (int64_t sub = i - 1; sub >= 0; sub--) {
+            factor = aux[sub * n + i];
+            x_out[sub] -= factor * x_out[i];
+            for (int64_t j = 0; j < n; j++) aux[sub * n + j] -= factor * aux[i * n + j];
+        }
+    free(aux);
+}
+
+int sao_estimate_params(sao_model_t *m, const int64_t *strand_event_map, double *events, int64_t n_events,
+                        const char *strand_read, int64_t read_len, double *out7) {
+    /* nanopore_getOneDAssignmentsFromRead: impl/nanopore.c:601-631 */
+    int64_t rows = read_len - (m->k - 1);
+    int64_t n = 0;
+    double *eMean = malloc(sizeof(double) * (rows > 0 ? rows : 1)), *eSd = malloc(sizeof(double) * (rows > 0 ? rows : 1)),
+           *eDt = malloc(sizeof(double) * (rows > 0 ? rows : 1));
+    int64_t *eK = malloc(sizeof(int64_t) * (rows > 0 ? rows : 1));
+    int64_t prev = -1;
+    for (int64_t i = 0; i < rows; i++) {
+        int64_t ei = strand_event_map[i];
+        int64_t kid = sao_kmer_id(strand_read + i, m->alphabet, m->n_alpha, m->k);
+        if (kid < 0) return -1;
+        if (ei > prev) {
+            eMean[n] = events[ei * 4];
+            eSd[n] = events[ei * 4 + 1];
+            eDt[n] = events[ei * 4 + 3];
+            eK[n] = kid;
+            n++;
+            prev = ei;
+        }
+    }
+    if (n == 0) return -2;
+    const double *model = m->match5;
+    /* nanopore_compute_mean_scale_params(drift_out=TRUE, var_out=TRUE): impl/nanopore.c:756-827 */
+    double XWX[9] = {0}, XWy[3] = {0}, beta[3];
+    for (int64_t i = 0; i < n; i++) {
+        double event = eMean[i], time = eDt[i];
+        int64_t id = eK[i];
+        double level_mean = model[id * MODEL_PARAMS], level_sd = model[id * MODEL_PARAMS + 1];
+        double inv_var = 1.0 / (level_sd * level_sd);
+        double scaled_mean = level_mean * inv_var, scaled_time = time * inv_var;
+        XWX[0] += inv_var;
+        XWX[1] += scaled_mean;
+        XWX[2] += scaled_time;
+        XWX[4] += scaled_mean * level_mean;
+        XWX[5] += scaled_mean * time;
+        XWX[8] += scaled_time * time;
+        XWy[0] += inv_var * event;
+        XWy[1] += scaled_mean * event;
+        XWy[2] += scaled_time * event;
+    }
+    XWX[3] = XWX[1];
+    XWX[6] = XWX[2];
+    XWX[7] = XWX[5];
+    lineq_solve(XWX, XWy, beta, 3);
+    double shift = beta[0], scale = beta[1], drift = beta[2];
+    double dispersion = 0.0;
+    for (int64_t i = 0; i < n; i++) {
+        int64_t id = eK[i];
+        double level_mean = model[id * MODEL_PARAMS], level_sd = model[id * MODEL_PARAMS + 1];
+        double level_var = level_sd * level_sd;
+        double predicted = beta[0] + beta[1] * level_mean + beta[2] * eDt[i];
+        double residual = eMean[i] - predicted;
+        dispersion += (residual * residual) / level_var;
+    }
+    double var = sqrt(dispersion / n);
+    /* nanopore_compute_noise_scale_params: impl/nanopore.c:889-954 */
+    double A4[4] = {0}, y2[2] = {0}, b2[2];
+    for (int64_t i = 0; i < n; i++) {
+        int64_t id = eK[i];
+        double noise = eSd[i];
+        double noise_mean = model[id * MODEL_PARAMS + 2], noise_sd = model[id * MODEL_PARAMS + 3];
+        double inv_var = 1.0 / (noise_sd * noise_sd);
+        double scaled_mean = noise_mean * inv_var;
+        A4[0] += inv_var;
+        A4[1] += scaled_mean;
+        A4[3] += scaled_mean * noise_mean;
+        y2[0] += inv_var * noise;
+        y2[1] += scaled_mean * noise;
+    }
+    A4[2] = A4[1];
+    lineq_solve(A4, y2, b2, 2);
+    double shift_sd = b2[0], scale_sd = b2[1];
+    dispersion = 0.0;
+    for (int64_t i = 0; i < n; i++) {
+        int64_t id = eK[i];
+        double noise_mean = model[id * MODEL_PARAMS + 2], noise_sd = model[id * MODEL_PARAMS + 3];
+        double level_var = noise_sd * noise_sd;
+        double predicted = b2[0] + b2[1] * noise_mean;
+        double residual = eSd[i] - predicted;
+        dispersion += (residual * residual) / level_var;
+    }
+    double var_sd = sqrt(dispersion / n);
+    out7[0] = scale; out7[1] = shift; out7[2] = var; out7[3] = drift;
+    out7[4] = scale_sd; out7[5] = var_sd; out7[6] = shift_sd;
+    m->scale = scale;
+    m->shift = shift;
+    m->var = var;
+    /* nanopore_adjustEventsForDriftP: impl/nanopore.c:633-638 */
+    for (int64_t i = 0; i < n_events; i++) events[i * 4] = events[i * 4] - (events[i * 4 + 3] * drift);
+    /* emissions_signal_scaleNoise */
+    sao_model_scale_noise(m, scale_sd, var_sd);
+    free(eMean);
+    free(eSd);
+    free(eDt);
+    free(eK);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-threaded batch driver (cpu_baseline leg of bench.py): one read per thread at a time.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const sao_model_t *m;
+    const sao_job_t *jobs;
+    int64_t n_jobs;
+    const sao_params_t *p;
+    int64_t *n_pairs;
+    double *cells;
+    int64_t *next;
+    pthread_mutex_t *mu;
+    const char *const *ambig;
+} mt_t;
+
+static void *mt_worker(void *arg) {
+    mt_t *t = arg;
+    for (;;) {
+        pthread_mutex_lock(t->mu);
+        int64_t i = (*t->next)++;
+        pthread_mutex_unlock(t->mu);
+        if (i >= t->n_jobs) break;
+        sao_model_t local = *t->m; /* per-read scale/shift/var */
+        local.scale = t->jobs[i].scale;
+        local.shift = t->jobs[i].shift;
+        local.var = t->jobs[i].var;
+        sao_pair_t *pairs = NULL;
+        sao_stats_t st;
+        int64_t n = sao_align(&local, t->jobs[i].ref, t->jobs[i].lX, t->jobs[i].events, t->jobs[i].stride,
+                              t->jobs[i].lY, t->jobs[i].ax, t->jobs[i].ay, t->jobs[i].n_anchors, t->p, t->ambig, 1, 1,
+                              1, &pairs, &st);
+        free(pairs);
+        if (t->n_pairs) t->n_pairs[i] = n;
+        if (t->cells) t->cells[i] = st.cells_forward + st.cells_backward;
+    }
+    return NULL;
+}
+
+int sao_align_batch_mt(const sao_model_t *m, const sao_job_t *jobs, int64_t n_jobs, const sao_params_t *p,
+                       int n_threads, int64_t *n_pairs_out, double *cells_out) {
+    const char *ambig[256];
+    sao_default_ambig(ambig);
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    int64_t next = 0;
+    mt_t t = {m, jobs, n_jobs, p, n_pairs_out, cells_out, &next, &mu, ambig};
+    if (n_threads < 1) n_threads = 1;
+    pthread_t *th = malloc(sizeof(pthread_t) * n_threads);
+    for (int i = 0; i < n_threads; i++) pthread_create(&th[i], NULL, mt_worker, &t);
+    for (int i = 0; i < n_threads; i++) pthread_join(th[i], NULL);
+    free(th);
+    return 0;
+}
