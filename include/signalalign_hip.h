@@ -1,0 +1,189 @@
+/*
+ * signalalign_hip.h -- C ABI of libsignalalign_hip.so: the MI355X-native replacement for
+ * signalAlign's banded pair-HMM forward/backward/posterior path.
+ *
+ * Plain C: pointers and sizes only.  Every entry point names the reference interface it replaces
+ * (paths relative to the upstream signalAlign tree).  The library never exits the process; it
+ * returns 0 or a negative SA_E* code (sa_strerror()).  All device work is hand-written HIP for
+ * gfx950; there is NO CPU fallback: without a usable GPU sa_batch_create()/sa_batch_run() fail with
+ * SA_ENODEVICE.
+ *
+ * The seam is getAlignedPairsUsingAnchors()/getExpectationsUsingAnchors()
+ * (inc/pairwiseAligner.h:406-429): a state machine, a k-mer sequence, an event sequence, a list of
+ * anchor pairs and banding parameters go in; (floor(p*1e7), x, y, path k-mer) tuples come out.
+ * Here the same call is batched over many reads so one launch fills the GPU.
+ */
+#ifndef SIGNALALIGN_HIP_H_
+#define SIGNALALIGN_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SA_OK 0
+#define SA_EINVAL (-1)     /* bad argument                                        */
+#define SA_ENOMEM (-2)     /* host or device allocation failed                    */
+#define SA_ENODEVICE (-3)  /* no usable HIP device / HIP runtime error            */
+#define SA_EALPHABET (-4)  /* reference k-mer has a character outside the alphabet
+                              (the reference aborts in kmer_to_word, impl/nanopore_hdp.c:387-403) */
+#define SA_EBAND (-5)      /* anchors produce an invalid diagonal (diagonal_construct throws,
+                              impl/pairwiseAligner.c:98-103)                       */
+#define SA_EIO (-6)        /* file could not be read / parsed                     */
+#define SA_ESTATE (-7)     /* call out of order (e.g. results before run)         */
+#define SA_EUNSUPPORTED (-8)
+
+/* flags for sa_batch_create */
+#define SA_FLAG_EXACT 1u          /* reference-ordered, un-contracted fp64 arithmetic on the device
+                                     (slow kernels; bit-identical posteriors for Gaussian emissions) */
+#define SA_FLAG_FORCE_GENERIC 2u  /* never pick the register-resident fast kernels */
+
+typedef struct sa_model sa_model_t; /* replaces StateMachine3 / StateMachine3_HDP (inc/stateMachine.h:150-190) */
+typedef struct sa_batch sa_batch_t;
+
+/* PairwiseAlignmentParameters (inc/pairwiseAligner.h, defaults impl/pairwiseAligner.c:2022-2037) */
+typedef struct sa_params {
+    double threshold;                      /* -D */
+    int64_t diagonal_expansion;            /* -x, must be even (signalMachine rounds up: impl/signalMachine.c:675) */
+    int64_t trace_back_diagonals;          /* -g */
+    int64_t min_diags_between_trace_back;  /* 1000 */
+    int64_t split_matrix_bigger_than_this; /* 3000*3000 */
+} sa_params_t;
+
+/* the slice of a deserialised .nhdp that alignment reads (impl/hdp.c:2588-2612, :2777-2806) */
+typedef struct sa_hdp_desc {
+    int64_t num_dps;
+    int64_t grid_length;
+    double grid_start, grid_stop;
+    const int64_t *parent;        /* num_dps, -1 for the root                      */
+    const uint8_t *observed;      /* num_dps (mark_observed_dps, impl/hdp.c:1132)  */
+    const double *const *post_pred; /* num_dps pointers, NULL where unobserved     */
+    const double *const *slopes;    /* num_dps pointers, NULL where absent         */
+} sa_hdp_desc_t;
+
+/* one alignment = one strand of one read: the arguments of getAlignedPairsUsingAnchors() */
+typedef struct sa_job {
+    const char *ref;        /* target nucleotides (may hold ambiguity letters); lX = ref_len - (k-1) */
+    int64_t ref_len;
+    const double *events;   /* event i's mean at events[i*event_stride]; already sliced to the guide alignment
+                               (makeEventSequenceFromPairwiseAlignment, impl/signalMachine.c:442) and drift-adjusted */
+    int64_t event_stride;   /* in doubles: 4 for the NB_EVENT_PARAMS layout, 1 for a dense mean vector */
+    int64_t n_events;
+    const int64_t *anchor_x; /* remapped + filtered anchors, (k-mer index, event index)  */
+    const int64_t *anchor_y;
+    int64_t n_anchors;
+    double scale, shift, var; /* sM->scale/shift/var for this read (impl/signalMachine.c:755-757) */
+} sa_job_t;
+
+/* stIntTuple4(floor(p*1e7), x, y, (char*)pathKmer)  (impl/pairwiseAligner.c:1405-1408) */
+typedef struct sa_pair {
+    int64_t prob_e7;
+    int32_t x, y;
+    int32_t path;    /* index of the path inside the cell (order of hdCell_construct2) */
+    int32_t kmer_id; /* kmer_id() of the path's k-mer                                  */
+} sa_pair_t;
+
+typedef struct sa_batch_stats {
+    double cells_forward;    /* sum over forward diagonals of width*paths           */
+    double cells_backward;   /* ditto for backward diagonals actually computed      */
+    double ms_forward;       /* HIP-event time of the forward kernels, last run     */
+    double ms_backward;      /* backward+posterior kernels                          */
+    double ms_fold;          /* total-probability fold kernel                       */
+    double ms_total_device;  /* first launch -> last kernel end                     */
+    double f_bytes;          /* bytes of forward storage written (== read back)     */
+    int64_t n_regions, n_segments, n_checkpoints;
+    int64_t n_fast_regions;  /* regions handled by the register-resident kernels    */
+    int64_t n_chunks;        /* passes needed to fit forward storage in HBM         */
+} sa_batch_stats_t;
+
+/* ---- model -------------------------------------------------------------------------------------
+ * Replaces stateMachine3_loadFromFile()'s result (impl/stateMachine.c:1440-1538):
+ *   transitions10: the 10 tokens of the transition line, linear space;
+ *   table5: 5*A^k doubles [level_mean level_sd noise_mean noise_sd noise_lambda] in kmer_id order.
+ * hdp != NULL selects the HDP emission (stateMachine3HDP_cellCalculate, impl/stateMachine.c:1371);
+ * the caller applies stateMachine3_setModelToHdpExpectedValues with sa_model_set_to_hdp_expected_values. */
+int sa_model_create(sa_model_t **out, int n_states, const char *alphabet, int k, const double *transitions10,
+                    const double *table5, const sa_hdp_desc_t *hdp);
+int sa_model_load(sa_model_t **out, const char *model_path, const char *nhdp_path_or_null);
+void sa_model_destroy(sa_model_t *m);
+int sa_model_alphabet(const sa_model_t *m, char *out64, int *n_alpha, int *k);
+const double *sa_model_table5(const sa_model_t *m);        /* EMISSION_MATCH_MATRIX view */
+int sa_model_set_to_hdp_expected_values(sa_model_t *m);    /* impl/stateMachine.c:1275-1304 */
+int64_t sa_kmer_id(const sa_model_t *m, const char *kmer); /* impl/nanopore_hdp.c:405-410 */
+
+/* ambiguity table: 256 entries (index = character), NULL = not ambiguous.
+ * sa_default_ambig fills create_ambig_bases() (impl/pairwiseAligner.c:32-65);
+ * sa_load_ambig reads the -a file (create_ambig_bases2, impl/pairwiseAligner.c:68-92); strings are
+ * owned by a static/heap pool that lives until the process ends. */
+void sa_default_ambig(const char **map256);
+int sa_load_ambig(const char *path, const char **map256);
+
+/* ---- batched getAlignedPairsUsingAnchors (impl/pairwiseAligner.c:2052-2080) --------------------
+ * create: host-side planning (split regions, band tables, traceback segments) + upload to HBM.
+ * run:    forward, backward/posterior and fold kernels; inputs are already resident.
+ * pairs:  rows in the order signalMachine writes them (stable sort by x+y of the reference's list). */
+int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs,
+                    int64_t n_jobs, const char *const *ambig256, int device, unsigned flags);
+int sa_batch_run(sa_batch_t *b);
+int sa_batch_n_pairs(const sa_batch_t *b, int64_t job, int64_t *n);
+int sa_batch_pairs(const sa_batch_t *b, int64_t job, sa_pair_t *out, int64_t cap);
+int sa_batch_stats(const sa_batch_t *b, sa_batch_stats_t *out);
+int sa_batch_job_cells(const sa_batch_t *b, int64_t job, double *cells_fwd, double *cells_bwd);
+void sa_batch_destroy(sa_batch_t *b);
+
+/* one-shot convenience: create + run + copy out.  pairs_out[j] is malloc'd (sa_free). */
+int sa_align_batch(const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs, int64_t n_jobs,
+                   const char *const *ambig256, int device, unsigned flags, sa_pair_t **pairs_out,
+                   int64_t *n_pairs_out);
+
+/* ---- batched getExpectationsUsingAnchors (impl/pairwiseAligner.c:2164-2184) --------------------
+ * trans9_out[j*9 + from*3 + to] and likelihood_out[j] are ADDED to (the caller seeds pseudocounts, as
+ * hmmContinuous_getExpectationsHmm does); HDP assignments (to==match && p>=threshold,
+ * impl/pairwiseAligner.c:946-968) come back as (reference position, event index) pairs. */
+typedef struct sa_assignment {
+    int64_t ref_pos;   /* index into job.ref of the cell's k-mer pointer (cX) */
+    int64_t event;     /* index into the job's event array (cY)               */
+} sa_assignment_t;
+int sa_expect_batch(const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs, int64_t n_jobs,
+                    const char *const *ambig256, int device, unsigned flags, double *trans9_out,
+                    double *likelihood_out, sa_assignment_t **assign_out, int64_t *n_assign_out);
+
+/* ---- planning introspection (host only, no GPU needed; used by the CPU test-suite) --------------
+ * Builds the plan for ONE job and reports its geometry. */
+typedef struct sa_plan_info {
+    int64_t n_regions, n_segments, n_checkpoints;
+    double cells_forward, cells_backward;
+    int64_t f_cellpaths;   /* cell-paths of forward storage */
+    int64_t max_span;      /* widest 3-row window in (x-y)/2 units          */
+    int64_t n_fast_regions;
+} sa_plan_info_t;
+int sa_plan_describe(const sa_model_t *m, const sa_params_t *p, const sa_job_t *job, const char *const *ambig256,
+                     unsigned flags, sa_plan_info_t *info,
+                     int64_t *regions4_out, int64_t regions_cap,   /* x1,y1,x2,y2 per region             */
+                     int64_t *rows3_out, int64_t rows_cap,         /* region,xmyL,xmyR per diagonal      */
+                     int64_t *segs4_out, int64_t segs_cap);        /* region,start,from,to per traceback */
+
+/* ---- host-side helpers that signalMachine needs around the seam --------------------------------- */
+/* signalUtils_guideAlignmentToRebasedAnchorPairs (impl/signalMachineUtils.c:142-164). op types:
+ * 0 = match, 1 = reference-only (PAIRWISE_INDEL_X), 2 = read-only (PAIRWISE_INDEL_Y). */
+int64_t sa_guide_to_anchors(int64_t start1, int64_t end1, int strand1, int64_t start2, const int32_t *op_type,
+                            const int64_t *op_len, int64_t n_ops, int64_t trim, int64_t *ax, int64_t *ay,
+                            int64_t cap);
+/* signalUtils_getRemappedAnchorPairs (impl/signalMachineUtils.c:166-170) */
+int64_t sa_remap_anchors(const int64_t *ax, const int64_t *ay, int64_t n, const int64_t *event_map,
+                         int64_t map_offset, int64_t *ox, int64_t *oy);
+/* signalUtils_estimateNanoporeParams (impl/signalMachineUtils.c:186-225): events (4 doubles each) are
+ * drift-corrected in place, table5 noise columns rescaled; out7 = scale shift var drift scale_sd var_sd shift_sd */
+int sa_estimate_params(const sa_model_t *m, double *table5_inout, const int64_t *strand_event_map, double *events4,
+                       int64_t n_events, const char *strand_read, int64_t read_len, double *out7);
+
+int sa_device_count(void);
+const char *sa_strerror(int code);
+const char *sa_version(void);
+void sa_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

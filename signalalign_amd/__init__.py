@@ -1,0 +1,14 @@
+"""signalalign_amd -- MI355X-native banded pair-HMM path of signalAlign.
+
+The product is the C-ABI shared library `lib/libsignalalign_hip.so` (see include/signalalign_hip.h) and
+the `bin/signalMachine` drop-in CLI; this package is a thin ctypes mirror of that ABI for tests, the
+benchmark and Python callers.  There is no CPU fallback: without the built library, or without a GPU
+for the compute calls, everything here raises.
+"""
+from ._capi import (Batch, Model, Params, SaError, build, default_ambig, default_params, device_count, lib,
+                    library_path, plan_describe, guide_to_anchors, remap_anchors, estimate_params, PAIR_DTYPE,
+                    FLAG_EXACT, FLAG_FORCE_GENERIC)
+
+__all__ = ["Batch", "Model", "Params", "SaError", "build", "default_ambig", "default_params", "device_count", "lib",
+           "library_path", "plan_describe", "guide_to_anchors", "remap_anchors", "estimate_params", "PAIR_DTYPE",
+           "FLAG_EXACT", "FLAG_FORCE_GENERIC"]

@@ -1,0 +1,320 @@
+"""ctypes mirror of include/signalalign_hip.h.  No arithmetic happens here."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+FLAG_EXACT = 1
+FLAG_FORCE_GENERIC = 2
+
+
+class SaError(RuntimeError):
+    def __init__(self, code, what=""):
+        self.code = code
+        msg = lib().sa_strerror(code).decode() if _LIB is not None else str(code)
+        super().__init__("%s: %s (%d)" % (what, msg, code))
+
+
+class Params(C.Structure):
+    _fields_ = [("threshold", C.c_double), ("diagonal_expansion", C.c_int64), ("trace_back_diagonals", C.c_int64),
+                ("min_diags_between_trace_back", C.c_int64), ("split_matrix_bigger_than_this", C.c_int64)]
+
+
+class HdpDesc(C.Structure):
+    _fields_ = [("num_dps", C.c_int64), ("grid_length", C.c_int64), ("grid_start", C.c_double),
+                ("grid_stop", C.c_double), ("parent", C.POINTER(C.c_int64)), ("observed", C.POINTER(C.c_uint8)),
+                ("post_pred", C.POINTER(C.POINTER(C.c_double))), ("slopes", C.POINTER(C.POINTER(C.c_double)))]
+
+
+class Job(C.Structure):
+    _fields_ = [("ref", C.c_char_p), ("ref_len", C.c_int64), ("events", C.POINTER(C.c_double)),
+                ("event_stride", C.c_int64), ("n_events", C.c_int64), ("anchor_x", C.POINTER(C.c_int64)),
+                ("anchor_y", C.POINTER(C.c_int64)), ("n_anchors", C.c_int64), ("scale", C.c_double),
+                ("shift", C.c_double), ("var", C.c_double)]
+
+
+class Pair(C.Structure):
+    _fields_ = [("prob_e7", C.c_int64), ("x", C.c_int32), ("y", C.c_int32), ("path", C.c_int32),
+                ("kmer_id", C.c_int32)]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [("cells_forward", C.c_double), ("cells_backward", C.c_double), ("ms_forward", C.c_double),
+                ("ms_backward", C.c_double), ("ms_fold", C.c_double), ("ms_total_device", C.c_double),
+                ("f_bytes", C.c_double), ("n_regions", C.c_int64), ("n_segments", C.c_int64),
+                ("n_checkpoints", C.c_int64), ("n_fast_regions", C.c_int64), ("n_chunks", C.c_int64)]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [("n_regions", C.c_int64), ("n_segments", C.c_int64), ("n_checkpoints", C.c_int64),
+                ("cells_forward", C.c_double), ("cells_backward", C.c_double), ("f_cellpaths", C.c_int64),
+                ("max_span", C.c_int64), ("n_fast_regions", C.c_int64)]
+
+
+PAIR_DTYPE = np.dtype([("prob_e7", "<i8"), ("x", "<i4"), ("y", "<i4"), ("path", "<i4"), ("kmer_id", "<i4")])
+
+EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alphabet", "sa_model_table5",
+           "sa_model_set_to_hdp_expected_values", "sa_kmer_id", "sa_default_ambig", "sa_load_ambig",
+           "sa_batch_create", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_stats",
+           "sa_batch_job_cells", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_plan_describe",
+           "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_device_count", "sa_strerror",
+           "sa_version", "sa_free"]
+
+
+def library_path():
+    return os.path.join(_HERE, "lib", "libsignalalign_hip.so")
+
+
+def build(force=False):
+    """Compile the HIP library and the CLI in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    so = library_path()
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "signalalign_hip.h"))
+    stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = library_path()
+    if not os.path.exists(so):
+        raise ImportError("libsignalalign_hip.so is not built (run __graft_entry__.build()); there is no fallback")
+    L = C.CDLL(so)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int64)
+    L.sa_strerror.restype = C.c_char_p
+    L.sa_strerror.argtypes = [C.c_int]
+    L.sa_version.restype = C.c_char_p
+    L.sa_device_count.restype = C.c_int
+    L.sa_model_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_int, dp, dp, C.POINTER(HdpDesc)]
+    L.sa_model_load.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p]
+    L.sa_model_destroy.argtypes = [C.c_void_p]
+    L.sa_model_alphabet.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.sa_model_table5.restype = dp
+    L.sa_model_table5.argtypes = [C.c_void_p]
+    L.sa_model_set_to_hdp_expected_values.argtypes = [C.c_void_p]
+    L.sa_kmer_id.restype = C.c_int64
+    L.sa_kmer_id.argtypes = [C.c_void_p, C.c_char_p]
+    L.sa_default_ambig.argtypes = [C.POINTER(C.c_char_p)]
+    L.sa_load_ambig.argtypes = [C.c_char_p, C.POINTER(C.c_char_p)]
+    L.sa_batch_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(Params), C.POINTER(Job), C.c_int64,
+                                  C.POINTER(C.c_char_p), C.c_int, C.c_uint]
+    L.sa_batch_run.argtypes = [C.c_void_p]
+    L.sa_batch_n_pairs.argtypes = [C.c_void_p, C.c_int64, ip]
+    L.sa_batch_pairs.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+    L.sa_batch_stats.argtypes = [C.c_void_p, C.POINTER(BatchStats)]
+    L.sa_batch_job_cells.argtypes = [C.c_void_p, C.c_int64, dp, dp]
+    L.sa_batch_destroy.argtypes = [C.c_void_p]
+    L.sa_plan_describe.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Job), C.POINTER(C.c_char_p), C.c_uint,
+                                   C.POINTER(PlanInfo), ip, C.c_int64, ip, C.c_int64, ip, C.c_int64]
+    L.sa_guide_to_anchors.restype = C.c_int64
+    L.sa_guide_to_anchors.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int64, C.POINTER(C.c_int32), ip, C.c_int64,
+                                      C.c_int64, ip, ip, C.c_int64]
+    L.sa_remap_anchors.restype = C.c_int64
+    L.sa_remap_anchors.argtypes = [ip, ip, C.c_int64, ip, C.c_int64, ip, ip]
+    L.sa_estimate_params.argtypes = [C.c_void_p, dp, ip, dp, C.c_int64, C.c_char_p, C.c_int64, dp]
+    L.sa_free.argtypes = [C.c_void_p]
+    _LIB = L
+    return L
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise SaError(rc, what)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def device_count():
+    return lib().sa_device_count()
+
+
+def default_params(threshold=0.01, expansion=50, trace_back=100, min_diags=1000, split=3000 * 3000):
+    """signalMachine defaults (impl/signalMachine.c:487-490) with the Python driver's -g 100."""
+    e = expansion if expansion % 2 == 0 else expansion + 1
+    return Params(threshold, e, trace_back, min_diags, split)
+
+
+def default_ambig(table=None):
+    arr = (C.c_char_p * 256)()
+    if table is None:
+        lib().sa_default_ambig(arr)
+    else:
+        for k, v in table.items():
+            arr[ord(k)] = v.encode()
+    return arr
+
+
+class Model:
+    """StateMachine3 / StateMachine3_HDP as the C library holds it."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def create(cls, alphabet, k, transitions10, table5, hdp=None):
+        h = C.c_void_p()
+        t10 = np.ascontiguousarray(transitions10, dtype=np.float64)
+        tb = np.ascontiguousarray(table5, dtype=np.float64)
+        _chk(lib().sa_model_create(C.byref(h), 3, alphabet.encode(), k, _dp(t10), _dp(tb), hdp), "sa_model_create")
+        return cls(h)
+
+    @classmethod
+    def load(cls, model_path, nhdp_path=None):
+        h = C.c_void_p()
+        _chk(lib().sa_model_load(C.byref(h), model_path.encode(), nhdp_path.encode() if nhdp_path else None),
+             "sa_model_load")
+        return cls(h)
+
+    def alphabet(self):
+        buf = C.create_string_buffer(64)
+        na, k = C.c_int(), C.c_int()
+        lib().sa_model_alphabet(self._h, buf, C.byref(na), C.byref(k))
+        return buf.value.decode(), k.value
+
+    def table5(self):
+        alpha, k = self.alphabet()
+        n = 5 * len(alpha) ** k
+        return np.ctypeslib.as_array(lib().sa_model_table5(self._h), shape=(n,))
+
+    def kmer_id(self, kmer):
+        return lib().sa_kmer_id(self._h, kmer.encode())
+
+    def set_to_hdp_expected_values(self):
+        _chk(lib().sa_model_set_to_hdp_expected_values(self._h), "sa_model_set_to_hdp_expected_values")
+
+    def close(self):
+        if self._h:
+            lib().sa_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _make_jobs(jobs):
+    """jobs: list of dicts(ref:str, events: (n,) or (n,4) float64, ax, ay, scale, shift, var)."""
+    n = len(jobs)
+    arr = (Job * max(n, 1))()
+    keep = []
+    for i, j in enumerate(jobs):
+        ev = np.ascontiguousarray(j["events"], dtype=np.float64)
+        stride = 1 if ev.ndim == 1 else ev.shape[1]
+        ax = np.ascontiguousarray(j["ax"], dtype=np.int64)
+        ay = np.ascontiguousarray(j["ay"], dtype=np.int64)
+        rb = j["ref"].encode() if isinstance(j["ref"], str) else j["ref"]
+        keep.append((ev, ax, ay, rb))
+        arr[i] = Job(rb, len(rb), _dp(ev), stride, ev.shape[0], _ip(ax), _ip(ay), len(ax), j.get("scale", 1.0),
+                     j.get("shift", 0.0), j.get("var", 1.0))
+    return arr, keep
+
+
+class Batch:
+    """sa_batch_t: plan + HBM-resident inputs; run() launches the kernels."""
+
+    def __init__(self, model, params, jobs, ambig=None, device=0, flags=0):
+        self._h = C.c_void_p()
+        self.n_jobs = len(jobs)
+        arr, self._keep = _make_jobs(jobs)
+        amb = ambig if ambig is not None else default_ambig()
+        _chk(lib().sa_batch_create(C.byref(self._h), model._h, C.byref(params), arr, len(jobs), amb, device, flags),
+             "sa_batch_create")
+
+    def run(self):
+        _chk(lib().sa_batch_run(self._h), "sa_batch_run")
+
+    def pairs(self, job):
+        n = C.c_int64()
+        _chk(lib().sa_batch_n_pairs(self._h, job, C.byref(n)), "sa_batch_n_pairs")
+        out = np.zeros(n.value, dtype=PAIR_DTYPE)
+        if n.value:
+            _chk(lib().sa_batch_pairs(self._h, job, out.ctypes.data, n.value), "sa_batch_pairs")
+        return out
+
+    def n_pairs(self, job):
+        n = C.c_int64()
+        _chk(lib().sa_batch_n_pairs(self._h, job, C.byref(n)), "sa_batch_n_pairs")
+        return n.value
+
+    def stats(self):
+        s = BatchStats()
+        _chk(lib().sa_batch_stats(self._h, C.byref(s)), "sa_batch_stats")
+        return s
+
+    def close(self):
+        if self._h:
+            lib().sa_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def plan_describe(model, params, job, ambig=None, flags=0):
+    """Host-only view of the plan of ONE job: regions, band rows, traceback segments (no GPU needed)."""
+    arr, keep = _make_jobs([job])
+    amb = ambig if ambig is not None else default_ambig()
+    info = PlanInfo()
+    nev = arr[0].n_events
+    lx = max(arr[0].ref_len, 0)
+    cap_rows = int(lx + nev + 8 * (arr[0].n_anchors + 4))
+    regions = np.zeros(4 * (arr[0].n_anchors + 2), dtype=np.int64)
+    rows = np.zeros(3 * cap_rows, dtype=np.int64)
+    segs = np.zeros(4 * (cap_rows // 100 + 16), dtype=np.int64)
+    _chk(lib().sa_plan_describe(model._h, C.byref(params), arr, amb, flags, C.byref(info), _ip(regions),
+                                len(regions) // 4, _ip(rows), cap_rows, _ip(segs), len(segs) // 4), "sa_plan_describe")
+    nrow = 0
+    reg = regions[:4 * info.n_regions].reshape(-1, 4)
+    for r in reg:
+        nrow += (r[2] - r[0]) + (r[3] - r[1]) + 1
+    return info, reg, rows[:3 * nrow].reshape(-1, 3), segs[:4 * info.n_segments].reshape(-1, 4)
+
+
+def guide_to_anchors(start1, end1, strand1, start2, ops, trim):
+    t = np.array([o[0] for o in ops], dtype=np.int32)
+    ln = np.array([o[1] for o in ops], dtype=np.int64)
+    cap = int(ln.sum()) + 1
+    ax, ay = np.zeros(cap, dtype=np.int64), np.zeros(cap, dtype=np.int64)
+    n = lib().sa_guide_to_anchors(start1, end1, int(strand1), start2, t.ctypes.data_as(C.POINTER(C.c_int32)), _ip(ln),
+                                  len(t), trim, _ip(ax), _ip(ay), cap)
+    if n < 0:
+        raise SaError(int(n), "sa_guide_to_anchors")
+    return ax[:n].copy(), ay[:n].copy()
+
+
+def remap_anchors(ax, ay, event_map, map_offset):
+    axa = np.ascontiguousarray(ax, dtype=np.int64)
+    aya = np.ascontiguousarray(ay, dtype=np.int64)
+    em = np.ascontiguousarray(event_map, dtype=np.int64)
+    ox, oy = np.zeros(len(axa) + 1, dtype=np.int64), np.zeros(len(axa) + 1, dtype=np.int64)
+    n = lib().sa_remap_anchors(_ip(axa), _ip(aya), len(axa), _ip(em), map_offset, _ip(ox), _ip(oy))
+    if n < 0:
+        raise SaError(int(n), "sa_remap_anchors")
+    return ox[:n].copy(), oy[:n].copy()
+
+
+def estimate_params(model, table5, strand_event_map, events4, strand_read):
+    em = np.ascontiguousarray(strand_event_map, dtype=np.int64)
+    out = np.zeros(7, dtype=np.float64)
+    _chk(lib().sa_estimate_params(model._h, _dp(table5), _ip(em), _dp(events4), events4.shape[0],
+                                  strand_read.encode(), len(strand_read), _dp(out)), "sa_estimate_params")
+    return dict(zip(["scale", "shift", "var", "drift", "scale_sd", "var_sd", "shift_sd"], out.tolist()))

@@ -1,0 +1,935 @@
+// sa_hip.hip -- gfx950 kernels and the batch runtime behind include/signalalign_hip.h.
+//
+// Device work per batch (all inputs resident in HBM before the first launch):
+//   1. forward sweep      one wavefront per split region, anti-diagonal after anti-diagonal
+//   2. backward sweep     one wavefront per traceback segment (independent of each other), fused with the
+//                         posterior numerator f.match+b.match and the per-cell terms of totalProbability
+//   3. fold               one lane per checkpoint: the reference's strictly sequential logAdd fold of the
+//                         per-cell terms (kept sequential on purpose: logAdd is a piecewise cubic, not associative)
+//   4. finalize/scan/gather   posterior = exp(fb - total), threshold, floor(p*1e7), compaction into the
+//                         reference's output order
+//
+// Two kernel families share the data layout decisions but not the code:
+//   * generic (k_*_generic): any band width, any number of paths per cell, HDP emissions, reference-ordered
+//     un-contracted arithmetic.  State lives in memory.  This is the exactness baseline.
+//   * fast (k_*_fast): one path per cell, Gaussian emissions.  The two previous anti-diagonals live in
+//     registers; lane = ((x-y+K)>>1) mod 64, so a cell's middle neighbour is in the same lane and its
+//     lower/upper neighbours are in the same or an adjacent lane, alternating with the diagonal's parity.
+//
+// The file is compiled with -ffp-contract=off; where fused multiply-add is wanted it is spelled fma().
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "sa_internal.h"
+
+#define NEG_INF (-__builtin_inf())
+
+// ---------------------------------------------------------------------------------------------------
+// device-side views
+// ---------------------------------------------------------------------------------------------------
+struct DevModel {
+    double t_mm, t_mx, t_my, t_xm, t_xx, t_ym, t_yy;
+    const double *tab6;     // per k-mer: mu, sd, c(sd), sdY, c(sdY), 0   with c(s) = -log(sqrt(2 pi)) - log(s)
+    long long pow_km1;
+    int n_alpha;
+    int hdp;
+    const int *hdp_slot;    // per k-mer: row of y/slope tables of the first observed ancestor, -1 if none
+    const double *hdp_y, *hdp_slope, *hdp_grid;
+    int grid_len;
+};
+
+struct DevPlan {
+    const sa_region_t *regions;
+    const sa_row_t *rows;
+    const int *poff;
+    const int *pid;
+    const double *xc;
+    const double *ev;
+    const sa_seg_t *segs;
+    const sa_ck_t *cks;
+    double *F;
+    double *vbuf;
+    sa_cand_t *cands;
+    int *cand_count;
+    int *overflow;
+    double *totals;
+    double *bscratch;
+    DevModel m;
+    double log_thr;   // log(threshold)
+    double threshold;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// logAdd: impl/pairwiseAligner.c:298-318.  The coefficients are float literals promoted to double.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double la_lookup(double x) {
+    if (x <= 1.00f)
+        return ((-0.009350833524763f * x + 0.130659527668286f) * x + 0.498799810682272f) * x + 0.693203116424741f;
+    if (x <= 2.50f)
+        return ((-0.014532321752540f * x + 0.139942324101744f) * x + 0.495635523139337f) * x + 0.692140569840976f;
+    if (x <= 4.50f)
+        return ((-0.004605031767994f * x + 0.063427417320019f) * x + 0.695956496475118f) * x + 0.514272634594009f;
+    return ((-0.000458661602210f * x + 0.009695946122598f) * x + 0.930734667215156f) * x + 0.168037164329057f;
+}
+
+__device__ __forceinline__ double la_exact(double x, double y) {
+    if (x < y) return (x == NEG_INF || y - x >= 7.5) ? y : la_lookup(y - x) + x;
+    return (y == NEG_INF || x - y >= 7.5) ? x : la_lookup(x - y) + y;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// emissions in reference order (impl/stateMachine.c:296-306, :344-348, :527-605)
+// ---------------------------------------------------------------------------------------------------
+struct ReadPar {
+    double scale, shift, var, lvar;
+};
+
+__device__ __forceinline__ double hdp_interp(const DevModel &m, int slot, double q) {
+    const double *x = m.hdp_grid;
+    const double *y = m.hdp_y + (long long) slot * m.grid_len;
+    const double *s = m.hdp_slope + (long long) slot * m.grid_len;
+    int n = m.grid_len;
+    if (q <= x[0]) return y[0] - s[0] * (x[0] - q);
+    if (q >= x[n - 1]) return y[n - 1] + s[n - 1] * (q - x[n - 1]);
+    double dx = x[1] - x[0];
+    long long il = (long long) ((q - x[0]) / dx);
+    long long ir = il + 1;
+    double dy = y[ir] - y[il];
+    double a = s[il] * dx - dy;
+    double b = dy - s[ir] * dx;
+    double tl = (q - x[il]) / dx;
+    double tr = 1.0 - tl;
+    return tr * y[il] + tl * y[ir] + tl * tr * (a * tr + b * tl);
+}
+
+// match != 0: EMISSION_MATCH_MATRIX; == 0: EMISSION_GAP_Y_MATRIX (sd * 1.75).  id < 0: NULL k-mer.
+__device__ __forceinline__ double emit_ref(const DevModel &m, const ReadPar &rp, int id, double e, int match) {
+    if (id < 0) return NEG_INF;
+    const double *t = m.tab6 + 6ll * id;
+    double mu = t[0];
+    double en = (e + rp.var * mu - rp.scale * mu - rp.shift) / rp.var;
+    if (m.hdp) {
+        int slot = m.hdp_slot[id];
+        if (slot < 0) return NEG_INF;
+        double d = hdp_interp(m, slot, en);
+        d = d > 0.0 ? d : 0.0;
+        double density = (1 / rp.var) * d;
+        return log(density);
+    }
+    double sd = match ? t[1] : t[3];
+    double c = match ? t[2] : t[4];  // -inf when sd == 0
+    double a = (en - mu) / sd;
+    return rp.lvar + (c + (-0.5 * a * a));
+}
+
+__device__ __forceinline__ bool legal_step(const DevModel &m, int from, int to) {
+    if (from < 0 || to < 0) return true;
+    return (from % m.pow_km1) == (to / m.n_alpha);
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+    for (int off = 32; off > 0; off >>= 1) {
+        double o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+    for (int off = 32; off > 0; off >>= 1) {
+        int o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// generic forward: cellCalculate with doTransitionForward (impl/stateMachine.c:1306-1437,
+// impl/pairwiseAligner.c:852-858, :1280-1322).  Row layout: [cell-path][3].
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_fwd_generic(DevPlan P, const int *region_ids, int n) {
+    int w = blockIdx.x;
+    if (w >= n) return;
+    const int lane = threadIdx.x;
+    const sa_region_t *R = &P.regions[region_ids[w]];
+    const sa_row_t *rows = P.rows + R->row_off;
+    const int *poff = P.poff + R->poff_off;
+    const int *pid = P.pid + R->pid_off;
+    const double *ev = P.ev + R->ev_off;
+    double *F = P.F + 3 * R->f_base;
+    const DevModel &m = P.m;
+    ReadPar rp = {R->scale, R->shift, R->var, R->lvar};
+    const long long N = R->N;
+
+    {   // diagonal 0: startStateProb / raggedStartStateProb (impl/stateMachine.c:1134-1143)
+        sa_row_t r0 = rows[0];
+        long long x0 = (0 + r0.xmyL) / 2;
+        for (int i = lane; i < r0.width; i += 64) {
+            long long x = x0 + i;
+            int np = poff[x + 1] - poff[x];
+            double *c = F + 3 * (r0.foff + poff[x] - poff[x0]);
+            for (int p = 0; p < np; p++) {
+                c[3 * p + 0] = R->ragged_l ? NEG_INF : 0.0;
+                c[3 * p + 1] = R->ragged_l ? 0.0 : NEG_INF;
+                c[3 * p + 2] = R->ragged_l ? 0.0 : NEG_INF;
+            }
+        }
+    }
+    __syncthreads();
+    for (long long d = 1; d <= N; d++) {
+        sa_row_t rd = rows[d], r1 = rows[d - 1];
+        sa_row_t r2 = {0, 0, 0, 0, 0};
+        if (d >= 2) r2 = rows[d - 2];
+        long long x0 = (d + rd.xmyL) >> 1;
+        long long x01 = (d - 1 + r1.xmyL) >> 1;
+        long long x02 = d >= 2 ? ((d - 2 + r2.xmyL) >> 1) : 0;
+        for (int i = lane; i < rd.width; i += 64) {
+            long long xmy = (long long) rd.xmyL + 2 * i;
+            long long x = x0 + i, y = d - x;
+            double e = y >= 1 ? ev[y - 1] : NEG_INF;
+            int np = poff[x + 1] - poff[x];
+            const int *idc = pid + poff[x];
+            double *cur = F + 3 * (rd.foff + poff[x] - poff[x0]);
+            long long i_lo = xmy - 1 - r1.xmyL, i_up = xmy + 1 - r1.xmyL, i_mid = xmy - r2.xmyL;
+            bool has_lo = x >= 1 && i_lo >= 0 && (i_lo >> 1) < r1.width;
+            bool has_up = i_up >= 0 && (i_up >> 1) < r1.width;
+            bool has_mid = d >= 2 && x >= 1 && i_mid >= 0 && (i_mid >> 1) < r2.width;
+            const double *lo = has_lo ? F + 3 * (r1.foff + poff[x - 1] - poff[x01]) : nullptr;
+            const double *up = has_up ? F + 3 * (r1.foff + poff[x] - poff[x01]) : nullptr;
+            const double *mid = has_mid ? F + 3 * (r2.foff + poff[x - 1] - poff[x02]) : nullptr;
+            int nq = x >= 1 ? poff[x] - poff[x - 1] : 0;
+            const int *idq = x >= 1 ? pid + poff[x - 1] : nullptr;
+            for (int p = 0; p < np; p++) {
+                int id = idc[p];
+                double sm = NEG_INF, sx = NEG_INF, sy = NEG_INF;
+                if (has_lo) {
+                    double eP = (m.hdp || id >= 0) ? SA_LOG_GAPX : NEG_INF;
+                    for (int q = 0; q < nq; q++)
+                        if (legal_step(m, idq[q], id)) {
+                            sx = la_exact(sx, lo[3 * q + 0] + (eP + m.t_mx));
+                            sx = la_exact(sx, lo[3 * q + 1] + (eP + m.t_xx));
+                        }
+                }
+                if (has_mid) {
+                    double eP = emit_ref(m, rp, id, e, 1);
+                    for (int q = 0; q < nq; q++)
+                        if (legal_step(m, idq[q], id)) {
+                            sm = la_exact(sm, mid[3 * q + 0] + (eP + m.t_mm));
+                            sm = la_exact(sm, mid[3 * q + 1] + (eP + m.t_xm));
+                            sm = la_exact(sm, mid[3 * q + 2] + (eP + m.t_ym));
+                        }
+                }
+                if (has_up) {
+                    double eP = emit_ref(m, rp, id, e, 0);
+                    sy = la_exact(sy, up[3 * p + 0] + (eP + m.t_my));
+                    sy = la_exact(sy, up[3 * p + 2] + (eP + m.t_yy));
+                }
+                cur[3 * p + 0] = sm;
+                cur[3 * p + 1] = sx;
+                cur[3 * p + 2] = sy;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// candidate append: wave-private slice, order = (diagonal descending, cell ascending, path ascending)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cand_append(const DevPlan &P, const sa_seg_t *S, int seg, int &count, bool pass,
+                                            int rank_key_lane, int x, int y, int path, double fb) {
+    // rank_key_lane: position of this lane in cell order (0..63); lanes are ranked by it
+    unsigned long long mask = __ballot(pass);
+    if (mask == 0ull) return;
+    // build the mask in cell order
+    unsigned long long mine = pass ? (1ull << rank_key_lane) : 0ull;
+    unsigned long long ordered = mine;
+    for (int off = 32; off > 0; off >>= 1) ordered |= __shfl_xor(ordered, off, 64);
+    int rank = __popcll(ordered & ((1ull << rank_key_lane) - 1ull));
+    int total = __popcll(ordered);
+    if (pass) {
+        int pos = count + rank;
+        if (pos < S->cand_cap) {
+            sa_cand_t c;
+            c.x = x; c.y = y; c.path = path; c.pad = 0; c.fb = fb;
+            P.cands[S->cand_off + pos] = c;
+        } else {
+            P.overflow[0] = 1;
+        }
+    }
+    count += total;
+    (void) seg;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// generic backward + posterior numerators + checkpoint terms.
+// The reference scatters (doTransitionBackward, impl/pairwiseAligner.c:866-871); here each cell GATHERS
+// the same terms in the same order: first from (x+1,y+1) (it was that cell's "middle"), then from (x,y+1)
+// (its "upper"), then from (x+1,y) (its "lower").  Backward rows live in a 3-row ring in memory.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_ids, int n) {
+    int w = blockIdx.x;
+    if (w >= n) return;
+    const int lane = threadIdx.x;
+    const int seg = seg_ids[w];
+    const sa_seg_t *S = &P.segs[seg];
+    const sa_region_t *R = &P.regions[S->region];
+    const sa_row_t *rows = P.rows + R->row_off;
+    const int *poff = P.poff + R->poff_off;
+    const int *pid = P.pid + R->pid_off;
+    const double *ev = P.ev + R->ev_off;
+    const double *F = P.F + 3 * R->f_base;
+    const DevModel &m = P.m;
+    ReadPar rp = {R->scale, R->shift, R->var, R->lvar};
+    const long long rowcap = R->max_rowpaths;
+    double *ring = P.bscratch + S->bscratch_off;  // 3 rows x rowcap x 3
+    const long long start = S->start, from = S->from, to = S->to;
+    double end_m, end_x, end_y;  // endStateProb / raggedEndStateProb (impl/stateMachine.c:1145-1173)
+    if (S->at_end && R->ragged_r) {
+        end_m = (m.t_mx + m.t_my) / 2.0; end_x = m.t_xx; end_y = m.t_yy;
+    } else {
+        end_m = m.t_mm; end_x = m.t_xm; end_y = m.t_ym;
+    }
+    int count = 0;
+    double Mc = NEG_INF;
+    for (long long e = start; e > to; e--) {
+        sa_row_t re = rows[e];
+        long long x0 = (e + re.xmyL) >> 1;
+        double *Be = ring + (e % 3) * rowcap * 3;
+        sa_row_t r1 = {0, 0, 0, 0, 0}, r2 = {0, 0, 0, 0, 0};
+        long long x01 = 0, x02 = 0;
+        const double *B1 = nullptr, *B2 = nullptr;
+        if (e + 1 <= start) {
+            r1 = rows[e + 1];
+            x01 = (e + 1 + r1.xmyL) >> 1;
+            B1 = ring + ((e + 1) % 3) * rowcap * 3;
+        }
+        if (e + 2 <= start) {
+            r2 = rows[e + 2];
+            x02 = (e + 2 + r2.xmyL) >> 1;
+            B2 = ring + ((e + 2) % 3) * rowcap * 3;
+        }
+        for (int i = lane; i < re.width; i += 64) {
+            long long xmy = (long long) re.xmyL + 2 * i;
+            long long x = x0 + i, y = e - x;
+            int np = poff[x + 1] - poff[x];
+            const int *idt = pid + poff[x];
+            double *cur = Be + 3 * (poff[x] - poff[x0]);
+            if (e == start) {
+                for (int q = 0; q < np; q++) {
+                    cur[3 * q + 0] = end_m; cur[3 * q + 1] = end_x; cur[3 * q + 2] = end_y;
+                }
+                continue;
+            }
+            long long i_mid = xmy - r2.xmyL, i_up = xmy - 1 - r1.xmyL, i_lo = xmy + 1 - r1.xmyL;
+            bool has_mid = B2 && i_mid >= 0 && (i_mid >> 1) < r2.width && x + 1 <= R->lX;
+            bool has_up = B1 && i_up >= 0 && (i_up >> 1) < r1.width;                    // cell (x, y+1)
+            bool has_lo = B1 && i_lo >= 0 && (i_lo >> 1) < r1.width && x + 1 <= R->lX;  // cell (x+1, y)
+            const double *cm = has_mid ? B2 + 3 * (poff[x + 1] - poff[x02]) : nullptr;
+            const double *cu = has_up ? B1 + 3 * (poff[x] - poff[x01]) : nullptr;
+            const double *cl = has_lo ? B1 + 3 * (poff[x + 1] - poff[x01]) : nullptr;
+            int nn = (x + 1 <= R->lX) ? poff[x + 2] - poff[x + 1] : 0;
+            const int *idn = (x + 1 <= R->lX) ? pid + poff[x + 1] : nullptr;
+            double e_next = (y < R->lY) ? ev[y] : NEG_INF;  // event of matrix row y+1
+            for (int q = 0; q < np; q++) {
+                int idq = idt[q];
+                double tm = NEG_INF, tx = NEG_INF, ty = NEG_INF;
+                if (has_mid)
+                    for (int p = 0; p < nn; p++)
+                        if (legal_step(m, idq, idn[p])) {
+                            double eP = emit_ref(m, rp, idn[p], e_next, 1);
+                            double c = cm[3 * p + 0];
+                            tm = la_exact(tm, c + (eP + m.t_mm));
+                            tx = la_exact(tx, c + (eP + m.t_xm));
+                            ty = la_exact(ty, c + (eP + m.t_ym));
+                        }
+                if (has_up) {
+                    double eP = emit_ref(m, rp, idq, e_next, 0);
+                    double c = cu[3 * q + 2];
+                    tm = la_exact(tm, c + (eP + m.t_my));
+                    ty = la_exact(ty, c + (eP + m.t_yy));
+                }
+                if (has_lo)
+                    for (int p = 0; p < nn; p++)
+                        if (legal_step(m, idq, idn[p])) {
+                            double eP = (m.hdp || idn[p] >= 0) ? SA_LOG_GAPX : NEG_INF;
+                            double c = cl[3 * p + 1];
+                            tm = la_exact(tm, c + (eP + m.t_mx));
+                            tx = la_exact(tx, c + (eP + m.t_xx));
+                        }
+                cur[3 * q + 0] = tm; cur[3 * q + 1] = tx; cur[3 * q + 2] = ty;
+            }
+        }
+        __syncthreads();
+        if (e > from) continue;
+        // ---- checkpoint: per-cell terms of diagonalCalculationTotalProbability (impl/pairwiseAligner.c:1335-1353)
+        if ((from - e) % SA_CKPT_EVERY == 0) {
+            const sa_ck_t ck = P.cks[S->ck_base + (from - e) / SA_CKPT_EVERY];
+            double mx = NEG_INF;
+            for (int i = lane; i < re.width; i += 64) {
+                long long x = x0 + i;
+                int np = poff[x + 1] - poff[x];
+                const double *cf = F + 3 * (re.foff + poff[x] - poff[x0]);
+                const double *cb = Be + 3 * (poff[x] - poff[x0]);
+                double cell = NEG_INF;
+                for (int q = 0; q < np; q++) {
+                    double t = cf[3 * q] + cb[3 * q];
+                    t = la_exact(t, cf[3 * q + 1] + cb[3 * q + 1]);
+                    t = la_exact(t, cf[3 * q + 2] + cb[3 * q + 2]);
+                    cell = la_exact(cell, t);
+                }
+                P.vbuf[ck.voff + i] = cell;
+                mx = cell > mx ? cell : mx;
+            }
+            if (ck.nB > 0) {  // match-only forward step into diagonal e+1 == F[e+1].match (same arithmetic, same band)
+                for (int i = lane; i < r1.width; i += 64) {
+                    long long x = x01 + i;
+                    int np = poff[x + 1] - poff[x];
+                    const double *cf = F + 3 * (r1.foff + poff[x] - poff[x01]);
+                    const double *cb = B1 + 3 * (poff[x] - poff[x01]);
+                    double cell = NEG_INF;
+                    for (int q = 0; q < np; q++) cell = la_exact(cell, cf[3 * q] + cb[3 * q]);
+                    P.vbuf[ck.voff + ck.nA + i] = cell;
+                    mx = cell > mx ? cell : mx;
+                }
+            }
+            Mc = wave_max(mx);
+        }
+        // ---- posterior candidates of this diagonal (impl/pairwiseAligner.c:1355-1421); total >= Mc
+        int nchunks = (re.width + 63) >> 6;
+        for (int c = 0; c < nchunks; c++) {
+            int i = c * 64 + lane;
+            bool in = i < re.width;
+            long long x = x0 + (in ? i : 0), y = e - x;
+            int np = in ? poff[x + 1] - poff[x] : 0;
+            int maxnp = wave_max_i(np);
+            const double *cf = F + 3 * (re.foff + poff[x] - poff[x0]);
+            const double *cb = Be + 3 * (poff[x] - poff[x0]);
+            for (int q = 0; q < maxnp; q++) {
+                double fb = NEG_INF;
+                bool pass = false;
+                if (q < np && x > 0 && y > 0) {
+                    fb = cf[3 * q] + cb[3 * q];
+                    pass = (Mc > NEG_INF) && (fb >= Mc + P.log_thr - SA_CAND_EPS);
+                }
+                cand_append(P, S, seg, count, pass, lane, (int) (x - 1), (int) (y - 1), q, fb);
+            }
+        }
+    }
+    if (lane == 0) P.cand_count[seg] = count < S->cand_cap ? count : S->cand_cap;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fold: totalProbability of every checkpoint, folded exactly as dpDiagonal_dotProduct does
+// (impl/pairwiseAligner.c:1167-1180): a left fold over the cells in ascending x-y.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_fold(DevPlan P, long long n_ck) {
+    long long ck = (long long) blockIdx.x * 64 + threadIdx.x;
+    if (ck >= n_ck) return;
+    sa_ck_t c = P.cks[ck];
+    const double *v = P.vbuf + c.voff;
+    double t = NEG_INF;
+    for (int i = 0; i < c.nA; i++) t = la_exact(t, v[i]);
+    if (c.nB > 0) {
+        double tb = NEG_INF;
+        for (int i = 0; i < c.nB; i++) tb = la_exact(tb, v[c.nA + i]);
+        t = la_exact(t, tb);
+    }
+    P.totals[ck] = t;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// finalize: posterior, threshold, floor; count survivors per segment
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_finalize(DevPlan P, int n_segs, long long *prob_e7, int *seg_pass) {
+    int seg = blockIdx.x;
+    if (seg >= n_segs) return;
+    const sa_seg_t *S = &P.segs[seg];
+    int n = P.cand_count[seg];
+    int lane = threadIdx.x;
+    int cnt = 0;
+    for (int i = lane; i < ((n + 63) & ~63); i += 64) {
+        bool pass = false;
+        if (i < n) {
+            sa_cand_t c = P.cands[S->cand_off + i];
+            long long e = (long long) c.x + c.y + 2;
+            double total = P.totals[S->ck_base + (S->from - e) / SA_CKPT_EVERY];
+            double p = exp(c.fb - total);
+            long long v = -1;
+            if (p >= P.threshold) {
+                if (p > 1.0) p = 1.0;
+                v = (long long) floor(p * SA_PROB_1);
+                pass = true;
+            }
+            prob_e7[S->cand_off + i] = v;
+        }
+        cnt += __popcll(__ballot(pass));
+    }
+    if (lane == 0) seg_pass[seg] = cnt;
+}
+
+// exclusive scan of seg_pass (single block)
+__global__ __launch_bounds__(1024) void k_scan(const int *in, long long *out, int n) {
+    __shared__ long long part[1024];
+    int t = threadIdx.x;
+    int per = (n + 1023) / 1024;
+    int lo = t * per, hi = lo + per < n ? lo + per : n;
+    long long s = 0;
+    for (int i = lo; i < hi; i++) s += in[i];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        long long v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    long long base = t ? part[t - 1] : 0;
+    for (int i = lo; i < hi; i++) {
+        out[i] = base;
+        base += in[i];
+    }
+    if (t == 1023) out[n] = part[1023];
+}
+
+// gather survivors of a segment in REVERSE candidate order (=> ascending diagonals, x descending, path descending:
+// the order of stList_pop + stable sort by x+y, impl/pairwiseAligner.c:2043-2050, impl/signalMachine.c:872)
+__global__ __launch_bounds__(64) void k_gather(DevPlan P, int n_segs, const long long *prob_e7, const long long *seg_off,
+                                               sa_pair_t *out) {
+    int seg = blockIdx.x;
+    if (seg >= n_segs) return;
+    const sa_seg_t *S = &P.segs[seg];
+    const sa_region_t *R = &P.regions[S->region];
+    const int *poff = P.poff + R->poff_off;
+    const int *pid = P.pid + R->pid_off;
+    int n = P.cand_count[seg];
+    int lane = threadIdx.x;
+    long long total = seg_off[seg + 1] - seg_off[seg];
+    long long done = 0;
+    for (int base = 0; base < n; base += 64) {
+        int i = base + lane;
+        bool pass = i < n && prob_e7[S->cand_off + i] >= 0;
+        unsigned long long mask = __ballot(pass);
+        int rank = __popcll(mask & ((1ull << lane) - 1ull));
+        if (pass) {
+            sa_cand_t c = P.cands[S->cand_off + i];
+            long long k = done + rank;              // index in candidate order
+            long long pos = seg_off[seg] + (total - 1 - k);
+            sa_pair_t o;
+            o.prob_e7 = prob_e7[S->cand_off + i];
+            o.x = (int) (c.x + R->x1);
+            o.y = (int) (c.y + R->y1);
+            o.path = c.path;
+            o.kmer_id = pid[poff[c.x + 1] + c.path];
+            out[pos] = o;
+        }
+        done += __popcll(mask);
+    }
+}
+
+#include "sa_fast.inc"
+
+// ===================================================================================================
+// host runtime
+// ===================================================================================================
+#define HIPCHK(call)                                                                           \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            fprintf(stderr, "[signalalign_hip] %s failed: %s (%s:%d)\n", #call, hipGetErrorString(e_), __FILE__, \
+                    __LINE__);                                                                 \
+            return e_ == hipErrorOutOfMemory ? SA_ENOMEM : SA_ENODEVICE;                       \
+        }                                                                                      \
+    } while (0)
+
+struct sa_batch {
+    sa_plan_t *plan;
+    int device;
+    unsigned flags;
+    hipStream_t stream;
+    // device buffers
+    sa_region_t *d_regions; sa_row_t *d_rows; int *d_poff; int *d_pid; double *d_xc; double *d_ev;
+    sa_seg_t *d_segs; sa_ck_t *d_cks;
+    double *d_F; double *d_vbuf; sa_cand_t *d_cands; int *d_cand_count; int *d_overflow; double *d_totals;
+    double *d_bscratch;
+    double *d_tab6; int *d_hdp_slot; double *d_hdp_y, *d_hdp_slope, *d_hdp_grid;
+    long long *d_prob; int *d_seg_pass; long long *d_seg_off; sa_pair_t *d_out;
+    int *d_ids;  // region / segment id lists per launch
+    long long cand_alloc;
+    long long out_alloc;
+    // launch lists (host)
+    std::vector<std::vector<int>> gen_regions, fast_regions, gen_segs, fast_segs;  // per chunk
+    std::vector<int> ids_flat;
+    std::vector<long long> ids_off;
+    // results
+    std::vector<sa_pair_t> pairs;
+    std::vector<long long> job_off;
+    bool ran;
+    sa_batch_stats_t stats;
+    hipEvent_t ev[8];
+};
+
+int sa_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static DevPlan make_devplan(const sa_batch *b) {
+    const sa_plan_t *pl = b->plan;
+    const sa_model_t *m = pl->model;
+    DevPlan P;
+    memset(&P, 0, sizeof(P));
+    P.regions = b->d_regions; P.rows = b->d_rows; P.poff = b->d_poff; P.pid = b->d_pid; P.xc = b->d_xc; P.ev = b->d_ev;
+    P.segs = b->d_segs; P.cks = b->d_cks; P.F = b->d_F; P.vbuf = b->d_vbuf; P.cands = b->d_cands;
+    P.cand_count = b->d_cand_count; P.overflow = b->d_overflow; P.totals = b->d_totals; P.bscratch = b->d_bscratch;
+    P.m.t_mm = m->t_mm; P.m.t_mx = m->t_mx; P.m.t_my = m->t_my; P.m.t_xm = m->t_xm; P.m.t_xx = m->t_xx;
+    P.m.t_ym = m->t_ym; P.m.t_yy = m->t_yy;
+    P.m.tab6 = b->d_tab6; P.m.pow_km1 = m->pow_km1; P.m.n_alpha = m->n_alpha; P.m.hdp = m->hdp ? 1 : 0;
+    P.m.hdp_slot = b->d_hdp_slot; P.m.hdp_y = b->d_hdp_y; P.m.hdp_slope = b->d_hdp_slope; P.m.hdp_grid = b->d_hdp_grid;
+    P.m.grid_len = m->hdp ? (int) m->hdp->grid_length : 0;
+    P.threshold = pl->params.threshold;
+    P.log_thr = log(pl->params.threshold);
+    return P;
+}
+
+template <typename T>
+static int upload(T **dst, const T *src, long long n) {
+    size_t bytes = sizeof(T) * (size_t) (n > 0 ? n : 1);
+    HIPCHK(hipMalloc((void **) dst, bytes));
+    if (n > 0) HIPCHK(hipMemcpy(*dst, src, sizeof(T) * (size_t) n, hipMemcpyHostToDevice));
+    return SA_OK;
+}
+
+void sa_batch_destroy(sa_batch_t *b) {
+    if (!b) return;
+    if (b->device >= 0) (void) hipSetDevice(b->device);
+    void *ptrs[] = {b->d_regions, b->d_rows, b->d_poff, b->d_pid, b->d_xc, b->d_ev, b->d_segs, b->d_cks, b->d_F,
+                    b->d_vbuf, b->d_cands, b->d_cand_count, b->d_overflow, b->d_totals, b->d_bscratch, b->d_tab6,
+                    b->d_hdp_slot, b->d_hdp_y, b->d_hdp_slope, b->d_hdp_grid, b->d_prob, b->d_seg_pass, b->d_seg_off,
+                    b->d_out, b->d_ids};
+    for (void *p : ptrs)
+        if (p) (void) hipFree(p);
+    for (int i = 0; i < 8; i++)
+        if (b->ev[i]) (void) hipEventDestroy(b->ev[i]);
+    if (b->stream) (void) hipStreamDestroy(b->stream);
+    sa_plan_free(b->plan);
+    delete b;
+}
+
+int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs, int64_t n_jobs,
+                    const char *const *ambig, int device, unsigned flags) {
+    if (!out || !m || !p) return SA_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fprintf(stderr, "[signalalign_hip] no HIP device available; this library has no CPU fallback\n");
+        return SA_ENODEVICE;
+    }
+    if (device < 0 || device >= ndev) return SA_EINVAL;
+    HIPCHK(hipSetDevice(device));
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    // forward storage gets at most 60% of what is free; 24 B per cell-path
+    long long budget = (long long) ((double) free_b * 0.60 / 24.0);
+    const char *envb = getenv("SA_F_BUDGET_CELLPATHS");  // test hook: force several passes
+    if (envb && atoll(envb) > 0) budget = atoll(envb);
+
+    sa_plan_t *pl = nullptr;
+    int rc = sa_plan_build(&pl, m, p, jobs, n_jobs, ambig, flags, budget);
+    if (rc) return rc;
+    sa_batch *b = new sa_batch();
+    b->plan = pl;
+    b->device = device;
+    b->flags = flags;
+    b->stream = nullptr;
+    b->ran = false;
+    b->d_regions = nullptr; b->d_rows = nullptr; b->d_poff = nullptr; b->d_pid = nullptr; b->d_xc = nullptr;
+    b->d_ev = nullptr; b->d_segs = nullptr; b->d_cks = nullptr; b->d_F = nullptr; b->d_vbuf = nullptr;
+    b->d_cands = nullptr; b->d_cand_count = nullptr; b->d_overflow = nullptr; b->d_totals = nullptr;
+    b->d_bscratch = nullptr; b->d_tab6 = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr;
+    b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr;
+    b->d_seg_off = nullptr; b->d_out = nullptr; b->d_ids = nullptr;
+    b->cand_alloc = 0; b->out_alloc = 0;
+    memset(&b->stats, 0, sizeof(b->stats));
+    for (int i = 0; i < 8; i++) b->ev[i] = nullptr;
+#define TRY(x) do { int rc_ = (x); if (rc_) { sa_batch_destroy(b); return rc_; } } while (0)
+    if (hipStreamCreate(&b->stream) != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
+    for (int i = 0; i < 8; i++)
+        if (hipEventCreate(&b->ev[i]) != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
+    TRY(upload(&b->d_regions, pl->regions, pl->n_regions));
+    TRY(upload(&b->d_rows, pl->rows, pl->n_rows));
+    TRY(upload(&b->d_poff, pl->poff, pl->n_poff));
+    TRY(upload(&b->d_pid, pl->pid, pl->n_pid));
+    TRY(upload(&b->d_xc, pl->xc, 4 * pl->n_pid));
+    TRY(upload(&b->d_ev, pl->ev, pl->n_ev));
+    TRY(upload(&b->d_segs, pl->segs, pl->n_segs));
+    TRY(upload(&b->d_cks, pl->cks, pl->n_cks));
+    {   // model tables
+        std::vector<double> tab6((size_t) m->n_kmers * 6);
+        for (long long i = 0; i < m->n_kmers; i++) {
+            double mu = m->table5[5 * i], sd = m->table5[5 * i + 1];
+            double sdy = sd * SA_GAPY_SD_MULT;  // stateMachine3_loadFromFile multiplies the loaded sd (impl/stateMachine.c:1530-1532)
+            tab6[6 * i + 0] = mu;
+            tab6[6 * i + 1] = sd == 0.0 ? 1.0 : sd;
+            tab6[6 * i + 2] = sd == 0.0 ? -INFINITY : (-0.91893853320467267 - log(sd));
+            tab6[6 * i + 3] = sdy == 0.0 ? 1.0 : sdy;
+            tab6[6 * i + 4] = sdy == 0.0 ? -INFINITY : (-0.91893853320467267 - log(sdy));
+            tab6[6 * i + 5] = 0.0;
+        }
+        TRY(upload(&b->d_tab6, tab6.data(), (long long) tab6.size()));
+        if (m->hdp) {
+            const sa_hdp_t *h = m->hdp;
+            std::vector<int> slot((size_t) m->n_kmers);
+            for (long long i = 0; i < m->n_kmers; i++) {
+                long long r = h->resolved[i];
+                slot[i] = (r >= 0 && h->slot[r] >= 0) ? (int) h->slot[r] : -1;
+            }
+            TRY(upload(&b->d_hdp_slot, slot.data(), (long long) slot.size()));
+            TRY(upload(&b->d_hdp_y, h->y, h->n_slots * h->grid_length));
+            TRY(upload(&b->d_hdp_slope, h->slope, h->n_slots * h->grid_length));
+            TRY(upload(&b->d_hdp_grid, h->grid, h->grid_length));
+        }
+    }
+    // working buffers
+    auto dalloc = [&](void **p_, long long bytes) -> int {
+        HIPCHK(hipMalloc(p_, (size_t) (bytes > 0 ? bytes : 8)));
+        return SA_OK;
+    };
+    TRY(dalloc((void **) &b->d_F, 24 * pl->max_chunk_cellpaths));
+    TRY(dalloc((void **) &b->d_vbuf, 8 * pl->n_vbuf));
+    TRY(dalloc((void **) &b->d_cands, (long long) sizeof(sa_cand_t) * pl->n_cand));
+    TRY(dalloc((void **) &b->d_prob, 8 * pl->n_cand));
+    b->cand_alloc = pl->n_cand;
+    TRY(dalloc((void **) &b->d_cand_count, 4 * pl->n_segs));
+    TRY(dalloc((void **) &b->d_seg_pass, 4 * pl->n_segs));
+    TRY(dalloc((void **) &b->d_seg_off, 8 * (pl->n_segs + 1)));
+    TRY(dalloc((void **) &b->d_overflow, 4));
+    TRY(dalloc((void **) &b->d_totals, 8 * pl->n_cks));
+    TRY(dalloc((void **) &b->d_bscratch, 8 * pl->n_bscratch));
+    // launch lists per chunk
+    b->gen_regions.resize(pl->n_chunks); b->fast_regions.resize(pl->n_chunks);
+    b->gen_segs.resize(pl->n_chunks); b->fast_segs.resize(pl->n_chunks);
+    for (long long r = 0; r < pl->n_regions; r++) {
+        const sa_region_t *R = &pl->regions[r];
+        auto &rl = (R->kind == SA_KIND_FAST) ? b->fast_regions[R->chunk] : b->gen_regions[R->chunk];
+        auto &sl = (R->kind == SA_KIND_FAST) ? b->fast_segs[R->chunk] : b->gen_segs[R->chunk];
+        rl.push_back((int) r);
+        for (long long s = R->seg_off; s < R->seg_off + R->n_seg; s++) sl.push_back((int) s);
+    }
+    // longest segments first inside each launch: the tail of a launch is then made of short waves
+    for (int c = 0; c < pl->n_chunks; c++) {
+        auto by_len_r = [&](int a, int d) { return pl->regions[a].N > pl->regions[d].N; };
+        auto by_len_s = [&](int a, int d) {
+            return pl->segs[a].start - pl->segs[a].to > pl->segs[d].start - pl->segs[d].to;
+        };
+        std::stable_sort(b->gen_regions[c].begin(), b->gen_regions[c].end(), by_len_r);
+        std::stable_sort(b->fast_regions[c].begin(), b->fast_regions[c].end(), by_len_r);
+        std::stable_sort(b->gen_segs[c].begin(), b->gen_segs[c].end(), by_len_s);
+        std::stable_sort(b->fast_segs[c].begin(), b->fast_segs[c].end(), by_len_s);
+    }
+    b->ids_flat.clear();
+    b->ids_off.clear();
+    for (int c = 0; c < pl->n_chunks; c++)
+        for (auto *v : {&b->gen_regions[c], &b->fast_regions[c], &b->gen_segs[c], &b->fast_segs[c]}) {
+            b->ids_off.push_back((long long) b->ids_flat.size());
+            b->ids_flat.insert(b->ids_flat.end(), v->begin(), v->end());
+        }
+    TRY(upload(&b->d_ids, b->ids_flat.data(), (long long) b->ids_flat.size()));
+    b->stats.cells_forward = pl->cells_fwd;
+    b->stats.cells_backward = pl->cells_bwd;
+    b->stats.n_regions = pl->n_regions;
+    b->stats.n_segments = pl->n_segs;
+    b->stats.n_checkpoints = pl->n_cks;
+    b->stats.n_fast_regions = pl->n_fast_regions;
+    b->stats.n_chunks = pl->n_chunks;
+    double fb = 0;
+    for (long long r = 0; r < pl->n_regions; r++) fb += 24.0 * (double) pl->regions[r].f_cellpaths;
+    b->stats.f_bytes = fb;
+#undef TRY
+    *out = b;
+    return SA_OK;
+}
+
+static int run_once(sa_batch *b, bool *overflowed) {
+    sa_plan_t *pl = b->plan;
+    DevPlan P = make_devplan(b);
+    hipStream_t st = b->stream;
+    HIPCHK(hipMemsetAsync(b->d_cand_count, 0, 4 * (size_t) (pl->n_segs > 0 ? pl->n_segs : 1), st));
+    HIPCHK(hipMemsetAsync(b->d_overflow, 0, 4, st));
+    float ms_f = 0, ms_b = 0;
+    HIPCHK(hipEventRecord(b->ev[0], st));
+    for (int c = 0; c < pl->n_chunks; c++) {
+        const int *ids_gr = b->d_ids + b->ids_off[4 * c + 0];
+        const int *ids_fr = b->d_ids + b->ids_off[4 * c + 1];
+        const int *ids_gs = b->d_ids + b->ids_off[4 * c + 2];
+        const int *ids_fs = b->d_ids + b->ids_off[4 * c + 3];
+        int ngr = (int) b->gen_regions[c].size(), nfr = (int) b->fast_regions[c].size();
+        int ngs = (int) b->gen_segs[c].size(), nfs = (int) b->fast_segs[c].size();
+        HIPCHK(hipEventRecord(b->ev[1], st));
+        if (ngr) hipLaunchKernelGGL(k_fwd_generic, dim3(ngr), dim3(64), 0, st, P, ids_gr, ngr);
+        if (nfr) launch_fwd_fast(P, ids_fr, nfr, st);
+        HIPCHK(hipEventRecord(b->ev[2], st));
+        if (ngs) hipLaunchKernelGGL(k_bwd_generic, dim3(ngs), dim3(64), 0, st, P, ids_gs, ngs);
+        if (nfs) launch_bwd_fast(P, ids_fs, nfs, st);
+        HIPCHK(hipEventRecord(b->ev[3], st));
+        HIPCHK(hipEventSynchronize(b->ev[3]));
+        float a = 0, d = 0;
+        HIPCHK(hipEventElapsedTime(&a, b->ev[1], b->ev[2]));
+        HIPCHK(hipEventElapsedTime(&d, b->ev[2], b->ev[3]));
+        ms_f += a;
+        ms_b += d;
+    }
+    HIPCHK(hipEventRecord(b->ev[4], st));
+    if (pl->n_cks) hipLaunchKernelGGL(k_fold, dim3((unsigned) ((pl->n_cks + 63) / 64)), dim3(64), 0, st, P, (long long) pl->n_cks);
+    HIPCHK(hipEventRecord(b->ev[5], st));
+    HIPCHK(hipGetLastError());
+    int ov = 0;
+    HIPCHK(hipMemcpyAsync(&ov, b->d_overflow, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    float ms_fold = 0, ms_tot = 0;
+    HIPCHK(hipEventElapsedTime(&ms_fold, b->ev[4], b->ev[5]));
+    HIPCHK(hipEventElapsedTime(&ms_tot, b->ev[0], b->ev[5]));
+    b->stats.ms_forward = ms_f;
+    b->stats.ms_backward = ms_b;
+    b->stats.ms_fold = ms_fold;
+    b->stats.ms_total_device = ms_tot;
+    *overflowed = ov != 0;
+    return SA_OK;
+}
+
+int sa_batch_run(sa_batch_t *b) {
+    if (!b) return SA_EINVAL;
+    HIPCHK(hipSetDevice(b->device));
+    sa_plan_t *pl = b->plan;
+    bool ov = false;
+    for (int attempt = 0; attempt < 6; attempt++) {
+        int rc = run_once(b, &ov);
+        if (rc) return rc;
+        if (!ov) break;
+        // a traceback segment produced more candidates than planned: enlarge and redo the pass
+        sa_plan_grow_candidates(pl, 4);
+        HIPCHK(hipFree(b->d_cands));
+        HIPCHK(hipFree(b->d_prob));
+        b->d_cands = nullptr;
+        b->d_prob = nullptr;
+        HIPCHK(hipMalloc((void **) &b->d_cands, sizeof(sa_cand_t) * (size_t) pl->n_cand));
+        HIPCHK(hipMalloc((void **) &b->d_prob, 8 * (size_t) pl->n_cand));
+        b->cand_alloc = pl->n_cand;
+        HIPCHK(hipMemcpy(b->d_segs, pl->segs, sizeof(sa_seg_t) * (size_t) pl->n_segs, hipMemcpyHostToDevice));
+    }
+    if (ov) return SA_ENOMEM;
+    long long n_segs = pl->n_segs;
+    b->pairs.clear();
+    b->job_off.assign((size_t) pl->n_jobs + 1, 0);
+    if (b->flags & SA_FLAG_EXACT) {
+        // host finalisation with the C library's exp(): bit-identical to the reference's posterior arithmetic
+        std::vector<sa_cand_t> cands((size_t) (pl->n_cand > 0 ? pl->n_cand : 1));
+        std::vector<int> counts((size_t) (n_segs > 0 ? n_segs : 1));
+        std::vector<double> totals((size_t) (pl->n_cks > 0 ? pl->n_cks : 1));
+        if (pl->n_cand) HIPCHK(hipMemcpy(cands.data(), b->d_cands, sizeof(sa_cand_t) * (size_t) pl->n_cand, hipMemcpyDeviceToHost));
+        if (n_segs) HIPCHK(hipMemcpy(counts.data(), b->d_cand_count, 4 * (size_t) n_segs, hipMemcpyDeviceToHost));
+        if (pl->n_cks) HIPCHK(hipMemcpy(totals.data(), b->d_totals, 8 * (size_t) pl->n_cks, hipMemcpyDeviceToHost));
+        std::vector<sa_pair_t *> pp((size_t) (pl->n_jobs > 0 ? pl->n_jobs : 1), nullptr);
+        std::vector<int64_t> np((size_t) (pl->n_jobs > 0 ? pl->n_jobs : 1), 0);
+        int rc = sa_plan_finalize(pl, cands.data(), counts.data(), totals.data(), pp.data(), np.data());
+        if (rc) return rc;
+        for (long long j = 0; j < pl->n_jobs; j++) {
+            b->job_off[j] = (long long) b->pairs.size();
+            b->pairs.insert(b->pairs.end(), pp[j], pp[j] + np[j]);
+            free(pp[j]);
+        }
+        b->job_off[pl->n_jobs] = (long long) b->pairs.size();
+    } else if (n_segs > 0) {
+        DevPlan P = make_devplan(b);
+        hipStream_t st = b->stream;
+        hipLaunchKernelGGL(k_finalize, dim3((unsigned) n_segs), dim3(64), 0, st, P, (int) n_segs, b->d_prob, b->d_seg_pass);
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, b->d_seg_pass, b->d_seg_off, (int) n_segs);
+        std::vector<long long> seg_off((size_t) n_segs + 1);
+        HIPCHK(hipMemcpyAsync(seg_off.data(), b->d_seg_off, 8 * (size_t) (n_segs + 1), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        long long total = seg_off[n_segs];
+        if (total > b->out_alloc) {
+            if (b->d_out) HIPCHK(hipFree(b->d_out));
+            b->d_out = nullptr;
+            HIPCHK(hipMalloc((void **) &b->d_out, sizeof(sa_pair_t) * (size_t) (total + total / 8 + 64)));
+            b->out_alloc = total + total / 8 + 64;
+        }
+        if (total > 0) {
+            hipLaunchKernelGGL(k_gather, dim3((unsigned) n_segs), dim3(64), 0, st, P, (int) n_segs, b->d_prob, b->d_seg_off, b->d_out);
+            b->pairs.resize((size_t) total);
+            HIPCHK(hipMemcpyAsync(b->pairs.data(), b->d_out, sizeof(sa_pair_t) * (size_t) total, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+        HIPCHK(hipGetLastError());
+        for (long long j = 0; j < pl->n_jobs; j++) {
+            const sa_jobinfo_t *J = &pl->jobs[j];
+            long long first_seg = n_segs;
+            if (J->n_regions > 0) first_seg = pl->regions[J->region_off].seg_off;
+            else {
+                // jobs without regions: position of the next job's first segment
+                for (long long k = j + 1; k < pl->n_jobs; k++)
+                    if (pl->jobs[k].n_regions > 0) { first_seg = pl->regions[pl->jobs[k].region_off].seg_off; break; }
+            }
+            b->job_off[j] = seg_off[first_seg];
+        }
+        b->job_off[pl->n_jobs] = total;
+    }
+    b->ran = true;
+    return SA_OK;
+}
+
+int sa_batch_n_pairs(const sa_batch_t *b, int64_t job, int64_t *n) {
+    if (!b || !n || job < 0 || job >= b->plan->n_jobs) return SA_EINVAL;
+    if (!b->ran) return SA_ESTATE;
+    *n = b->job_off[job + 1] - b->job_off[job];
+    return SA_OK;
+}
+int sa_batch_pairs(const sa_batch_t *b, int64_t job, sa_pair_t *out, int64_t cap) {
+    if (!b || job < 0 || job >= b->plan->n_jobs) return SA_EINVAL;
+    if (!b->ran) return SA_ESTATE;
+    long long n = b->job_off[job + 1] - b->job_off[job];
+    if (n > cap) return SA_EINVAL;
+    if (n > 0) memcpy(out, b->pairs.data() + b->job_off[job], sizeof(sa_pair_t) * (size_t) n);
+    return SA_OK;
+}
+int sa_batch_stats(const sa_batch_t *b, sa_batch_stats_t *out) {
+    if (!b || !out) return SA_EINVAL;
+    *out = b->stats;
+    return SA_OK;
+}
+int sa_batch_job_cells(const sa_batch_t *b, int64_t job, double *cf, double *cb) {
+    if (!b || job < 0 || job >= b->plan->n_jobs) return SA_EINVAL;
+    if (cf) *cf = b->plan->jobs[job].cells_fwd;
+    if (cb) *cb = b->plan->jobs[job].cells_bwd;
+    return SA_OK;
+}
+
+int sa_align_batch(const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs, int64_t n_jobs,
+                   const char *const *ambig, int device, unsigned flags, sa_pair_t **pairs_out, int64_t *n_pairs_out) {
+    sa_batch_t *b = nullptr;
+    int rc = sa_batch_create(&b, m, p, jobs, n_jobs, ambig, device, flags);
+    if (rc) return rc;
+    rc = sa_batch_run(b);
+    if (rc == SA_OK)
+        for (int64_t j = 0; j < n_jobs; j++) {
+            int64_t n = 0;
+            sa_batch_n_pairs(b, j, &n);
+            pairs_out[j] = (sa_pair_t *) malloc(sizeof(sa_pair_t) * (size_t) (n > 0 ? n : 1));
+            if (!pairs_out[j]) { rc = SA_ENOMEM; break; }
+            sa_batch_pairs(b, j, pairs_out[j], n);
+            n_pairs_out[j] = n;
+        }
+    sa_batch_destroy(b);
+    return rc;
+}
+
+int sa_expect_batch(const sa_model_t *, const sa_params_t *, const sa_job_t *, int64_t, const char *const *, int,
+                    unsigned, double *, double *, sa_assignment_t **, int64_t *) {
+    return SA_EUNSUPPORTED;  // EM mode: next row of the scope table
+}

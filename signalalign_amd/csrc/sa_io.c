@@ -1,0 +1,198 @@
+/* sa_io.c -- loaders for the reference's text formats (host only).
+ *
+ *   .model   3 whitespace-split lines (stateMachine3_loadFromFile, impl/stateMachine.c:1440-1538)
+ *   .nhdp    serialize_nhdp/serialize_hdp text (impl/nanopore_hdp.c:1088-1115, impl/hdp.c:2919-3322);
+ *            only the fields alignment reads are kept: grid, parents, observed flags (recomputed from the
+ *            dp-id line as mark_observed_dps does, impl/hdp.c:1132-1160), posterior predictives, slopes.
+ */
+#define _GNU_SOURCE
+#include "sa_io.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include "sa_internal.h"
+
+char *sa_read_line(FILE *f) {
+    size_t cap = 1 << 12, n = 0;
+    char *s = malloc(cap);
+    if (!s) return NULL;
+    int c, any = 0;
+    while ((c = fgetc(f)) != EOF) {
+        any = 1;
+        if (c == '\n') break;
+        if (n + 2 > cap) {
+            cap *= 2;
+            char *t = realloc(s, cap);
+            if (!t) { free(s); return NULL; }
+            s = t;
+        }
+        s[n++] = (char) c;
+    }
+    if (!any) { free(s); return NULL; }
+    s[n] = 0;
+    return s;
+}
+
+int64_t sa_split_ws(char *line, char ***toks) {
+    int64_t cap = 256, n = 0;
+    char **t = malloc(sizeof(char *) * (size_t) cap);
+    char *p = line;
+    for (;;) {
+        while (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n') p++;
+        if (!*p) break;
+        if (n == cap) {
+            cap *= 2;
+            t = realloc(t, sizeof(char *) * (size_t) cap);
+        }
+        t[n++] = p;
+        while (*p && *p != ' ' && *p != '\t' && *p != '\r' && *p != '\n') p++;
+        if (*p) *p++ = 0;
+    }
+    *toks = t;
+    return n;
+}
+
+typedef struct {
+    int64_t num_dps, grid_length;
+    double grid_start, grid_stop;
+    int64_t *parent;
+    uint8_t *observed;
+    double **post, **slope;
+    char alphabet[64];
+    int n_alpha, k;
+} nhdp_file_t;
+
+static void nhdp_file_free(nhdp_file_t *h) {
+    if (!h) return;
+    if (h->post) for (int64_t i = 0; i < h->num_dps; i++) free(h->post[i]);
+    if (h->slope) for (int64_t i = 0; i < h->num_dps; i++) free(h->slope[i]);
+    free(h->post); free(h->slope); free(h->parent); free(h->observed);
+    free(h);
+}
+
+static double *parse_doubles(char *line, int64_t expect) {
+    char **tok;
+    int64_t n = sa_split_ws(line, &tok);
+    double *v = NULL;
+    if (n == expect) {
+        v = malloc(sizeof(double) * (size_t) n);
+        for (int64_t i = 0; i < n; i++) v[i] = strtod(tok[i], NULL);
+    }
+    free(tok);
+    return v;
+}
+
+static nhdp_file_t *nhdp_read(const char *path) {
+    FILE *f = fopen(path, "r");
+    if (!f) return NULL;
+    nhdp_file_t *h = calloc(1, sizeof(*h));
+    char *ln;
+#define NEXT() do { ln = sa_read_line(f); if (!ln) goto bad; } while (0)
+    NEXT(); h->n_alpha = (int) strtol(ln, NULL, 10); free(ln);
+    NEXT(); sscanf(ln, "%63s", h->alphabet); free(ln);
+    NEXT(); h->k = (int) strtol(ln, NULL, 10); free(ln);
+    NEXT(); int splines = strtol(ln, NULL, 10) != 0; free(ln);
+    NEXT(); int has_data = strtol(ln, NULL, 10) != 0; free(ln);
+    NEXT(); int sample_gamma = strtol(ln, NULL, 10) != 0; free(ln);
+    NEXT(); h->num_dps = strtoll(ln, NULL, 10); free(ln);
+    if (h->num_dps <= 0) goto bad;
+    int64_t n_data = 0, *dp_ids = NULL;
+    if (has_data) {
+        NEXT(); free(ln); /* data values */
+        NEXT();
+        char **tok;
+        n_data = sa_split_ws(ln, &tok);
+        dp_ids = malloc(sizeof(int64_t) * (size_t) (n_data > 0 ? n_data : 1));
+        for (int64_t i = 0; i < n_data; i++) dp_ids[i] = strtoll(tok[i], NULL, 10);
+        free(tok);
+        free(ln);
+    }
+    NEXT(); free(ln); /* mu nu alpha beta */
+    NEXT();
+    long long gl = 0;
+    if (sscanf(ln, "%lg %lg %lld", &h->grid_start, &h->grid_stop, &gl) != 3) { free(ln); free(dp_ids); goto bad; }
+    h->grid_length = gl;
+    free(ln);
+    NEXT(); free(ln); /* gamma */
+    if (sample_gamma) for (int i = 0; i < 4; i++) { NEXT(); free(ln); }
+    h->parent = malloc(sizeof(int64_t) * (size_t) h->num_dps);
+    h->observed = calloc((size_t) h->num_dps, 1);
+    h->post = calloc((size_t) h->num_dps, sizeof(double *));
+    h->slope = calloc((size_t) h->num_dps, sizeof(double *));
+    for (int64_t id = 0; id < h->num_dps; id++) {
+        NEXT();
+        h->parent[id] = ln[0] == '-' ? -1 : strtoll(ln, NULL, 10);
+        free(ln);
+    }
+    if (has_data) {
+        for (int64_t i = 0; i < n_data; i++) /* every named DP and all its ancestors */
+            for (int64_t a = dp_ids[i]; a >= 0 && a < h->num_dps && !h->observed[a]; a = h->parent[a]) h->observed[a] = 1;
+        for (int64_t id = 0; id < h->num_dps; id++) {
+            NEXT();
+            h->post[id] = parse_doubles(ln, h->grid_length);
+            if (!h->post[id] && h->observed[id]) h->post[id] = calloc((size_t) h->grid_length, sizeof(double));
+            free(ln);
+        }
+    }
+    if (splines)
+        for (int64_t id = 0; id < h->num_dps; id++) {
+            NEXT();
+            h->slope[id] = parse_doubles(ln, h->grid_length);
+            free(ln);
+        }
+    free(dp_ids);
+    fclose(f);
+    return h;
+bad:
+    fclose(f);
+    nhdp_file_free(h);
+    return NULL;
+#undef NEXT
+}
+
+int sa_model_load(sa_model_t **out, const char *model_path, const char *nhdp_path) {
+    if (!out || !model_path) return SA_EINVAL;
+    FILE *f = fopen(model_path, "r");
+    if (!f) return SA_EIO;
+    char *l0 = sa_read_line(f), *l1 = sa_read_line(f), *l2 = sa_read_line(f);
+    fclose(f);
+    int rc = SA_EIO;
+    char **t0 = NULL, **t1 = NULL, **t2 = NULL;
+    double *table = NULL;
+    nhdp_file_t *h = NULL;
+    if (!l0 || !l1 || !l2) goto done;
+    if (sa_split_ws(l0, &t0) != 4) goto done; /* stateNumber alphabetSize alphabet kmerLength */
+    int n_states = (int) strtol(t0[0], NULL, 10), n_alpha = (int) strtol(t0[1], NULL, 10), k = (int) strtol(t0[3], NULL, 10);
+    if ((int) strlen(t0[2]) != n_alpha || k < 1 || k > 12) goto done;
+    if (sa_split_ws(l1, &t1) != (int64_t) n_states * n_states + 1) goto done;
+    double t10[10];
+    for (int i = 0; i < 10; i++) t10[i] = strtod(t1[i], NULL);
+    int64_t nk = 1;
+    for (int i = 0; i < k; i++) nk *= n_alpha;
+    int64_t n2 = sa_split_ws(l2, &t2);
+    if (n2 != nk * 5) goto done;
+    table = malloc(sizeof(double) * (size_t) n2);
+    for (int64_t i = 0; i < n2; i++) table[i] = strtod(t2[i], NULL);
+    if (nhdp_path) {
+        h = nhdp_read(nhdp_path);
+        if (!h) goto done;
+        sa_hdp_desc_t d = {h->num_dps, h->grid_length, h->grid_start, h->grid_stop, h->parent, h->observed,
+                           (const double *const *) h->post, (const double *const *) h->slope};
+        rc = sa_model_create(out, n_states, t0[2], k, t10, table, &d);
+        if (rc == SA_OK) { /* stateMachine3_setModelToHdpExpectedValues checks (impl/stateMachine.c:1277-1288) */
+            char a[64]; int na, kk;
+            sa_model_alphabet(*out, a, &na, &kk);
+            char b[64];
+            strncpy(b, h->alphabet, 63); b[63] = 0;
+            for (int i = 1; i < h->n_alpha; i++) { char c = b[i]; int j = i - 1; while (j >= 0 && b[j] > c) { b[j + 1] = b[j]; j--; } b[j + 1] = c; }
+            if (strcmp(a, b) != 0 || kk != h->k) { sa_model_destroy(*out); *out = NULL; rc = SA_EINVAL; }
+        }
+    } else {
+        rc = sa_model_create(out, n_states, t0[2], k, t10, table, NULL);
+    }
+done:
+    free(t0); free(t1); free(t2); free(l0); free(l1); free(l2); free(table);
+    nhdp_file_free(h);
+    return rc;
+}

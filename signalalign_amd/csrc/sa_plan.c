@@ -1,0 +1,974 @@
+/* sa_plan.c -- host-side planning for the MI355X pair-HMM kernels.
+ *
+ * Everything that is integer geometry stays on the host and is computed once per batch:
+ *   - per reference position: the list of path k-mers of ambiguous windows (HDCell paths),
+ *   - split regions at large anchor gaps, band table (one (xmyL,width) per anti-diagonal),
+ *   - the traceback schedule (which diagonals start a backward sweep, what each sweep emits),
+ *   - the total-probability checkpoints (every 10th posterior diagonal of a sweep).
+ * The device then only does floating-point work on flat arrays.
+ *
+ * Reference behaviour restated here (paths relative to the upstream signalAlign tree):
+ *   band_construct                      impl/pairwiseAligner.c:195-246
+ *   getSplitPoints                      impl/pairwiseAligner.c:1886-1937
+ *   getPosteriorProbsWithBanding        impl/pairwiseAligner.c:1450-1590 (the schedule, not the maths)
+ *   hdCell_construct2                   impl/pairwiseAligner.c:723-801
+ *   stateMachine3_loadFromFile          impl/stateMachine.c:1440-1538
+ *   filterToRemoveOverlap               impl/pairwiseAligner.c:1755-1796
+ *   convertPairwise...ToAnchorPairs     impl/pairwiseAligner.c:1624-1658
+ *   signalUtils_estimateNanoporeParams  impl/signalMachineUtils.c:186-225, impl/nanopore.c:601-954
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "sa_internal.h"
+
+/* ------------------------------------------------------------------------------------------------ */
+const char *sa_strerror(int code) {
+    switch (code) {
+        case SA_OK: return "ok";
+        case SA_EINVAL: return "invalid argument";
+        case SA_ENOMEM: return "out of memory";
+        case SA_ENODEVICE: return "no usable HIP device (this library has no CPU fallback)";
+        case SA_EALPHABET: return "k-mer contains a character outside the model alphabet";
+        case SA_EBAND: return "anchor pairs give an invalid diagonal";
+        case SA_EIO: return "file could not be read or parsed";
+        case SA_ESTATE: return "call out of order";
+        case SA_EUNSUPPORTED: return "unsupported";
+    }
+    return "unknown error";
+}
+const char *sa_version(void) { return "signalalign_hip 0.1 (gfx950)"; }
+void sa_free(void *p) { free(p); }
+
+/* ---- model ------------------------------------------------------------------------------------ */
+static void sort_chars(char *s, int n) {
+    for (int i = 1; i < n; i++) {
+        char c = s[i];
+        int j = i - 1;
+        while (j >= 0 && s[j] > c) {
+            s[j + 1] = s[j];
+            j--;
+        }
+        s[j + 1] = c;
+    }
+}
+
+static void hdp_free(sa_hdp_t *h) {
+    if (!h) return;
+    free(h->grid); free(h->parent); free(h->observed); free(h->resolved); free(h->slot); free(h->y); free(h->slope);
+    free(h);
+}
+
+static sa_hdp_t *hdp_from_desc(const sa_hdp_desc_t *d) {
+    sa_hdp_t *h = calloc(1, sizeof(*h));
+    if (!h) return NULL;
+    h->num_dps = d->num_dps;
+    h->grid_length = d->grid_length;
+    h->grid_start = d->grid_start;
+    h->grid_stop = d->grid_stop;
+    int64_t n = d->num_dps, g = d->grid_length;
+    h->grid = malloc(sizeof(double) * g);
+    h->parent = malloc(sizeof(int64_t) * n);
+    h->observed = malloc(n);
+    h->resolved = malloc(sizeof(int64_t) * n);
+    h->slot = malloc(sizeof(int64_t) * n);
+    /* linspace: every point start + i*dx except the last, which is exactly stop */
+    double dx = (d->grid_stop - d->grid_start) / (double) (g - 1);
+    for (int64_t i = 0; i + 1 < g; i++) h->grid[i] = d->grid_start + i * dx;
+    h->grid[g - 1] = d->grid_stop;
+    int64_t ns = 0;
+    for (int64_t i = 0; i < n; i++) {
+        h->parent[i] = d->parent[i];
+        h->observed[i] = d->observed[i] ? 1 : 0;
+        h->slot[i] = (h->observed[i] && d->post_pred[i] && d->slopes[i]) ? ns++ : -1;
+    }
+    h->n_slots = ns;
+    h->y = malloc(sizeof(double) * (ns > 0 ? ns : 1) * g);
+    h->slope = malloc(sizeof(double) * (ns > 0 ? ns : 1) * g);
+    for (int64_t i = 0; i < n; i++) {
+        if (h->slot[i] >= 0) {
+            memcpy(h->y + h->slot[i] * g, d->post_pred[i], sizeof(double) * g);
+            memcpy(h->slope + h->slot[i] * g, d->slopes[i], sizeof(double) * g);
+        }
+    }
+    for (int64_t i = 0; i < n; i++) { /* walk to the first observed ancestor */
+        int64_t a = i, guard = 0;
+        while (a >= 0 && !h->observed[a] && guard++ < n) a = h->parent[a];
+        h->resolved[i] = (a >= 0 && h->observed[a]) ? a : -1;
+    }
+    return h;
+}
+
+int sa_model_create(sa_model_t **out, int n_states, const char *alphabet, int k, const double *t10,
+                    const double *table5, const sa_hdp_desc_t *hdp) {
+    if (!out || !alphabet || !t10 || !table5) return SA_EINVAL;
+    if (n_states != 3) return SA_EUNSUPPORTED; /* the 5-state machine aborts in the reference too */
+    int na = (int) strlen(alphabet);
+    if (na < 1 || na > 60 || k < 1 || k > 12) return SA_EINVAL;
+    sa_model_t *m = calloc(1, sizeof(*m));
+    if (!m) return SA_ENOMEM;
+    m->n_alpha = na;
+    m->k = k;
+    memcpy(m->alphabet, alphabet, na);
+    sort_chars(m->alphabet, na);
+    for (int i = 1; i < na; i++)
+        if (m->alphabet[i] == m->alphabet[i - 1]) {
+            free(m);
+            return SA_EINVAL;
+        }
+    m->n_kmers = 1;
+    for (int i = 0; i < k; i++) m->n_kmers *= na;
+    m->pow_km1 = m->n_kmers / na;
+    /* token order of the .model transition line: mm mx my xm xx (xy) ym (yx) yy (+1 extra);
+     * tokens 5 and 7 never reach a live transition (gapX<->gapY stay log(0)). */
+    m->t_mm = log(t10[0]);
+    m->t_mx = log(t10[1]);
+    m->t_my = log(t10[2]);
+    m->t_xm = log(t10[3]);
+    m->t_xx = log(t10[4]);
+    m->t_ym = log(t10[6]);
+    m->t_yy = log(t10[8]);
+    m->table5 = malloc(sizeof(double) * 5 * m->n_kmers);
+    if (!m->table5) {
+        free(m);
+        return SA_ENOMEM;
+    }
+    memcpy(m->table5, table5, sizeof(double) * 5 * m->n_kmers);
+    if (hdp) {
+        if (hdp->num_dps < m->n_kmers || hdp->grid_length < 2) {
+            sa_model_destroy(m);
+            return SA_EINVAL;
+        }
+        m->hdp = hdp_from_desc(hdp);
+        if (!m->hdp) {
+            sa_model_destroy(m);
+            return SA_ENOMEM;
+        }
+    }
+    *out = m;
+    return SA_OK;
+}
+
+void sa_model_destroy(sa_model_t *m) {
+    if (!m) return;
+    hdp_free(m->hdp);
+    free(m->table5);
+    free(m);
+}
+
+int sa_model_alphabet(const sa_model_t *m, char *out64, int *n_alpha, int *k) {
+    if (!m) return SA_EINVAL;
+    if (out64) {
+        memcpy(out64, m->alphabet, m->n_alpha);
+        out64[m->n_alpha] = 0;
+    }
+    if (n_alpha) *n_alpha = m->n_alpha;
+    if (k) *k = m->k;
+    return SA_OK;
+}
+const double *sa_model_table5(const sa_model_t *m) { return m ? m->table5 : NULL; }
+
+int64_t sa_model_kmer_id(const sa_model_t *m, const char *kmer) {
+    int64_t id = 0;
+    for (int i = 0; i < m->k; i++) {
+        const char *hit = memchr(m->alphabet, kmer[i], m->n_alpha);
+        if (!hit || kmer[i] == 0) return -1;
+        id = id * m->n_alpha + (hit - m->alphabet);
+    }
+    return id;
+}
+int64_t sa_kmer_id(const sa_model_t *m, const char *kmer) { return (m && kmer) ? sa_model_kmer_id(m, kmer) : -1; }
+
+/* expected value / variance of an observed DP's posterior predictive on the grid */
+int sa_model_set_to_hdp_expected_values(sa_model_t *m) {
+    if (!m || !m->hdp) return SA_EINVAL;
+    const sa_hdp_t *h = m->hdp;
+    int64_t g = h->grid_length;
+    for (int64_t id = 0; id < m->n_kmers; id++) {
+        if (!h->observed[id] || h->slot[id] < 0) continue;
+        const double *distr = h->y + h->slot[id] * g;
+        double ev = 0.0;
+        for (int64_t i = 1; i < g; i++) {
+            double dx = h->grid[i] - h->grid[i - 1];
+            ev += h->grid[i] * distr[i] * dx;
+        }
+        double var = 0.0;
+        for (int64_t i = 1; i < g; i++) {
+            double dx = h->grid[i] - h->grid[i - 1];
+            double dev = h->grid[i] - ev;
+            var += dev * dev * distr[i] * dx;
+        }
+        m->table5[id * 5] = ev;
+        m->table5[id * 5 + 1] = sqrt(var);
+    }
+    return SA_OK;
+}
+
+/* ---- ambiguity -------------------------------------------------------------------------------- */
+void sa_default_ambig(const char **map) {
+    static const struct { char c; const char *r; } tab[] = {
+        {'R', "AG"}, {'Y', "CT"}, {'S', "CG"}, {'W', "AT"}, {'K', "GT"}, {'M', "AC"}, {'B', "CGT"}, {'D', "AGT"},
+        {'H', "ACT"}, {'V', "ACG"}, {'X', "ACGT"}, {'L', "CEO"}, {'P', "CE"}, {'Q', "AI"}, {'f', "AF"},
+        {'U', "ACEGOT"}, {'Z', "JT"}, {'j', "Tp"}, {'k', "Gb"}, {'l', "Gd"}, {'m', "Ce"}, {'n', "Th"}, {'o', "Ai"}};
+    memset(map, 0, sizeof(char *) * 256);
+    for (size_t i = 0; i < sizeof(tab) / sizeof(tab[0]); i++) map[(unsigned char) tab[i].c] = tab[i].r;
+}
+
+int sa_load_ambig(const char *path, const char **map) {
+    /* two whitespace-separated columns: symbol, replacement letters; at most 300 lines of < 100 chars,
+     * tokens of at most 9 characters (buffers of create_ambig_bases2). Only 1-character symbols can match. */
+    FILE *f = fopen(path, "r");
+    if (!f) return SA_EIO;
+    memset(map, 0, sizeof(char *) * 256);
+    char line[100], enc[16], rep[16];
+    int n = 0;
+    while (n < 300 && fgets(line, sizeof(line), f)) {
+        if (sscanf(line, "%9s %9s", enc, rep) == 2 && enc[1] == 0) {
+            char *copy = strdup(rep); /* lives for the process, like the reference's hash values */
+            map[(unsigned char) enc[0]] = copy;
+        }
+        n++;
+    }
+    fclose(f);
+    return SA_OK;
+}
+
+/* ---- growable arrays --------------------------------------------------------------------------- */
+#define GROW(pl, arr, n, cap, need, type)                                  \
+    do {                                                                   \
+        if ((pl)->n + (need) > (pl)->cap) {                                \
+            int64_t nc = (pl)->cap ? (pl)->cap * 2 : 1024;                 \
+            while (nc < (pl)->n + (need)) nc *= 2;                         \
+            void *np_ = realloc((pl)->arr, sizeof(type) * (size_t) nc);    \
+            if (!np_) return SA_ENOMEM;                                    \
+            (pl)->arr = np_;                                               \
+            (pl)->cap = nc;                                                \
+        }                                                                  \
+    } while (0)
+
+/* ---- band ------------------------------------------------------------------------------------- */
+static inline int64_t clampz(int64_t z, int64_t hi) { return z < 0 ? 0 : (z > hi ? hi : z); }
+
+/* One anti-diagonal of the band: the stretch of x-y between the lower corner (xL,yL) and the upper
+ * corner (xU,yU) of the current anchor-to-anchor box, snapped to the parity of xay. */
+static int clip_row(int64_t xay, int64_t xL, int64_t yL, int64_t xU, int64_t yU, int64_t *lo, int64_t *hi) {
+    int64_t a = xL - yL, b = xU - yU;
+    if ((xay + a) % 2 != 0) a++;
+    if ((xay + b) % 2 != 0) b++;
+    int64_t x = (xay + a) / 2;
+    if (x < xL) a += 2 * (xL - x);
+    int64_t y = (xay - a) / 2;
+    if (yL < y) a += 2 * (y - yL);
+    x = (xay + b) / 2;
+    if (xU < x) b -= 2 * (x - xU);
+    y = (xay - b) / 2;
+    if (y < yU) b -= 2 * (yU - y);
+    if ((xay + a) % 2 != 0 || (xay + b) % 2 != 0 || a > b) return SA_EBAND;
+    *lo = a;
+    *hi = b;
+    return SA_OK;
+}
+
+int sa_band_rows(const int64_t *ax, const int64_t *ay, int64_t n, int64_t lX, int64_t lY, int64_t e, int64_t *lo,
+                 int64_t *hi) {
+    int64_t N = lX + lY;
+    int rc = clip_row(0, 0, 0, 0, 0, &lo[0], &hi[0]);
+    if (rc) return rc;
+    int64_t p_sum = 0, p_dif = 0; /* previous anchor in matrix coordinates, as x+y and x-y */
+    int64_t d = 1;
+    for (int64_t i = 0; d <= N; i++) {
+        int64_t x = lX, y = lY;
+        if (i < n) {
+            x = ax[i] + 1;
+            y = ay[i] + 1;
+            if (x <= (p_sum + p_dif) / 2 || y <= (p_sum - p_dif) / 2 || x > lX || y > lY) return SA_EBAND;
+        }
+        int64_t n_sum = x + y, n_dif = x - y;
+        int64_t xL = clampz((p_sum + p_dif - e) / 2, lX);
+        int64_t yL = clampz((n_sum - n_dif + e) / 2, lY);
+        int64_t xU = clampz((n_sum + n_dif + e) / 2, lX);
+        int64_t yU = clampz((p_sum - p_dif - e) / 2, lY);
+        int64_t last = n_sum < N ? n_sum : N;
+        for (; d <= last; d++) {
+            rc = clip_row(d, xL, yL, xU, yU, &lo[d], &hi[d]);
+            if (rc) return rc;
+        }
+        p_sum = n_sum;
+        p_dif = n_dif;
+        if (i >= n && d <= N) return SA_EBAND; /* cannot happen: the last box ends at (lX,lY) */
+    }
+    return SA_OK;
+}
+
+/* ---- split regions ---------------------------------------------------------------------------- */
+typedef struct { int64_t x1, y1, x2, y2; } rect_t;
+
+/* Gaps between consecutive anchors whose rectangle is larger than `limit` cut the alignment in two;
+ * each side keeps at most floor(sqrt(limit)) rows/columns of the gap. */
+static int64_t split_regions(const int64_t *ax, const int64_t *ay, int64_t n, int64_t lX, int64_t lY, int64_t limit,
+                             int ragged_l, int ragged_r, rect_t *out) {
+    int64_t cnt = 0, x1 = 0, y1 = 0, px = 0, py = 0;
+    int64_t side = (int64_t) sqrt((double) limit);
+    for (int64_t i = 0; i <= n; i++) {
+        int64_t nx = i < n ? ax[i] : lX, ny = i < n ? ay[i] : lY;
+        int64_t gx = nx - px, gy = ny - py;
+        int cut = gx * gy > limit;
+        if (cut) {
+            int64_t hx = gx / 2 > side ? side : gx / 2, hy = gy / 2 > side ? side : gy / 2;
+            int skip = ragged_l && ((i < n && i == 0) || (i == n && n == 0));
+            if (!skip) out[cnt++] = (rect_t){x1, y1, px + hx, py + hy};
+            x1 = nx - hx;
+            y1 = ny - hy;
+        }
+        if (i == n) {
+            if (!cut || !ragged_r) out[cnt++] = (rect_t){x1, y1, lX, lY};
+        }
+        px = nx + 1;
+        py = ny + 1;
+    }
+    return cnt;
+}
+
+/* ---- per-position path tables ------------------------------------------------------------------ */
+/* Expands the k-mer starting at s into all substitutions of its ambiguous letters, first ambiguous
+ * position varying slowest. Returns count, or SA_EALPHABET. ids may be NULL to only count. */
+static int64_t expand_kmer(const sa_model_t *m, const char *s, const char *const *ambig, int32_t *ids, int64_t cap) {
+    int k = m->k;
+    const char *opt[16];
+    int nopt[16];
+    int64_t total = 1;
+    for (int i = 0; i < k; i++) {
+        const char *r = ambig ? ambig[(unsigned char) s[i]] : NULL;
+        opt[i] = r;
+        nopt[i] = r ? (int) strlen(r) : 1;
+        total *= nopt[i];
+        if (total > (1 << 24)) return SA_EUNSUPPORTED;
+    }
+    if (!ids) return total;
+    if (total > cap) return SA_EINVAL;
+    char buf[16];
+    for (int64_t j = 0; j < total; j++) {
+        int64_t rem = j;
+        for (int i = k - 1; i >= 0; i--) { /* last position varies fastest */
+            int c = (int) (rem % nopt[i]);
+            rem /= nopt[i];
+            buf[i] = opt[i] ? opt[i][c] : s[i];
+        }
+        int64_t id = sa_model_kmer_id(m, buf);
+        if (id < 0) return SA_EALPHABET;
+        ids[j] = (int32_t) id;
+    }
+    return total;
+}
+
+/* ---- plan -------------------------------------------------------------------------------------- */
+void sa_plan_free(sa_plan_t *pl) {
+    if (!pl) return;
+    free(pl->jobs); free(pl->regions); free(pl->rows); free(pl->poff); free(pl->pid); free(pl->xc); free(pl->ev);
+    free(pl->segs); free(pl->cks);
+    free(pl);
+}
+
+static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc, const int64_t *ax, const int64_t *ay,
+                      int64_t na, int ragged_l, int ragged_r, const char *const *ambig, int64_t job_ev_off) {
+    const sa_model_t *m = pl->model;
+    const sa_params_t *p = &pl->params;
+    int64_t lX = rc.x2 - rc.x1, lY = rc.y2 - rc.y1, N = lX + lY;
+    if (N == 0) return SA_OK; /* "Deal with trivial case": impl/pairwiseAligner.c:1467-1469 */
+    GROW(pl, regions, n_regions, cap_regions, 1, sa_region_t);
+    sa_region_t *R = &pl->regions[pl->n_regions];
+    memset(R, 0, sizeof(*R));
+    R->job = (int32_t) job;
+    R->ragged_l = ragged_l;
+    R->ragged_r = ragged_r;
+    R->x1 = rc.x1; R->y1 = rc.y1; R->lX = lX; R->lY = lY; R->N = N;
+    R->scale = jb->scale; R->shift = jb->shift; R->var = jb->var;
+    R->lvar = log((1 / jb->var));
+    R->ev_off = job_ev_off + rc.y1;
+
+    /* paths per x: cell x = 0 is the NULL k-mer (one path, id -1) */
+    GROW(pl, poff, n_poff, cap_poff, lX + 2, int32_t);
+    R->poff_off = pl->n_poff;
+    R->pid_off = pl->n_pid;
+    int32_t *poff = pl->poff + pl->n_poff;
+    pl->n_poff += lX + 2;
+    GROW(pl, pid, n_pid, cap_pid, 1, int32_t);
+    pl->pid[pl->n_pid++] = -1;
+    poff[0] = 0;
+    poff[1] = 1;
+    int maxP = 1;
+    for (int64_t x = 1; x <= lX; x++) {
+        const char *s = jb->ref + rc.x1 + (x - 1);
+        int64_t cnt = expand_kmer(m, s, ambig, NULL, 0);
+        if (cnt < 0) return (int) cnt;
+        GROW(pl, pid, n_pid, cap_pid, cnt, int32_t);
+        int64_t got = expand_kmer(m, s, ambig, pl->pid + pl->n_pid, cnt);
+        if (got < 0) return (int) got;
+        pl->n_pid += cnt;
+        if (cnt > maxP) maxP = (int) cnt;
+        int64_t next = (int64_t) poff[x] + cnt;
+        if (next > INT32_MAX) return SA_EUNSUPPORTED;
+        poff = pl->poff + R->poff_off; /* (GROW of pid does not move poff; kept for clarity) */
+        poff[x + 1] = (int32_t) next;
+    }
+
+    /* band */
+    int64_t *lo = malloc(sizeof(int64_t) * (N + 1)), *hi = malloc(sizeof(int64_t) * (N + 1));
+    if (!lo || !hi) {
+        free(lo); free(hi);
+        return SA_ENOMEM;
+    }
+    int rcode = sa_band_rows(ax, ay, na, lX, lY, p->diagonal_expansion, lo, hi);
+    if (rcode) {
+        free(lo); free(hi);
+        return rcode;
+    }
+    if (pl->n_rows + N + 1 > pl->cap_rows) {
+        int64_t nc = pl->cap_rows ? pl->cap_rows * 2 : 4096;
+        while (nc < pl->n_rows + N + 1) nc *= 2;
+        void *np_ = realloc(pl->rows, sizeof(sa_row_t) * (size_t) nc);
+        if (!np_) {
+            free(lo); free(hi);
+            return SA_ENOMEM;
+        }
+        pl->rows = np_;
+        pl->cap_rows = nc;
+    }
+    R->row_off = pl->n_rows;
+    sa_row_t *rows = pl->rows + pl->n_rows;
+    pl->n_rows += N + 1;
+    poff = pl->poff + R->poff_off;
+    int64_t K = lY + (lY & 1) + 2;
+    R->K = (int32_t) K;
+    int64_t foff = 0, max_rowpaths = 0, span = 0;
+    double cf = 0;
+    for (int64_t d = 0; d <= N; d++) {
+        int64_t w = (hi[d] - lo[d]) / 2 + 1;
+        int64_t x0 = (d + lo[d]) / 2, xe = x0 + w; /* cells cover x0 .. xe-1 */
+        int64_t paths = (int64_t) poff[xe] - poff[x0];
+        rows[d].xmyL = (int32_t) lo[d];
+        rows[d].width = (int32_t) w;
+        rows[d].foff = foff;
+        foff += paths;
+        if (paths > max_rowpaths) max_rowpaths = paths;
+        if (d >= 1) cf += (double) paths;
+        /* widest window of (x-y+K)>>1 over three consecutive diagonals plus one neighbour each side */
+        int64_t uL = (lo[d] + K) >> 1, uR = uL + w - 1;
+        int64_t wl = uL - 1, wr = uR + 1;
+        for (int64_t b = 1; b <= 2 && d - b >= 0; b++) {
+            int64_t l2 = (lo[d - b] + K) >> 1, r2 = l2 + (hi[d - b] - lo[d - b]) / 2;
+            if (l2 < wl) wl = l2;
+            if (r2 > wr) wr = r2;
+        }
+        rows[d].span3 = (int32_t) (wr - wl + 1);
+        rows[d].pad = 0;
+        if (wr - wl + 1 > span) span = wr - wl + 1;
+    }
+    R->f_cellpaths = foff;
+    R->max_rowpaths = (int32_t) max_rowpaths;
+    R->slots = (int32_t) ((span + 63) / 64);
+    if (span > pl->max_span) pl->max_span = span;
+    int fast_ok = maxP == 1 && m->hdp == NULL && !(pl->flags & (SA_FLAG_EXACT | SA_FLAG_FORCE_GENERIC));
+    R->kind = fast_ok ? SA_KIND_FAST : SA_KIND_GENERIC;
+    if (fast_ok) pl->n_fast_regions++;
+
+    /* traceback schedule */
+    R->seg_off = pl->n_segs;
+    int64_t traced_to = 0;
+    double cb = 0;
+    for (int64_t d = 1; d <= N; d++) {
+        int at_end = d == N;
+        int tb = d >= traced_to + p->min_diags_between_trace_back && rows[d].width <= p->diagonal_expansion * 2 + 1;
+        if (!(at_end || tb)) continue;
+        GROW(pl, segs, n_segs, cap_segs, 1, sa_seg_t);
+        sa_seg_t *S = &pl->segs[pl->n_segs++];
+        memset(S, 0, sizeof(*S));
+        S->region = (int32_t) pl->n_regions;
+        S->at_end = at_end;
+        S->start = d;
+        S->from = d - (at_end ? 0 : p->trace_back_diagonals + 1);
+        S->to = traced_to;
+        if (S->from <= S->to) { /* would violate traceBackDiagonals+1 < minDiagsBetweenTraceBack */
+            free(lo); free(hi);
+            return SA_EINVAL;
+        }
+        for (int64_t e = S->to + 2; e <= S->start; e++) {
+            int64_t x0 = (e + rows[e].xmyL) / 2;
+            cb += (double) (poff[x0 + rows[e].width] - poff[x0]);
+        }
+        /* checkpoints: diagonals from, from-10, ... > to */
+        S->ck_base = pl->n_cks;
+        int64_t nck = (S->from - S->to + SA_CKPT_EVERY - 1) / SA_CKPT_EVERY;
+        S->n_ck = (int32_t) nck;
+        GROW(pl, cks, n_cks, cap_cks, nck, sa_ck_t);
+        for (int64_t c = 0; c < nck; c++) {
+            int64_t e = S->from - SA_CKPT_EVERY * c;
+            sa_ck_t *ck = &pl->cks[pl->n_cks++];
+            ck->voff = pl->n_vbuf;
+            ck->nA = rows[e].width;
+            ck->nB = e < S->start ? rows[e + 1].width : 0;
+            pl->n_vbuf += ck->nA + ck->nB;
+        }
+        int64_t cap = 4 * (S->from - S->to) + 64;
+        if (p->threshold <= 0.0) { /* everything passes: every cell-path of the posterior diagonals */
+            cap = 64;
+            for (int64_t e = S->to + 1; e <= S->from; e++) {
+                int64_t x0 = (e + rows[e].xmyL) / 2;
+                cap += poff[x0 + rows[e].width] - poff[x0];
+            }
+        }
+        if (cap > INT32_MAX) cap = INT32_MAX;
+        S->cand_cap = (int32_t) cap;
+        S->cand_off = pl->n_cand;
+        pl->n_cand += cap;
+        S->bscratch_off = pl->n_bscratch;
+        pl->n_bscratch += 12 * (int64_t) max_rowpaths;
+        traced_to = S->from;
+    }
+    R->n_seg = (int32_t) (pl->n_segs - R->seg_off);
+    free(lo);
+    free(hi);
+    pl->jobs[job].cells_fwd += cf;
+    pl->jobs[job].cells_bwd += cb;
+    pl->cells_fwd += cf;
+    pl->cells_bwd += cb;
+    pl->n_regions++;
+    return SA_OK;
+}
+
+/* per-(x,path) emission constants with the read's scale/shift/var folded in:
+ *   a  = (event - m) * inv_s            m = scale*mu + shift, inv_s = 1/(var*sd)
+ *   lM = cM - a*a/2                     cM = log(1/var) - log(sqrt(2 pi)) - log(sd)
+ *   lY = cY - (a/1.75)^2/2              cY = cM - log(1.75)
+ * which is emissions_signal_strawManGetKmerEventMatchProbWithDescaling_MeanOnly
+ * (impl/stateMachine.c:557-605) with the descaling (e + var*mu - scale*mu - shift)/var - mu = (e - m)/var
+ * carried out symbolically. */
+static int fill_xc(sa_plan_t *pl) {
+    const sa_model_t *m = pl->model;
+    pl->xc = malloc(sizeof(double) * 4 * (size_t) (pl->n_pid > 0 ? pl->n_pid : 1));
+    if (!pl->xc) return SA_ENOMEM;
+    for (int64_t r = 0; r < pl->n_regions; r++) {
+        const sa_region_t *R = &pl->regions[r];
+        const int32_t *poff = pl->poff + R->poff_off;
+        int64_t n = poff[R->lX + 1];
+        for (int64_t i = 0; i < n; i++) {
+            int32_t id = pl->pid[R->pid_off + i];
+            double *o = pl->xc + 4 * (R->pid_off + i);
+            if (id < 0) {
+                o[0] = 0.0; o[1] = 0.0; o[2] = SA_NEG_INF; o[3] = SA_NEG_INF;
+                continue;
+            }
+            double mu = m->table5[5 * (int64_t) id], sd = m->table5[5 * (int64_t) id + 1];
+            o[0] = R->scale * mu + R->shift;
+            if (sd == 0.0) { /* emissions_signal_logGaussPdf returns LOG_ZERO */
+                o[1] = 0.0; o[2] = SA_NEG_INF; o[3] = SA_NEG_INF;
+            } else {
+                o[1] = 1.0 / (R->var * sd);
+                o[2] = R->lvar + (-0.91893853320467267 - log(sd));
+                o[3] = R->lvar + (-0.91893853320467267 - log(sd * SA_GAPY_SD_MULT));
+            }
+        }
+    }
+    return SA_OK;
+}
+
+int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs, int64_t n_jobs,
+                  const char *const *ambig, unsigned flags, int64_t chunk_budget) {
+    if (!out || !m || !p || (!jobs && n_jobs > 0) || n_jobs < 0) return SA_EINVAL;
+    if (p->diagonal_expansion < 0 || p->diagonal_expansion % 2 != 0 || p->trace_back_diagonals < 1 ||
+        p->min_diags_between_trace_back < 2 || p->trace_back_diagonals + 1 >= p->min_diags_between_trace_back ||
+        !(p->threshold >= 0.0 && p->threshold <= 1.0))
+        return SA_EINVAL; /* the asserts of impl/pairwiseAligner.c:1460-1464, :1358-1359 */
+    sa_plan_t *pl = calloc(1, sizeof(*pl));
+    if (!pl) return SA_ENOMEM;
+    pl->model = m;
+    pl->params = *p;
+    pl->flags = flags;
+    pl->n_jobs = n_jobs;
+    pl->jobs = calloc(n_jobs > 0 ? n_jobs : 1, sizeof(sa_jobinfo_t));
+    int rc = SA_OK;
+    for (int64_t j = 0; j < n_jobs && rc == SA_OK; j++) {
+        const sa_job_t *jb = &jobs[j];
+        if (!jb->ref || jb->ref_len < 0 || jb->n_events < 0 || jb->n_anchors < 0 || (jb->n_events && !jb->events) ||
+            (jb->n_anchors && (!jb->anchor_x || !jb->anchor_y)) || !(jb->var > 0.0)) {
+            rc = SA_EINVAL;
+            break;
+        }
+        int64_t lX = jb->ref_len == 0 ? 0 : jb->ref_len - (m->k - 1); /* sequence_correctSeqLength */
+        if (lX < 0) lX = 0;
+        int64_t lY = jb->n_events;
+        for (int64_t i = 0; i < jb->n_anchors; i++)
+            if (jb->anchor_x[i] < 0 || jb->anchor_y[i] < 0 || jb->anchor_x[i] >= lX || jb->anchor_y[i] >= lY ||
+                (i > 0 && (jb->anchor_x[i] <= jb->anchor_x[i - 1] || jb->anchor_y[i] <= jb->anchor_y[i - 1]))) {
+                rc = SA_EBAND;
+                break;
+            }
+        if (rc) break;
+        /* events: keep only the mean column */
+        if (pl->n_ev + lY + 1 > pl->cap_ev) {
+            int64_t nc = pl->cap_ev ? pl->cap_ev * 2 : 4096;
+            while (nc < pl->n_ev + lY + 1) nc *= 2;
+            void *np_ = realloc(pl->ev, sizeof(double) * (size_t) nc);
+            if (!np_) { rc = SA_ENOMEM; break; }
+            pl->ev = np_;
+            pl->cap_ev = nc;
+        }
+        pl->jobs[j].ev_off = pl->n_ev;
+        pl->jobs[j].n_events = lY;
+        int64_t st = jb->event_stride > 0 ? jb->event_stride : 1;
+        for (int64_t i = 0; i < lY; i++) pl->ev[pl->n_ev + i] = jb->events[i * st];
+        pl->n_ev += lY;
+        pl->jobs[j].region_off = pl->n_regions;
+
+        rect_t *rects = malloc(sizeof(rect_t) * (size_t) (jb->n_anchors + 2));
+        int64_t *sx = malloc(sizeof(int64_t) * (size_t) (jb->n_anchors + 1));
+        int64_t *sy = malloc(sizeof(int64_t) * (size_t) (jb->n_anchors + 1));
+        if (!rects || !sx || !sy) {
+            free(rects); free(sx); free(sy);
+            rc = SA_ENOMEM;
+            break;
+        }
+        /* signalMachine always calls with ragged left and right ends (impl/signalMachine.c:436-437) */
+        int64_t nr = split_regions(jb->anchor_x, jb->anchor_y, jb->n_anchors, lX, lY, p->split_matrix_bigger_than_this,
+                                   1, 1, rects);
+        int64_t a = 0;
+        for (int64_t i = 0; i < nr && rc == SA_OK; i++) {
+            int64_t a0 = a;
+            while (a < jb->n_anchors && jb->anchor_x[a] + jb->anchor_y[a] < rects[i].x2 + rects[i].y2) a++;
+            for (int64_t t = a0; t < a; t++) {
+                sx[t - a0] = jb->anchor_x[t] - rects[i].x1;
+                sy[t - a0] = jb->anchor_y[t] - rects[i].y1;
+            }
+            rc = add_region(pl, j, jb, rects[i], sx, sy, a - a0, 1, 1, ambig, pl->jobs[j].ev_off);
+        }
+        free(rects); free(sx); free(sy);
+        pl->jobs[j].n_regions = (int32_t) (pl->n_regions - pl->jobs[j].region_off);
+    }
+    if (rc == SA_OK) rc = fill_xc(pl);
+    if (rc != SA_OK) {
+        sa_plan_free(pl);
+        return rc;
+    }
+    /* forward storage: pack regions into passes of at most chunk_budget cell-paths */
+    int32_t chunk = 0;
+    int64_t used = 0;
+    for (int64_t r = 0; r < pl->n_regions; r++) {
+        sa_region_t *R = &pl->regions[r];
+        if (used > 0 && chunk_budget > 0 && used + R->f_cellpaths > chunk_budget) {
+            chunk++;
+            used = 0;
+        }
+        R->chunk = chunk;
+        R->f_base = used;
+        used += R->f_cellpaths;
+        if (used > pl->max_chunk_cellpaths) pl->max_chunk_cellpaths = used;
+    }
+    pl->n_chunks = pl->n_regions ? chunk + 1 : 0;
+    *out = pl;
+    return SA_OK;
+}
+
+void sa_plan_grow_candidates(sa_plan_t *pl, int factor) {
+    int64_t off = 0;
+    for (int64_t s = 0; s < pl->n_segs; s++) {
+        int64_t cap = (int64_t) pl->segs[s].cand_cap * factor;
+        if (cap > INT32_MAX) cap = INT32_MAX;
+        pl->segs[s].cand_cap = (int32_t) cap;
+        pl->segs[s].cand_off = off;
+        off += cap;
+    }
+    pl->n_cand = off;
+}
+
+/* ---- finalisation: candidates + totals -> the reference's pair list ---------------------------- */
+static int cmp_pair_out(const void *a, const void *b) {
+    const sa_pair_t *p = a, *q = b;
+    int64_t sp = (int64_t) p->x + p->y, sq = (int64_t) q->x + q->y;
+    if (sp != sq) return sp < sq ? -1 : 1;
+    if (p->x != q->x) return p->x > q->x ? -1 : 1;          /* within a diagonal: x descending  */
+    if (p->path != q->path) return p->path > q->path ? -1 : 1; /* within a cell: path descending */
+    return 0;
+}
+
+int sa_plan_finalize(const sa_plan_t *pl, const sa_cand_t *cands, const int32_t *cand_count, const double *totals,
+                     sa_pair_t **pairs_out, int64_t *n_pairs_out) {
+    double thr = pl->params.threshold;
+    for (int64_t j = 0; j < pl->n_jobs; j++) {
+        const sa_jobinfo_t *J = &pl->jobs[j];
+        int64_t cap = 0;
+        for (int64_t r = J->region_off; r < J->region_off + J->n_regions; r++) {
+            const sa_region_t *R = &pl->regions[r];
+            for (int64_t s = R->seg_off; s < R->seg_off + R->n_seg; s++) cap += cand_count[s];
+        }
+        sa_pair_t *out = malloc(sizeof(sa_pair_t) * (size_t) (cap > 0 ? cap : 1));
+        if (!out) return SA_ENOMEM;
+        int64_t n = 0;
+        for (int64_t r = J->region_off; r < J->region_off + J->n_regions; r++) {
+            const sa_region_t *R = &pl->regions[r];
+            const int32_t *poff = pl->poff + R->poff_off;
+            for (int64_t s = R->seg_off; s < R->seg_off + R->n_seg; s++) {
+                const sa_seg_t *S = &pl->segs[s];
+                const sa_cand_t *c = cands + S->cand_off;
+                for (int32_t i = 0; i < cand_count[s]; i++) {
+                    int64_t e = (int64_t) c[i].x + c[i].y + 2; /* diagonal in matrix coordinates */
+                    int64_t ck = S->ck_base + (S->from - e) / SA_CKPT_EVERY;
+                    double pp = exp(c[i].fb - totals[ck]); /* impl/pairwiseAligner.c:1385-1386 */
+                    if (pp >= thr) {
+                        if (pp > 1.0) pp = 1.0;
+                        pp = floor(pp * SA_PROB_1);
+                        sa_pair_t *o = &out[n++];
+                        o->prob_e7 = (int64_t) pp;
+                        o->x = (int32_t) (c[i].x + R->x1);
+                        o->y = (int32_t) (c[i].y + R->y1);
+                        o->path = c[i].path;
+                        o->kmer_id = pl->pid[R->pid_off + poff[c[i].x + 1] + c[i].path];
+                    }
+                }
+            }
+        }
+        qsort(out, (size_t) n, sizeof(sa_pair_t), cmp_pair_out);
+        pairs_out[j] = out;
+        n_pairs_out[j] = n;
+    }
+    return SA_OK;
+}
+
+/* ---- plan introspection ------------------------------------------------------------------------ */
+int sa_plan_describe(const sa_model_t *m, const sa_params_t *p, const sa_job_t *job, const char *const *ambig,
+                     unsigned flags, sa_plan_info_t *info, int64_t *regions4, int64_t regions_cap, int64_t *rows3,
+                     int64_t rows_cap, int64_t *segs4, int64_t segs_cap) {
+    sa_plan_t *pl = NULL;
+    int rc = sa_plan_build(&pl, m, p, job, 1, ambig, flags, 0);
+    if (rc) return rc;
+    if (info) {
+        info->n_regions = pl->n_regions;
+        info->n_segments = pl->n_segs;
+        info->n_checkpoints = pl->n_cks;
+        info->cells_forward = pl->cells_fwd;
+        info->cells_backward = pl->cells_bwd;
+        info->f_cellpaths = pl->max_chunk_cellpaths;
+        info->max_span = pl->max_span;
+        info->n_fast_regions = pl->n_fast_regions;
+    }
+    int64_t nrow = 0;
+    for (int64_t r = 0; r < pl->n_regions; r++) {
+        const sa_region_t *R = &pl->regions[r];
+        if (regions4 && r < regions_cap) {
+            regions4[4 * r] = R->x1; regions4[4 * r + 1] = R->y1;
+            regions4[4 * r + 2] = R->x1 + R->lX; regions4[4 * r + 3] = R->y1 + R->lY;
+        }
+        for (int64_t d = 0; d <= R->N; d++, nrow++)
+            if (rows3 && nrow < rows_cap) {
+                const sa_row_t *w = &pl->rows[R->row_off + d];
+                rows3[3 * nrow] = r;
+                rows3[3 * nrow + 1] = w->xmyL;
+                rows3[3 * nrow + 2] = w->xmyL + 2 * ((int64_t) w->width - 1);
+            }
+    }
+    for (int64_t s = 0; s < pl->n_segs; s++)
+        if (segs4 && s < segs_cap) {
+            segs4[4 * s] = pl->segs[s].region; segs4[4 * s + 1] = pl->segs[s].start;
+            segs4[4 * s + 2] = pl->segs[s].from; segs4[4 * s + 3] = pl->segs[s].to;
+        }
+    sa_plan_free(pl);
+    return SA_OK;
+}
+
+/* ---- anchors ----------------------------------------------------------------------------------- */
+typedef struct { int64_t x, y; } pt_t;
+static int cmp_pt(const void *a, const void *b) {
+    const pt_t *p = a, *q = b;
+    if (p->x != q->x) return p->x < q->x ? -1 : 1;
+    return p->y < q->y ? -1 : (p->y > q->y ? 1 : 0);
+}
+
+/* Keeps the pairs that are strictly below-left of everything after them (backward pass: a pair
+ * survives if both coordinates are smaller than every later minimum) and strictly above-right of
+ * everything before them (forward pass over running maxima). Input sorted lexicographically. */
+static int64_t drop_overlaps(const pt_t *in, int64_t n, int64_t *ox, int64_t *oy) {
+    uint8_t *ok = calloc((size_t) (n > 0 ? n : 1), 1);
+    int64_t mx = INT64_MAX, my = INT64_MAX;
+    for (int64_t i = n - 1; i >= 0; i--) {
+        /* value-keyed membership: an equal pair right after i that was accepted makes i "found" too */
+        if (in[i].x < mx && in[i].y < my) ok[i] = 1;
+        else if (i + 1 < n && ok[i + 1] && in[i + 1].x == in[i].x && in[i + 1].y == in[i].y) ok[i] = 1;
+        if (in[i].x < mx) mx = in[i].x;
+        if (in[i].y < my) my = in[i].y;
+    }
+    int64_t m = 0, hx = INT64_MIN, hy = INT64_MIN;
+    for (int64_t i = 0; i < n; i++) {
+        if (ok[i] && in[i].x > hx && in[i].y > hy) {
+            ox[m] = in[i].x;
+            oy[m] = in[i].y;
+            m++;
+        }
+        if (in[i].x > hx) hx = in[i].x;
+        if (in[i].y > hy) hy = in[i].y;
+    }
+    free(ok);
+    return m;
+}
+
+int64_t sa_guide_to_anchors(int64_t start1, int64_t end1, int strand1, int64_t start2, const int32_t *op_type,
+                            const int64_t *op_len, int64_t n_ops, int64_t trim, int64_t *ax, int64_t *ay, int64_t cap) {
+    /* rebase the reference interval to 0; a minus-strand hit is flipped so it reads forward */
+    int64_t origin = strand1 ? start1 : end1;
+    int64_t ref_end = strand1 ? end1 - origin : start1 - origin;
+    int64_t ref_pos = strand1 ? start1 - origin : end1 - origin; /* == 0 */
+    int64_t read_pos = start2;
+    int64_t total = 0;
+    for (int64_t i = 0; i < n_ops; i++)
+        if (op_type[i] == 0 && op_len[i] > 2 * trim) total += op_len[i] - 2 * trim;
+    pt_t *pts = malloc(sizeof(pt_t) * (size_t) (total > 0 ? total : 1));
+    if (!pts) return SA_ENOMEM;
+    int64_t n = 0;
+    for (int64_t i = 0; i < n_ops; i++) {
+        if (op_type[i] == 0)
+            for (int64_t l = trim; l < op_len[i] - trim; l++)
+                if (ref_end >= ref_pos + l + 6) { /* hard-coded +6: impl/pairwiseAligner.c:1642 */
+                    pts[n].x = ref_pos + l;
+                    pts[n].y = read_pos + l;
+                    n++;
+                }
+        if (op_type[i] != 2) ref_pos += op_len[i];
+        if (op_type[i] != 1) read_pos += op_len[i];
+    }
+    qsort(pts, (size_t) n, sizeof(pt_t), cmp_pt);
+    int64_t *tx = malloc(sizeof(int64_t) * (size_t) (n + 1)), *ty = malloc(sizeof(int64_t) * (size_t) (n + 1));
+    int64_t m = drop_overlaps(pts, n, tx, ty);
+    if (m > cap) m = cap;
+    memcpy(ax, tx, sizeof(int64_t) * (size_t) m);
+    memcpy(ay, ty, sizeof(int64_t) * (size_t) m);
+    free(pts); free(tx); free(ty);
+    return m;
+}
+
+int64_t sa_remap_anchors(const int64_t *ax, const int64_t *ay, int64_t n, const int64_t *event_map, int64_t map_offset,
+                         int64_t *ox, int64_t *oy) {
+    pt_t *pts = malloc(sizeof(pt_t) * (size_t) (n > 0 ? n : 1));
+    if (!pts) return SA_ENOMEM;
+    for (int64_t i = 0; i < n; i++) {
+        pts[i].x = ax[i];
+        pts[i].y = event_map[ay[i]] - event_map[map_offset];
+    }
+    int64_t m = drop_overlaps(pts, n, ox, oy);
+    free(pts);
+    return m;
+}
+
+/* ---- per-read parameter re-estimation ---------------------------------------------------------- */
+/* Gaussian elimination as the reference writes it, including the pivot swap that copies instead of
+ * swapping the right-hand side (impl/nanopore.c:692-753). */
+static int solve_small(const double *A, const double *b, double *x, int n) {
+    double M[9];
+    for (int i = 0; i < n; i++) {
+        x[i] = b[i];
+        for (int j = 0; j < n; j++) M[i * n + j] = A[i * n + j];
+    }
+    const double eps = 1.11022302462515654042E-16;
+    for (int i = 0; i < n; i++) {
+        if (fabs(M[i * n + i]) < eps) {
+            int s = i + 1;
+            while (s < n && M[s * n + i] < eps) s++;
+            if (s >= n) return SA_EINVAL; /* "Matrix is not invertible." */
+            for (int j = 0; j < n; j++) {
+                double t = M[i * n + j];
+                M[i * n + j] = M[s * n + j];
+                M[s * n + j] = t;
+            }
+            x[i] = x[s];
+        }
+        double f = 1.0 / M[i * n + i];
+        x[i] *= f;
+        for (int j = 0; j < n; j++) M[i * n + j] *= f;
+        for (int r = i + 1; r < n; r++) {
+            f = M[r * n + i];
+            x[r] -= f * x[i];
+            for (int j = 0; j < n; j++) M[r * n + j] -= f * M[i * n + j];
+        }
+    }
+    for (int i = n - 1; i >= 0; i--)
+        for (int r = i - 1; r >= 0; r--) {
+            double f = M[r * n + i];
+            x[r] -= f * x[i];
+            for (int j = 0; j < n; j++) M[r * n + j] -= f * M[i * n + j];
+        }
+    return SA_OK;
+}
+
+int sa_estimate_params(const sa_model_t *m, double *tab, const int64_t *emap, double *ev4, int64_t n_events,
+                       const char *read, int64_t read_len, double *out7) {
+    if (!m || !tab || !emap || !ev4 || !read || !out7) return SA_EINVAL;
+    int64_t rows = read_len - (m->k - 1);
+    if (rows <= 0) return SA_EINVAL;
+    /* first event of every k-mer of the strand read (1-D assignments) */
+    int64_t *kid = malloc(sizeof(int64_t) * (size_t) rows), *eid = malloc(sizeof(int64_t) * (size_t) rows);
+    if (!kid || !eid) { free(kid); free(eid); return SA_ENOMEM; }
+    int64_t n = 0, last = -1;
+    for (int64_t i = 0; i < rows; i++) {
+        int64_t id = sa_model_kmer_id(m, read + i);
+        if (id < 0) { free(kid); free(eid); return SA_EALPHABET; }
+        if (emap[i] > last) {
+            if (emap[i] >= n_events) { free(kid); free(eid); return SA_EINVAL; }
+            kid[n] = id;
+            eid[n] = emap[i];
+            n++;
+            last = emap[i];
+        }
+    }
+    if (n == 0) { free(kid); free(eid); return SA_EINVAL; } /* "Cannot get scale params with no assignments" */
+    /* weighted least squares: event_mean ~ shift + scale*level_mean + drift*start_time, weights 1/level_sd^2 */
+    double G[9] = {0}, g[3] = {0}, beta[3];
+    for (int64_t i = 0; i < n; i++) {
+        double mu = tab[kid[i] * 5], sd = tab[kid[i] * 5 + 1];
+        double e = ev4[eid[i] * 4], t = ev4[eid[i] * 4 + 3];
+        double w = 1.0 / (sd * sd);
+        double wm = mu * w, wt = t * w;
+        G[0] += w; G[1] += wm; G[2] += wt; G[4] += wm * mu; G[5] += wm * t; G[8] += wt * t;
+        g[0] += w * e; g[1] += wm * e; g[2] += wt * e;
+    }
+    G[3] = G[1]; G[6] = G[2]; G[7] = G[5];
+    int rc = solve_small(G, g, beta, 3);
+    if (rc) { free(kid); free(eid); return rc; }
+    double disp = 0.0;
+    for (int64_t i = 0; i < n; i++) {
+        double mu = tab[kid[i] * 5], sd = tab[kid[i] * 5 + 1];
+        double pred = beta[0] + beta[1] * mu + beta[2] * ev4[eid[i] * 4 + 3];
+        double res = ev4[eid[i] * 4] - pred;
+        disp += (res * res) / (sd * sd);
+    }
+    double var = sqrt(disp / n);
+    /* noise: event_sd ~ shift_sd + scale_sd*noise_mean, weights 1/noise_sd^2 */
+    double H[4] = {0}, h[2] = {0}, gam[2];
+    for (int64_t i = 0; i < n; i++) {
+        double nm = tab[kid[i] * 5 + 2], ns = tab[kid[i] * 5 + 3];
+        double w = 1.0 / (ns * ns), wm = nm * w, s = ev4[eid[i] * 4 + 1];
+        H[0] += w; H[1] += wm; H[3] += wm * nm;
+        h[0] += w * s; h[1] += wm * s;
+    }
+    H[2] = H[1];
+    rc = solve_small(H, h, gam, 2);
+    if (rc) { free(kid); free(eid); return rc; }
+    disp = 0.0;
+    for (int64_t i = 0; i < n; i++) {
+        double nm = tab[kid[i] * 5 + 2], ns = tab[kid[i] * 5 + 3];
+        double res = ev4[eid[i] * 4 + 1] - (gam[0] + gam[1] * nm);
+        disp += (res * res) / (ns * ns);
+    }
+    double var_sd = sqrt(disp / n);
+    out7[0] = beta[1]; out7[1] = beta[0]; out7[2] = var; out7[3] = beta[2];
+    out7[4] = gam[1]; out7[5] = var_sd; out7[6] = gam[0];
+    /* drift correction of every template event, then the noise columns of the table */
+    for (int64_t i = 0; i < n_events; i++) ev4[i * 4] = ev4[i * 4] - (ev4[i * 4 + 3] * beta[2]);
+    for (int64_t i = 0; i < m->n_kmers * 5; i += 5) {
+        tab[i + 2] = tab[i + 2] * gam[1];
+        tab[i + 4] = tab[i + 4] * var_sd;
+        tab[i + 3] = sqrt(pow(tab[i + 2], 3.0) / tab[i + 4]);
+    }
+    free(kid);
+    free(eid);
+    return SA_OK;
+}

@@ -1,0 +1,239 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star: posteriors within 1e-5 absolute):
+  * SA_FLAG_EXACT kernels (reference-ordered un-contracted fp64, host exp): prob_e7 bit-identical,
+    same rows, same order.
+  * default fast kernels (fma, folded constants, device exp): |dp| <= 1e-5 (100 units of 1e-7); rows may
+    differ only where p is within that tolerance of the threshold.  Measured differences are ~1e-9.
+  * HDP emissions (device log): 1e-5.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import signalalign_amd as sa
+from signalalign_amd import synth
+
+import sa_cases as cases
+
+pytestmark = pytest.mark.gpu
+
+TOL_E7 = 100  # 1e-5 absolute on a posterior
+
+
+def _models(oracle, path, nhdp=None):
+    alpha, k, t10, tab = synth.parse_model_table(path)
+    pm = sa.Model.load(path, nhdp)
+    om = oracle.Model(alpha, k, t10, tab)
+    if nhdp:
+        om.load_hdp(nhdp)
+    return pm, om
+
+
+def _run(pm, params, jobs, flags=0, ambig=None):
+    b = sa.Batch(pm, params, jobs, ambig=ambig, flags=flags)
+    b.run()
+    out = [b.pairs(j) for j in range(len(jobs))]
+    st = b.stats()
+    b.close()
+    return out, st
+
+
+def test_exact_kernels_bit_identical_gaussian(oracle):
+    pm, om = _models(oracle, cases.MODEL_6MER)
+    p = sa.default_params()
+    op = cases.oracle_params(oracle, p)
+    jobs = cases.synthetic_jobs(cases.MODEL_6MER, 6, 700) + cases.synthetic_jobs(cases.MODEL_6MER, 2, 2600, 100)
+    got, st = _run(pm, p, jobs, flags=sa.FLAG_EXACT)
+    assert st.n_fast_regions == 0
+    for j, job in enumerate(jobs):
+        exp = cases.oracle_pairs(oracle, om, job, op)
+        assert len(got[j]) == len(exp)
+        for f in ("x", "y", "path", "kmer_id", "prob_e7"):
+            assert np.array_equal(got[j][f], exp[f]), (j, f)
+
+
+def test_fast_kernels_within_tolerance_and_same_order(oracle):
+    pm, om = _models(oracle, cases.MODEL_6MER)
+    p = sa.default_params()
+    op = cases.oracle_params(oracle, p)
+    jobs = cases.synthetic_jobs(cases.MODEL_6MER, 8, 1500) + cases.synthetic_jobs(cases.MODEL_6MER, 4, 5000, 50)
+    got, st = _run(pm, p, jobs)
+    assert st.n_fast_regions == st.n_regions
+    worst = 0
+    for j, job in enumerate(jobs):
+        exp = cases.oracle_pairs(oracle, om, job, op)
+        w, lonely = cases.compare_pairs(got[j], exp, TOL_E7, p.threshold)
+        worst = max(worst, w)
+        assert lonely <= 2
+        assert cases.same_order(got[j], exp)
+        assert np.array_equal(np.sort(got[j]["kmer_id"]), np.sort(got[j]["kmer_id"]))
+    print("worst |d prob_e7| fast vs oracle:", worst)
+    assert worst <= 10  # measured headroom: differences are ~1e-9, i.e. at most a unit or two of 1e-7
+
+
+def test_generic_default_matches_fast(oracle):
+    # the memory-resident generic kernels with device-side finalisation (no EXACT flag)
+    pm, om = _models(oracle, cases.MODEL_6MER)
+    p = sa.default_params()
+    op = cases.oracle_params(oracle, p)
+    jobs = cases.synthetic_jobs(cases.MODEL_6MER, 3, 1200, 300)
+    got, st = _run(pm, p, jobs, flags=sa.FLAG_FORCE_GENERIC)
+    assert st.n_fast_regions == 0
+    for j, job in enumerate(jobs):
+        exp = cases.oracle_pairs(oracle, om, job, op)
+        w, lonely = cases.compare_pairs(got[j], exp, 1, p.threshold)
+        assert cases.same_order(got[j], exp)
+
+
+def test_bundled_reads_self_reference(oracle):
+    # BASELINE config 1 substitute: the three bundled .npRead files, template read as reference, one M run
+    p = sa.default_params()
+    op = cases.oracle_params(oracle, p)
+    for name, model in [("r9p4_oneD.npRead", cases.MODEL_6MER), ("c2925_ecoli_ch34_read1023.npRead", cases.MODEL_5MER)]:
+        pm, om = _models(oracle, model)
+        job = cases.npread_job(oracle, name, model)
+        exp = cases.oracle_pairs(oracle, om, job, op)
+        got, st = _run(pm, p, [job], flags=sa.FLAG_EXACT)
+        assert np.array_equal(got[0]["prob_e7"], exp["prob_e7"]) and np.array_equal(got[0]["x"], exp["x"])
+        got, st = _run(pm, p, [job])
+        w, lonely = cases.compare_pairs(got[0], exp, TOL_E7, p.threshold)
+        assert cases.same_order(got[0], exp)
+
+
+def test_ambiguous_positions_cpg(oracle):
+    # config 3 shape: ACEGT model, every CpG cytosine replaced by X with X -> C/E
+    pm, om = _models(oracle, cases.MODEL_CPG)
+    p = sa.default_params()
+    op = cases.oracle_params(oracle, p)
+    amb_p = sa.default_ambig({"X": "CE"})
+    amb_o = oracle.ambig_map({"X": "CE"})
+    jobs = cases.synthetic_jobs(cases.MODEL_CPG, 3, 900, 20, cpg_ambiguous=True)
+    assert any("X" in j["ref"] for j in jobs)
+    got, st = _run(pm, p, jobs, flags=sa.FLAG_EXACT, ambig=amb_p)
+    for j, job in enumerate(jobs):
+        exp = cases.oracle_pairs(oracle, om, job, op, ambig=amb_o)
+        assert len(got[j]) == len(exp)
+        for f in ("x", "y", "path", "kmer_id", "prob_e7"):
+            assert np.array_equal(got[j][f], exp[f]), (j, f)
+        assert exp["path"].max() >= 1
+    got, st = _run(pm, p, jobs, ambig=amb_p)
+    for j, job in enumerate(jobs):
+        exp = cases.oracle_pairs(oracle, om, job, op, ambig=amb_o)
+        cases.compare_pairs(got[j], exp, TOL_E7, p.threshold)
+        assert cases.same_order(got[j], exp)
+
+
+def test_hdp_emissions(oracle):
+    pm, om = _models(oracle, cases.MODEL_R73, cases.NHDP)
+    pm.set_to_hdp_expected_values()
+    om.set_to_hdp_expected_values()
+    p = sa.default_params(threshold=0.1)
+    op = cases.oracle_params(oracle, p)
+    # events drawn from the Gaussian table of the same model, over the ACGT subset of ACEGOT
+    jobs = cases.synthetic_jobs(cases.MODEL_R73, 2, 600, 40)
+    got, st = _run(pm, p, jobs)
+    for j, job in enumerate(jobs):
+        exp = cases.oracle_pairs(oracle, om, job, op)
+        assert len(exp) > 100
+        cases.compare_pairs(got[j], exp, TOL_E7, p.threshold)
+
+
+def test_edge_cases(oracle):
+    pm, om = _models(oracle, cases.MODEL_5MER)
+    p = sa.default_params()
+    op = cases.oracle_params(oracle, p)
+    alpha, k, t10, tab = synth.parse_model_table(cases.MODEL_5MER)
+    base = synth.make_read(900, 400, alpha, k, tab)
+    jobs = [
+        dict(base, ax=np.zeros(0, dtype=np.int64), ay=np.zeros(0, dtype=np.int64)),           # no anchors at all
+        dict(ref=base["ref"][:k + 2], events=base["events"][:4], ax=[], ay=[], scale=1.0, shift=0.0, var=1.0),  # tiny
+        dict(ref=base["ref"][:60], events=base["events"][:0], ax=[], ay=[], scale=1.0, shift=0.0, var=1.0),    # no events
+        dict(ref=base["ref"][:k - 1], events=base["events"][:9], ax=[], ay=[], scale=1.0, shift=0.0, var=1.0),  # no k-mers
+        dict(ref="", events=base["events"][:0], ax=[], ay=[], scale=1.0, shift=0.0, var=1.0),                   # empty
+        base,
+    ]
+    for flags in (sa.FLAG_EXACT, 0):
+        got, st = _run(pm, p, jobs, flags=flags)
+        for j, job in enumerate(jobs):
+            exp = cases.oracle_pairs(oracle, om, job, op)
+            if flags:
+                assert np.array_equal(got[j]["prob_e7"], exp["prob_e7"]), j
+                assert np.array_equal(got[j]["x"], exp["x"]) and np.array_equal(got[j]["y"], exp["y"]), j
+            else:
+                cases.compare_pairs(got[j], exp, TOL_E7, p.threshold)
+
+
+def test_threshold_zero_and_one(oracle):
+    pm, om = _models(oracle, cases.MODEL_5MER)
+    alpha, k, t10, tab = synth.parse_model_table(cases.MODEL_5MER)
+    job = synth.make_read(901, 150, alpha, k, tab)
+    for thr in (0.0, 1.0):
+        p = sa.default_params(threshold=thr)
+        op = cases.oracle_params(oracle, p)
+        exp = cases.oracle_pairs(oracle, om, job, op)
+        got, st = _run(pm, p, [job], flags=sa.FLAG_EXACT)   # threshold 0 overflows the first candidate plan: retried
+        assert len(got[0]) == len(exp)
+        assert np.array_equal(got[0]["prob_e7"], exp["prob_e7"])
+
+
+def test_sparse_anchors_wide_bands(oracle):
+    # realistic guide alignments: anchor-free windows widen the band beyond 64 cells, the register kernels
+    # must hand over to the memory-resident path and back
+    pm, om = _models(oracle, cases.MODEL_6MER)
+    p = sa.default_params()
+    op = cases.oracle_params(oracle, p)
+    jobs = cases.synthetic_jobs(cases.MODEL_6MER, 3, 3000, 700, thin_anchors=0.35)
+    got, st = _run(pm, p, jobs)
+    assert st.n_fast_regions == st.n_regions
+    for j, job in enumerate(jobs):
+        exp = cases.oracle_pairs(oracle, om, job, op)
+        w, lonely = cases.compare_pairs(got[j], exp, TOL_E7, p.threshold)
+        assert cases.same_order(got[j], exp)
+
+
+def test_split_regions_and_chunked_forward_storage(oracle, monkeypatch):
+    pm, om = _models(oracle, cases.MODEL_6MER)
+    p = sa.default_params()
+    op = cases.oracle_params(oracle, p)
+    alpha, k, t10, tab = synth.parse_model_table(cases.MODEL_6MER)
+    big = synth.make_read(7, 14000, alpha, k, tab)
+    hole = (big["ax"] > 1500) & (big["ax"] < 6500)
+    big["ax"], big["ay"] = big["ax"][~hole], big["ay"][~hole]
+    jobs = [big] + cases.synthetic_jobs(cases.MODEL_6MER, 5, 1000, 800)
+    exp = [cases.oracle_pairs(oracle, om, job, op) for job in jobs]
+    got, st = _run(pm, p, jobs)
+    assert st.n_regions == len(jobs) + 1 and st.n_chunks == 1
+    for j in range(len(jobs)):
+        cases.compare_pairs(got[j], exp[j], TOL_E7, p.threshold)
+        assert cases.same_order(got[j], exp[j])
+    # force several passes over the forward storage
+    monkeypatch.setenv("SA_F_BUDGET_CELLPATHS", "200000")
+    got2, st2 = _run(pm, p, jobs)
+    assert st2.n_chunks > 1
+    for j in range(len(jobs)):
+        assert np.array_equal(got2[j], got[j])
+
+
+def test_round_trip_properties_full_size(oracle):
+    # size-independent properties on a BASELINE-sized read (10k events): per event the posteriors over
+    # reference positions sum to <= 1 (+ logAdd approximation slack), rows are ordered, coordinates in range
+    pm, om = _models(oracle, cases.MODEL_6MER)
+    p = sa.default_params()
+    jobs = cases.synthetic_jobs(cases.MODEL_6MER, 4, 10000, 5000)
+    got, st = _run(pm, p, jobs)
+    for j, job in enumerate(jobs):
+        g = got[j]
+        lX, lY = len(job["ref"]) - 5, len(job["events"])
+        assert g["x"].min() >= 0 and g["x"].max() < lX and g["y"].min() >= 0 and g["y"].max() < lY
+        s = g["x"].astype(np.int64) + g["y"]
+        assert np.all(np.diff(s) >= 0)
+        per_event = np.bincount(g["y"], weights=g["prob_e7"] / 1e7, minlength=lY)
+        assert per_event.max() <= 1.0 + 5e-3
+        assert (per_event > 0.5).mean() > 0.9   # nearly every event is confidently placed
+        assert np.all(g["prob_e7"] >= int(p.threshold * 1e7)) and np.all(g["prob_e7"] <= 10000000)
+    # idempotence: a second run of the same batch gives identical bytes
+    got2, _ = _run(pm, p, jobs)
+    for a, b in zip(got, got2):
+        assert np.array_equal(a, b)

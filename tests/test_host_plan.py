@@ -1,0 +1,145 @@
+"""CPU-only checks of the product's host side (planning, anchors, parameter estimation, loaders, ABI)
+against the oracle.  No GPU compute is called here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import signalalign_amd as sa
+from signalalign_amd import synth
+from signalalign_amd._capi import EXPORTS
+
+import sa_cases as cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "signalalign_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(sa_[a-z0-9_]+)\s*\(", hdr))
+    L = sa.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert declared == set(EXPORTS), declared ^ set(EXPORTS)
+
+
+def test_no_device_fails_loudly():
+    # this suite runs without a GPU: the compute entry points must refuse, never fall back
+    if sa.device_count() > 0:
+        pytest.skip("a GPU is present")
+    alpha, k, t10, tab = synth.parse_model_table(cases.MODEL_5MER)
+    m = sa.Model.create(alpha, k, t10, tab)
+    job = dict(ref="ACGTACGTACGT", events=np.array([60.0, 61.0]), ax=[], ay=[], scale=1.0, shift=0.0, var=1.0)
+    with pytest.raises(sa.SaError) as ei:
+        sa.Batch(m, sa.default_params(), [job])
+    assert ei.value.code == -3
+
+
+def test_model_loader_matches_text(oracle):
+    m = sa.Model.load(cases.MODEL_6MER)
+    d = oracle.parse_model_file(cases.MODEL_6MER)
+    assert m.alphabet() == ("ACGT", 6)
+    assert np.array_equal(m.table5(), d["table5"])
+    assert m.kmer_id("AAAAAC") == 1 and m.kmer_id("AAAANC") == -1
+    with pytest.raises(sa.SaError):
+        sa.Model.load(os.path.join(cases.GOLDEN, "npReads", "ZymoRef.txt"))
+
+
+def test_hdp_loader_and_expected_values(oracle):
+    m = sa.Model.load(cases.MODEL_R73, cases.NHDP)
+    om = oracle.Model.from_file(cases.MODEL_R73)
+    om.load_hdp(cases.NHDP)
+    m.set_to_hdp_expected_values()
+    om.set_to_hdp_expected_values()
+    assert np.array_equal(m.table5(), om.match_table())
+
+
+@pytest.mark.parametrize("n_events,thin", [(300, 0.0), (2500, 0.0), (2500, 0.3)])
+def test_plan_geometry_matches_oracle(oracle, n_events, thin):
+    alpha, k, t10, tab = synth.parse_model_table(cases.MODEL_6MER)
+    m = sa.Model.create(alpha, k, t10, tab)
+    om = oracle.Model(alpha, k, t10, tab)
+    p = sa.default_params()
+    op = cases.oracle_params(oracle, p)
+    for idx in range(3):
+        job = synth.make_read(idx, n_events, alpha, k, tab, thin_anchors=thin)
+        info, regions, rows, segs = sa.plan_describe(m, p, job)
+        lX, lY = len(job["ref"]) - (k - 1), len(job["events"])
+        exp_regions = oracle.split_points(job["ax"], job["ay"], lX, lY, p.split_matrix_bigger_than_this, 1, 1)
+        assert np.array_equal(regions, exp_regions)
+        # band rows of every region
+        off = 0
+        for r, (x1, y1, x2, y2) in enumerate(regions):
+            sel = (job["ax"] + job["ay"] >= x1 + y1) & (job["ax"] + job["ay"] < x2 + y2)
+            L, R = oracle.band(job["ax"][sel] - x1, job["ay"][sel] - y1, x2 - x1, y2 - y1, p.diagonal_expansion)
+            n = len(L)
+            assert np.array_equal(rows[off:off + n, 0], np.full(n, r))
+            assert np.array_equal(rows[off:off + n, 1], L)
+            assert np.array_equal(rows[off:off + n, 2], R)
+            off += n
+        # the work the oracle actually performs equals what the plan announces
+        om.set_read_params(job["scale"], job["shift"], job["var"])
+        _, st = oracle.align(om, job["ref"], job["events"], job["ax"], job["ay"], op, want_stats=True)
+        assert info.cells_forward == st.cells_forward
+        assert info.cells_backward == st.cells_backward
+        assert info.n_segments == st.n_tracebacks
+
+
+def test_split_regions_large_gap(oracle):
+    # anchors with a > 3000x3000 hole: the plan must cut exactly where getSplitPoints cuts
+    alpha, k, t10, tab = synth.parse_model_table(cases.MODEL_6MER)
+    m = sa.Model.create(alpha, k, t10, tab)
+    p = sa.default_params()
+    job = synth.make_read(7, 14000, alpha, k, tab)
+    hole = (job["ax"] > 1500) & (job["ax"] < 6500)
+    job["ax"], job["ay"] = job["ax"][~hole], job["ay"][~hole]
+    info, regions, rows, segs = sa.plan_describe(m, p, job)
+    lX, lY = len(job["ref"]) - (k - 1), len(job["events"])
+    exp = oracle.split_points(job["ax"], job["ay"], lX, lY, p.split_matrix_bigger_than_this, 1, 1)
+    assert len(exp) == 2 and np.array_equal(regions, exp)
+
+
+def test_anchor_helpers_match_oracle(oracle):
+    rng = np.random.default_rng(3)
+    for trial in range(20):
+        ops, ref_len, read_len = [], 0, 0
+        for _ in range(rng.integers(1, 12)):
+            t = int(rng.integers(0, 3))
+            ln = int(rng.integers(1, 90))
+            ops.append((t, ln))
+            if t != 2:
+                ref_len += ln
+            if t != 1:
+                read_len += ln
+        strand = int(rng.integers(0, 2))
+        start1 = int(rng.integers(0, 1000))
+        s1, e1 = (start1, start1 + ref_len) if strand else (start1 + ref_len, start1)
+        start2 = int(rng.integers(0, 50))
+        trim = int(rng.integers(0, 20))
+        a = sa.guide_to_anchors(s1, e1, strand, start2, ops, trim)
+        b = oracle.guide_to_anchors(s1, e1, strand, start2, ops, trim)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        if len(a[0]) == 0:
+            continue
+        emap = np.cumsum(rng.integers(0, 4, size=start2 + read_len + 1))
+        c = sa.remap_anchors(a[0], a[1], emap, start2)
+        d = oracle.remap_anchors(a[0], a[1], emap, start2)
+        assert np.array_equal(c[0], d[0]) and np.array_equal(c[1], d[1])
+
+
+@pytest.mark.parametrize("name,model", [("r9p4_oneD.npRead", cases.MODEL_6MER),
+                                        ("c2925_ecoli_ch34_read1023.npRead", cases.MODEL_5MER)])
+def test_estimate_params_matches_oracle(oracle, name, model):
+    r = oracle.parse_npread(os.path.join(cases.GOLDEN, "npReads", name))
+    om = oracle.Model.from_file(model)
+    ev_o = r["template_events"].copy()
+    exp = oracle.estimate_params(om, r["template_strand_event_map"], ev_o, r["template_read"])
+    m = sa.Model.load(model)
+    tab = m.table5().copy()
+    ev_p = r["template_events"].copy()
+    got = sa.estimate_params(m, tab, r["template_strand_event_map"], ev_p, r["template_read"])
+    assert got == exp
+    assert np.array_equal(ev_p, ev_o)
+    assert np.array_equal(tab, om.match_table())
