@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X pair-HMM path.
+
+One "step" = one pass of the hot path (forward, backward/posterior, fold, finalisation, result copy) over
+one batch of synthetic reads whose inputs are ALREADY resident in HBM (sa_batch_create uploaded them).
+Workload at every N: BASELINE.json configs[1] per GPU -- R9.4 6-mer template Gaussian HMM, 2000 synthetic
+5k-event reads, band (diagonal expansion) 50, threshold 0.01, traceBackDiagonals 100 -- i.e. weak scaling:
+reads are independent, each rank aligns its own 2000 (different seeds), no collective on the data path.
+
+metric: DP cell updates per second: sum over reads, traceback segments and
+anti-diagonals of width x paths, forward sweep plus backward sweep actually executed.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+MODEL = os.path.join(ROOT, "tests", "golden", "models", "testModelR9.4_450bps.nucleotide.6mer.template.model")
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ALGO_BYTES_PER_CELL = 24.0     # 3 fp64 states of every band cell, written once, read once
+
+
+def cpu_baseline(alpha, k, t10, tab, n_events, reads_per_thread, first_index):
+    """The CPU restatement (oracle, 'port') on a bounded sample of the same workload, one read per thread."""
+    from oracle import sa_oracle_py as oracle
+    from signalalign_amd import synth
+    cores = min(os.cpu_count() or 1, 16)
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    n = cores * reads_per_thread
+    jobs = synth.make_jobs(n, n_events, alpha, k, tab, first_index=first_index)
+    om = oracle.Model(alpha, k, t10, tab)
+    p = oracle.default_params()
+    t0 = time.perf_counter()
+    npairs, cells = oracle.align_batch_mt(om, jobs, p, cores)
+    dt = time.perf_counter() - t0
+    return dict(value=float(cells.sum() / dt), unit="cell_updates/s", cores=cores, kind="port",
+                sample="%d reads x %d events (same generator and parameters as the GPU workload), oracle/sa_oracle.c, "
+                       "%d threads, %.1f s wall" % (n, n_events, cores, dt),
+                events_per_s=float(sum(len(j["events"]) for j in jobs) / dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=2000, help="reads per GPU (BASELINE configs[1]: 2000)")
+    ap.add_argument("--events", type=int, default=5000, help="events per read (BASELINE configs[1]: 5000)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reads-per-thread", type=int, default=10)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl")  # RCCL; only used for the barrier and the max-over-ranks
+    import signalalign_amd as sa
+    from signalalign_amd import synth
+
+    alpha, k, t10, tab = synth.parse_model_table(MODEL)
+    pm = sa.Model.load(MODEL)
+    params = sa.default_params(threshold=0.01, expansion=50, trace_back=100)
+    # every rank aligns its own reads: seeds are offset by rank
+    jobs = synth.make_jobs(args.reads, args.events, alpha, k, tab, first_index=rank * args.reads)
+    n_events_total = sum(len(j["events"]) for j in jobs)
+    batch = sa.Batch(pm, params, jobs, device=local_rank if world > 1 else 0)
+    st0 = batch.stats()
+    cells = st0.cells_forward + st0.cells_backward
+
+    def sync():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.run()
+    sync()
+    t0 = time.perf_counter()
+    ms_f = ms_b = ms_fold = 0.0
+    for _ in range(args.steps):
+        batch.run()  # synchronous: returns when the pairs are on the host
+        s = batch.stats()
+        ms_f += s.ms_forward
+        ms_b += s.ms_backward
+        ms_fold += s.ms_fold
+    sync()
+    dt = time.perf_counter() - t0
+    n_pairs = sum(batch.n_pairs(j) for j in range(len(jobs)))
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tot = torch.tensor([cells, float(n_events_total)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        cells_all, events_all = float(tot[0].item()), float(tot[1].item())
+    else:
+        cells_all, events_all = cells, float(n_events_total)
+
+    if rank == 0:
+        K = args.steps
+        ms_f, ms_b, ms_fold = ms_f / K, ms_b / K, ms_fold / K
+        # dominant kernel of rank 0, timed with HIP events on the library's own stream
+        if ms_b >= ms_f:
+            dom, dom_ms, dom_cells = "k_bwd_fast", ms_b, st0.cells_backward
+        else:
+            dom, dom_ms, dom_cells = "k_fwd_fast", ms_f, st0.cells_forward
+        achieved = ALGO_BYTES_PER_CELL * dom_cells / (dom_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")  # written from the rocprofv3 --pmc passes, see DESIGN.md
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "dp_cell_updates_per_s",
+            "value": cells_all * K / dt,
+            "unit": "cell_updates/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": args.warmup,
+            "ms_per_step": dt / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: R9.4 6-mer template Gaussian HMM, %d synthetic %d-event reads per GPU, "
+                            "band=50, threshold 0.01, traceBackDiagonals 100" % (args.reads, args.events),
+                "reads_per_gpu": args.reads, "events_per_read": args.events,
+                "events_per_s": events_all * K / dt,
+                "cells_per_event": cells / max(n_events_total, 1),
+                "pairs_rank0": n_pairs,
+                "regions_on_register_kernels": "%d/%d" % (st0.n_fast_regions, st0.n_regions),
+                "forward_storage_passes": int(st0.n_chunks),
+                "kernel_ms": {"forward": ms_f, "backward_posterior": ms_b, "fold": ms_fold},
+                "kernel_cell_updates_per_s": {"forward": st0.cells_forward / (ms_f * 1e-3),
+                                              "backward_posterior": st0.cells_backward / (ms_b * 1e-3)},
+            },
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL * dom_cells,
+                         "launch_ms": dom_ms},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(alpha, k, t10, tab, args.events, args.cpu_reads_per_thread,
+                                               first_index=10 ** 6)
+        print(json.dumps(out))
+    batch.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -240,34 +240,6 @@ __global__ __launch_bounds__(64) void k_fwd_generic(DevPlan P, const int *region
 }
 
 // ---------------------------------------------------------------------------------------------------
-// candidate append: wave-private slice, order = (diagonal descending, cell ascending, path ascending)
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void cand_append(const DevPlan &P, const sa_seg_t *S, int seg, int &count, bool pass,
-                                            int rank_key_lane, int x, int y, int path, double fb) {
-    // rank_key_lane: position of this lane in cell order (0..63); lanes are ranked by it
-    unsigned long long mask = __ballot(pass);
-    if (mask == 0ull) return;
-    // build the mask in cell order
-    unsigned long long mine = pass ? (1ull << rank_key_lane) : 0ull;
-    unsigned long long ordered = mine;
-    for (int off = 32; off > 0; off >>= 1) ordered |= __shfl_xor(ordered, off, 64);
-    int rank = __popcll(ordered & ((1ull << rank_key_lane) - 1ull));
-    int total = __popcll(ordered);
-    if (pass) {
-        int pos = count + rank;
-        if (pos < S->cand_cap) {
-            sa_cand_t c;
-            c.x = x; c.y = y; c.path = path; c.pad = 0; c.fb = fb;
-            P.cands[S->cand_off + pos] = c;
-        } else {
-            P.overflow[0] = 1;
-        }
-    }
-    count += total;
-    (void) seg;
-}
-
-// ---------------------------------------------------------------------------------------------------
 // generic backward + posterior numerators + checkpoint terms.
 // The reference scatters (doTransitionBackward, impl/pairwiseAligner.c:866-871); here each cell GATHERS
 // the same terms in the same order: first from (x+1,y+1) (it was that cell's "middle"), then from (x,y+1)
@@ -407,19 +379,36 @@ __global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_id
             int i = c * 64 + lane;
             bool in = i < re.width;
             long long x = x0 + (in ? i : 0), y = e - x;
-            int np = in ? poff[x + 1] - poff[x] : 0;
-            int maxnp = wave_max_i(np);
+            int np = (in && x > 0 && y > 0) ? poff[x + 1] - poff[x] : 0;
             const double *cf = F + 3 * (re.foff + poff[x] - poff[x0]);
             const double *cb = Be + 3 * (poff[x] - poff[x0]);
-            for (int q = 0; q < maxnp; q++) {
-                double fb = NEG_INF;
-                bool pass = false;
-                if (q < np && x > 0 && y > 0) {
-                    fb = cf[3 * q] + cb[3 * q];
-                    pass = (Mc > NEG_INF) && (fb >= Mc + P.log_thr - SA_CAND_EPS);
-                }
-                cand_append(P, S, seg, count, pass, lane, (int) (x - 1), (int) (y - 1), q, fb);
+            const double lim = Mc + P.log_thr - SA_CAND_EPS;
+            int mine = 0;
+            if (Mc > NEG_INF)
+                for (int q = 0; q < np; q++) mine += (cf[3 * q] + cb[3 * q] >= lim) ? 1 : 0;
+            // exclusive prefix over lanes: candidates are laid out cell by cell, path by path
+            int incl = mine;
+            for (int off = 1; off < 64; off <<= 1) {
+                int o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
             }
+            int total = __shfl(incl, 63, 64);
+            int pos = count + incl - mine;
+            if (mine > 0)
+                for (int q = 0; q < np; q++) {
+                    double fb = cf[3 * q] + cb[3 * q];
+                    if (fb >= lim) {
+                        if (pos < S->cand_cap) {
+                            sa_cand_t cd;
+                            cd.x = (int) (x - 1); cd.y = (int) (y - 1); cd.path = q; cd.pad = 0; cd.fb = fb;
+                            P.cands[S->cand_off + pos] = cd;
+                        } else {
+                            P.overflow[0] = 1;
+                        }
+                        pos++;
+                    }
+                }
+            count += total;
         }
     }
     if (lane == 0) P.cand_count[seg] = count < S->cand_cap ? count : S->cand_cap;
