@@ -656,7 +656,11 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     TRY(upload(&b->d_poff, pl->poff, pl->n_poff));
     TRY(upload(&b->d_pid, pl->pid, pl->n_pid));
     TRY(upload(&b->d_xc, pl->xc, 4 * pl->n_pid));
-    TRY(upload(&b->d_ev, pl->ev, pl->n_ev));
+    {   // one readable element of padding: the kernels clamp event indices to 0 even for reads without events
+        std::vector<double> evp((size_t) pl->n_ev + 8, 0.0);
+        if (pl->n_ev) memcpy(evp.data(), pl->ev, sizeof(double) * (size_t) pl->n_ev);
+        TRY(upload(&b->d_ev, evp.data(), (long long) evp.size()));
+    }
     TRY(upload(&b->d_segs, pl->segs, pl->n_segs));
     TRY(upload(&b->d_cks, pl->cks, pl->n_cks));
     {   // model tables
