@@ -48,6 +48,7 @@ struct DevModel {
 struct DevPlan {
     const sa_region_t *regions;
     const sa_row_t *rows;
+    const int *pk;
     const int *poff;
     const int *pid;
     const double *xc;
@@ -418,19 +419,70 @@ __global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_id
 // fold: totalProbability of every checkpoint, folded exactly as dpDiagonal_dotProduct does
 // (impl/pairwiseAligner.c:1167-1180): a left fold over the cells in ascending x-y.
 // ---------------------------------------------------------------------------------------------------
+// branch-free form of la_exact (same comparisons, same un-contracted polynomial), coefficients from LDS
+__device__ __forceinline__ double la_exact_bf(const double *tab, double x, double y) {
+    double mx = __builtin_fmax(x, y);
+    double mn = __builtin_fmin(x, y);
+    double d = mx - mn;
+    int idx = (d > 1.0 ? 1 : 0) + (d > 2.5 ? 1 : 0) + (d > 4.5 ? 1 : 0);
+    const double4 c = *reinterpret_cast<const double4 *>(tab + 4 * idx);
+    double r = ((c.x * d + c.y) * d + c.z) * d + c.w;
+    r = r + mn;
+    return (d < 7.5) ? r : mx;
+}
+
+// One wave folds 64 consecutive checkpoints, one per lane.  Their per-cell terms are contiguous per checkpoint in
+// vbuf; they are brought in with coalesced loads (one checkpoint per load instruction) and transposed through LDS so
+// that every lane then walks its own checkpoint sequentially.
+#define FOLD_LD 65
 __global__ __launch_bounds__(64) void k_fold(DevPlan P, long long n_ck) {
-    long long ck = (long long) blockIdx.x * 64 + threadIdx.x;
-    if (ck >= n_ck) return;
-    sa_ck_t c = P.cks[ck];
-    const double *v = P.vbuf + c.voff;
-    double t = NEG_INF;
-    for (int i = 0; i < c.nA; i++) t = la_exact(t, v[i]);
-    if (c.nB > 0) {
-        double tb = NEG_INF;
-        for (int i = 0; i < c.nB; i++) tb = la_exact(tb, v[c.nA + i]);
-        t = la_exact(t, tb);
+    __shared__ double tile[64 * FOLD_LD];
+    __shared__ __attribute__((aligned(32))) double LT[16];
+    const int lane = threadIdx.x;
+    if (lane < 4) {
+        const float a3[4] = {-0.009350833524763f, -0.014532321752540f, -0.004605031767994f, -0.000458661602210f};
+        const float a2[4] = {0.130659527668286f, 0.139942324101744f, 0.063427417320019f, 0.009695946122598f};
+        const float a1[4] = {0.498799810682272f, 0.495635523139337f, 0.695956496475118f, 0.930734667215156f};
+        const float a0[4] = {0.693203116424741f, 0.692140569840976f, 0.514272634594009f, 0.168037164329057f};
+        LT[4 * lane + 0] = (double) a3[lane]; LT[4 * lane + 1] = (double) a2[lane];
+        LT[4 * lane + 2] = (double) a1[lane]; LT[4 * lane + 3] = (double) a0[lane];
     }
-    P.totals[ck] = t;
+    const long long ckid = (long long) blockIdx.x * 64 + lane;
+    sa_ck_t ck = {0, 0, 0};
+    if (ckid < n_ck) ck = P.cks[ckid];
+    const int len = ck.nA + ck.nB;
+    const int maxlen = wave_max_i(len);
+    const int vo_lo = (int) (ck.voff & 0xffffffffll), vo_hi = (int) (ck.voff >> 32);
+    double tA = NEG_INF, tB = NEG_INF;
+    __syncthreads();
+    for (int j0 = 0; j0 < maxlen; j0 += 64) {
+        for (int c0 = 0; c0 < 64; c0 += 8) {  // eight checkpoints' loads in flight before the first LDS write
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int c = c0 + k;
+                const int ln = __builtin_amdgcn_readlane(len, c);
+                const long long vo = ((long long) __builtin_amdgcn_readlane(vo_hi, c) << 32) |
+                                     (unsigned int) __builtin_amdgcn_readlane(vo_lo, c);
+                v[k] = NEG_INF;
+                if (j0 + lane < ln) v[k] = P.vbuf[vo + j0 + lane];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) tile[lane * FOLD_LD + c0 + k] = v[k];
+        }
+        __syncthreads();
+        const int lim = maxlen - j0 < 64 ? maxlen - j0 : 64;
+        for (int i = 0; i < lim; i++) {
+            const double v = tile[i * FOLD_LD + lane];  // -inf past the end: logAdd(t, -inf) == t
+            const bool inA = (j0 + i) < ck.nA;
+            double acc = inA ? tA : tB;
+            acc = la_exact_bf(LT, acc, v);
+            tA = inA ? acc : tA;
+            tB = inA ? tB : acc;
+        }
+        __syncthreads();
+    }
+    if (ckid < n_ck) P.totals[ckid] = (ck.nB > 0) ? la_exact_bf(LT, tA, tB) : tA;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -543,7 +595,7 @@ struct sa_batch {
     unsigned flags;
     hipStream_t stream;
     // device buffers
-    sa_region_t *d_regions; sa_row_t *d_rows; int *d_poff; int *d_pid; double *d_xc; double *d_ev;
+    sa_region_t *d_regions; sa_row_t *d_rows; int *d_pk; int *d_poff; int *d_pid; double *d_xc; double *d_ev;
     sa_seg_t *d_segs; sa_ck_t *d_cks;
     double *d_F; double *d_vbuf; sa_cand_t *d_cands; int *d_cand_count; int *d_overflow; double *d_totals;
     double *d_bscratch;
@@ -557,7 +609,8 @@ struct sa_batch {
     std::vector<int> ids_flat;
     std::vector<long long> ids_off;
     // results
-    std::vector<sa_pair_t> pairs;
+    sa_pair_t *h_pairs;      // pinned host copy of all pairs, job after job
+    long long h_pairs_cap, n_pairs_total;
     std::vector<long long> job_off;
     bool ran;
     sa_batch_stats_t stats;
@@ -575,7 +628,7 @@ static DevPlan make_devplan(const sa_batch *b) {
     const sa_model_t *m = pl->model;
     DevPlan P;
     memset(&P, 0, sizeof(P));
-    P.regions = b->d_regions; P.rows = b->d_rows; P.poff = b->d_poff; P.pid = b->d_pid; P.xc = b->d_xc; P.ev = b->d_ev;
+    P.regions = b->d_regions; P.rows = b->d_rows; P.pk = b->d_pk; P.poff = b->d_poff; P.pid = b->d_pid; P.xc = b->d_xc; P.ev = b->d_ev;
     P.segs = b->d_segs; P.cks = b->d_cks; P.F = b->d_F; P.vbuf = b->d_vbuf; P.cands = b->d_cands;
     P.cand_count = b->d_cand_count; P.overflow = b->d_overflow; P.totals = b->d_totals; P.bscratch = b->d_bscratch;
     P.m.t_mm = m->t_mm; P.m.t_mx = m->t_mx; P.m.t_my = m->t_my; P.m.t_xm = m->t_xm; P.m.t_xx = m->t_xx;
@@ -599,7 +652,7 @@ static int upload(T **dst, const T *src, long long n) {
 void sa_batch_destroy(sa_batch_t *b) {
     if (!b) return;
     if (b->device >= 0) (void) hipSetDevice(b->device);
-    void *ptrs[] = {b->d_regions, b->d_rows, b->d_poff, b->d_pid, b->d_xc, b->d_ev, b->d_segs, b->d_cks, b->d_F,
+    void *ptrs[] = {b->d_regions, b->d_rows, b->d_pk, b->d_poff, b->d_pid, b->d_xc, b->d_ev, b->d_segs, b->d_cks, b->d_F,
                     b->d_vbuf, b->d_cands, b->d_cand_count, b->d_overflow, b->d_totals, b->d_bscratch, b->d_tab6,
                     b->d_hdp_slot, b->d_hdp_y, b->d_hdp_slope, b->d_hdp_grid, b->d_prob, b->d_seg_pass, b->d_seg_off,
                     b->d_out, b->d_ids};
@@ -608,6 +661,7 @@ void sa_batch_destroy(sa_batch_t *b) {
     for (int i = 0; i < 8; i++)
         if (b->ev[i]) (void) hipEventDestroy(b->ev[i]);
     if (b->stream) (void) hipStreamDestroy(b->stream);
+    if (b->h_pairs) (void) hipHostFree(b->h_pairs);
     sa_plan_free(b->plan);
     delete b;
 }
@@ -638,13 +692,14 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     b->flags = flags;
     b->stream = nullptr;
     b->ran = false;
-    b->d_regions = nullptr; b->d_rows = nullptr; b->d_poff = nullptr; b->d_pid = nullptr; b->d_xc = nullptr;
+    b->d_regions = nullptr; b->d_rows = nullptr; b->d_pk = nullptr; b->d_poff = nullptr; b->d_pid = nullptr; b->d_xc = nullptr;
     b->d_ev = nullptr; b->d_segs = nullptr; b->d_cks = nullptr; b->d_F = nullptr; b->d_vbuf = nullptr;
     b->d_cands = nullptr; b->d_cand_count = nullptr; b->d_overflow = nullptr; b->d_totals = nullptr;
     b->d_bscratch = nullptr; b->d_tab6 = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr;
     b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr;
     b->d_seg_off = nullptr; b->d_out = nullptr; b->d_ids = nullptr;
     b->cand_alloc = 0; b->out_alloc = 0;
+    b->h_pairs = nullptr; b->h_pairs_cap = 0; b->n_pairs_total = 0;
     memset(&b->stats, 0, sizeof(b->stats));
     for (int i = 0; i < 8; i++) b->ev[i] = nullptr;
 #define TRY(x) do { int rc_ = (x); if (rc_) { sa_batch_destroy(b); return rc_; } } while (0)
@@ -653,6 +708,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
         if (hipEventCreate(&b->ev[i]) != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
     TRY(upload(&b->d_regions, pl->regions, pl->n_regions));
     TRY(upload(&b->d_rows, pl->rows, pl->n_rows));
+    TRY(upload(&b->d_pk, pl->pk, pl->n_pk));
     TRY(upload(&b->d_poff, pl->poff, pl->n_poff));
     TRY(upload(&b->d_pid, pl->pid, pl->n_pid));
     TRY(upload(&b->d_xc, pl->xc, 4 * pl->n_pid));
@@ -818,8 +874,18 @@ int sa_batch_run(sa_batch_t *b) {
     }
     if (ov) return SA_ENOMEM;
     long long n_segs = pl->n_segs;
-    b->pairs.clear();
+    b->n_pairs_total = 0;
     b->job_off.assign((size_t) pl->n_jobs + 1, 0);
+    auto reserve_pairs = [&](long long total) -> int {
+        if (total > b->h_pairs_cap) {
+            if (b->h_pairs) HIPCHK(hipHostFree(b->h_pairs));
+            b->h_pairs = nullptr;
+            long long cap = total + total / 8 + 1024;
+            HIPCHK(hipHostMalloc((void **) &b->h_pairs, sizeof(sa_pair_t) * (size_t) cap, hipHostMallocDefault));
+            b->h_pairs_cap = cap;
+        }
+        return SA_OK;
+    };
     if (b->flags & SA_FLAG_EXACT) {
         // host finalisation with the C library's exp(): bit-identical to the reference's posterior arithmetic
         std::vector<sa_cand_t> cands((size_t) (pl->n_cand > 0 ? pl->n_cand : 1));
@@ -832,12 +898,19 @@ int sa_batch_run(sa_batch_t *b) {
         std::vector<int64_t> np((size_t) (pl->n_jobs > 0 ? pl->n_jobs : 1), 0);
         int rc = sa_plan_finalize(pl, cands.data(), counts.data(), totals.data(), pp.data(), np.data());
         if (rc) return rc;
+        long long total = 0;
+        for (long long j = 0; j < pl->n_jobs; j++) total += np[j];
+        rc = reserve_pairs(total);
+        if (rc) return rc;
+        total = 0;
         for (long long j = 0; j < pl->n_jobs; j++) {
-            b->job_off[j] = (long long) b->pairs.size();
-            b->pairs.insert(b->pairs.end(), pp[j], pp[j] + np[j]);
+            b->job_off[j] = total;
+            if (np[j]) memcpy(b->h_pairs + total, pp[j], sizeof(sa_pair_t) * (size_t) np[j]);
+            total += np[j];
             free(pp[j]);
         }
-        b->job_off[pl->n_jobs] = (long long) b->pairs.size();
+        b->job_off[pl->n_jobs] = total;
+        b->n_pairs_total = total;
     } else if (n_segs > 0) {
         DevPlan P = make_devplan(b);
         hipStream_t st = b->stream;
@@ -855,8 +928,9 @@ int sa_batch_run(sa_batch_t *b) {
         }
         if (total > 0) {
             hipLaunchKernelGGL(k_gather, dim3((unsigned) n_segs), dim3(64), 0, st, P, (int) n_segs, b->d_prob, b->d_seg_off, b->d_out);
-            b->pairs.resize((size_t) total);
-            HIPCHK(hipMemcpyAsync(b->pairs.data(), b->d_out, sizeof(sa_pair_t) * (size_t) total, hipMemcpyDeviceToHost, st));
+            int rcp = reserve_pairs(total);
+            if (rcp) return rcp;
+            HIPCHK(hipMemcpyAsync(b->h_pairs, b->d_out, sizeof(sa_pair_t) * (size_t) total, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
         }
         HIPCHK(hipGetLastError());
@@ -872,6 +946,7 @@ int sa_batch_run(sa_batch_t *b) {
             b->job_off[j] = seg_off[first_seg];
         }
         b->job_off[pl->n_jobs] = total;
+        b->n_pairs_total = total;
     }
     b->ran = true;
     return SA_OK;
@@ -888,7 +963,7 @@ int sa_batch_pairs(const sa_batch_t *b, int64_t job, sa_pair_t *out, int64_t cap
     if (!b->ran) return SA_ESTATE;
     long long n = b->job_off[job + 1] - b->job_off[job];
     if (n > cap) return SA_EINVAL;
-    if (n > 0) memcpy(out, b->pairs.data() + b->job_off[job], sizeof(sa_pair_t) * (size_t) n);
+    if (n > 0) memcpy(out, b->h_pairs + b->job_off[job], sizeof(sa_pair_t) * (size_t) n);
     return SA_OK;
 }
 int sa_batch_stats(const sa_batch_t *b, sa_batch_stats_t *out) {

@@ -61,6 +61,7 @@ typedef struct sa_region {
     int32_t ragged_l, ragged_r;
     int64_t x1, y1, lX, lY, N;
     int64_t row_off;  /* rows[row_off + d], d = 0..N                                   */
+    int64_t pk_off;   /* pk[pk_off + SA_PK_PAD + d]: packed band word of diagonal d     */
     int64_t poff_off; /* poff[poff_off + x], x = 0..lX+1 (region-relative path offsets) */
     int64_t pid_off;  /* pid / xc arrays: index pid_off + poff[x] + p                   */
     int64_t ev_off;   /* ev[ev_off + y-1] is the event of matrix row y                  */
@@ -75,6 +76,14 @@ typedef struct sa_region {
     double scale, shift, var, lvar; /* lvar = log(1/var), impl/stateMachine.c:602       */
     int64_t f_cellpaths;
 } sa_region_t;
+
+/* packed band word (register kernels): width | flags | ((x-y+K)>>1 of the first cell) << SA_PK_SHIFT */
+#define SA_PK_WIDTH_MASK 127
+#define SA_PK_FWD 128   /* diagonal d, d-1, d-2 (+1 cell each side) fit in 64 lanes        */
+#define SA_PK_BWD 256   /* diagonal e, e+1, e+2 fit in 64 lanes                            */
+#define SA_PK_FULL 512  /* all three forward planes of this diagonal are read back (checkpoint diagonal) */
+#define SA_PK_SHIFT 10
+#define SA_PK_PAD 64    /* readable words in front of diagonal 0; 96 behind diagonal N     */
 
 typedef struct sa_seg {
     int32_t region, at_end;
@@ -114,6 +123,7 @@ typedef struct sa_plan {
     sa_jobinfo_t *jobs;
     sa_region_t *regions; int64_t n_regions, cap_regions;
     sa_row_t *rows;       int64_t n_rows, cap_rows;
+    int32_t *pk;          int64_t n_pk, cap_pk;
     int32_t *poff;        int64_t n_poff, cap_poff;
     int32_t *pid;         int64_t n_pid, cap_pid;
     double *xc;           /* 4 doubles per pid entry: m, inv_s, cM, cY (read-params folded in) */

@@ -367,7 +367,7 @@ static int64_t expand_kmer(const sa_model_t *m, const char *s, const char *const
 /* ---- plan -------------------------------------------------------------------------------------- */
 void sa_plan_free(sa_plan_t *pl) {
     if (!pl) return;
-    free(pl->jobs); free(pl->regions); free(pl->rows); free(pl->poff); free(pl->pid); free(pl->xc); free(pl->ev);
+    free(pl->jobs); free(pl->regions); free(pl->rows); free(pl->pk); free(pl->poff); free(pl->pid); free(pl->xc); free(pl->ev);
     free(pl->segs); free(pl->cks);
     free(pl);
 }
@@ -467,6 +467,23 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
         rows[d].pad = 0;
         if (wr - wl + 1 > span) span = wr - wl + 1;
     }
+    /* packed band words for the register kernels */
+    GROW(pl, pk, n_pk, cap_pk, N + 1 + SA_PK_PAD + 96, int32_t);
+    R->pk_off = pl->n_pk;
+    {
+        int32_t *pk = pl->pk + pl->n_pk;
+        memset(pk, 0, sizeof(int32_t) * (size_t) (N + 1 + SA_PK_PAD + 96));
+        rows = pl->rows + R->row_off;
+        for (int64_t d = 0; d <= N; d++) {
+            int64_t uL = ((int64_t) rows[d].xmyL + K) >> 1;
+            int64_t w = rows[d].width;
+            int32_t word = (int32_t) ((w > SA_PK_WIDTH_MASK ? SA_PK_WIDTH_MASK : w) | ((uint32_t) uL << SA_PK_SHIFT));
+            if (rows[d].span3 <= 64) word |= SA_PK_FWD;
+            if (rows[d + 2 <= N ? d + 2 : N].span3 <= 64) word |= SA_PK_BWD;
+            pk[SA_PK_PAD + d] = word;
+        }
+        pl->n_pk += N + 1 + SA_PK_PAD + 96;
+    }
     R->f_cellpaths = foff;
     R->max_rowpaths = (int32_t) max_rowpaths;
     R->slots = (int32_t) ((span + 63) / 64);
@@ -508,6 +525,7 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
             int64_t e = S->from - SA_CKPT_EVERY * c;
             sa_ck_t *ck = &pl->cks[pl->n_cks++];
             ck->voff = pl->n_vbuf;
+            pl->pk[R->pk_off + SA_PK_PAD + e] |= SA_PK_FULL; /* dot(F,B) over all three states is taken here */
             ck->nA = rows[e].width;
             ck->nB = e < S->start ? rows[e + 1].width : 0;
             pl->n_vbuf += ck->nA + ck->nB;
@@ -557,14 +575,14 @@ static int fill_xc(sa_plan_t *pl) {
         for (int64_t i = 0; i < n; i++) {
             int32_t id = pl->pid[R->pid_off + i];
             double *o = pl->xc + 4 * (R->pid_off + i);
-            if (id < 0) {
-                o[0] = 0.0; o[1] = 0.0; o[2] = SA_NEG_INF; o[3] = SA_NEG_INF;
+            if (id < 0) { /* NULL k-mer: both emissions are log(0); inv_s = 1 keeps (e - m) * inv_s finite */
+                o[0] = 0.0; o[1] = 1.0; o[2] = SA_NEG_INF; o[3] = SA_NEG_INF;
                 continue;
             }
             double mu = m->table5[5 * (int64_t) id], sd = m->table5[5 * (int64_t) id + 1];
             o[0] = R->scale * mu + R->shift;
             if (sd == 0.0) { /* emissions_signal_logGaussPdf returns LOG_ZERO */
-                o[1] = 0.0; o[2] = SA_NEG_INF; o[3] = SA_NEG_INF;
+                o[1] = 1.0; o[2] = SA_NEG_INF; o[3] = SA_NEG_INF;
             } else {
                 o[1] = 1.0 / (R->var * sd);
                 o[2] = R->lvar + (-0.91893853320467267 - log(sd));
