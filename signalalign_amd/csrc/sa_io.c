@@ -196,3 +196,206 @@ done:
     nhdp_file_free(h);
     return rc;
 }
+
+/* ---- .npRead --------------------------------------------------------------------------------- */
+static int parse_i64_line(char *line, int64_t expect, int64_t **out) {
+    char **tok;
+    int64_t n = sa_split_ws(line, &tok);
+    if (n != expect) { free(tok); return SA_EIO; }
+    int64_t *v = malloc(sizeof(int64_t) * (size_t) (n > 0 ? n : 1));
+    for (int64_t i = 0; i < n; i++) v[i] = strtoll(tok[i], NULL, 10);
+    free(tok);
+    *out = v;
+    return SA_OK;
+}
+
+void sa_npread_free(sa_npread_t *r) {
+    if (!r) return;
+    free(r->two_d_read); free(r->template_read); free(r->complement_read);
+    free(r->template_strand_event_map); free(r->complement_strand_event_map);
+    free(r->template_event_map); free(r->complement_event_map);
+    free(r->template_events); free(r->complement_events);
+    free(r);
+}
+
+static char *first_token_copy(const char *line, int64_t want_len) {
+    while (*line == ' ' || *line == '\t') line++;
+    size_t n = strcspn(line, " \t\r\n");
+    char *s = malloc(n + 1 > (size_t) want_len + 1 ? n + 1 : (size_t) want_len + 1);
+    memcpy(s, line, n);
+    s[n] = 0;
+    if ((int64_t) n > want_len) s[want_len] = 0; /* the reference terminates at the declared length */
+    return s;
+}
+
+int sa_npread_load(const char *path, sa_npread_t **out) {
+    FILE *f = fopen(path, "r");
+    if (!f) return SA_EIO;
+    sa_npread_t *r = calloc(1, sizeof(*r));
+    char *ln[14];
+    memset(ln, 0, sizeof(ln));
+    int rc = SA_EIO;
+    for (int i = 0; i < 14; i++) {
+        ln[i] = sa_read_line(f);
+        if (!ln[i] && i < 10) goto done; /* the model_state / p_model lines are not used by the aligner */
+    }
+    {
+        char **t;
+        char *h = strdup(ln[0]);
+        int64_t n = sa_split_ws(h, &t);
+        if (n != 18) { free(t); free(h); goto done; }
+        r->read_length = strtoll(t[0], NULL, 10);
+        r->n_template_events = strtoll(t[1], NULL, 10);
+        r->n_complement_events = strtoll(t[2], NULL, 10);
+        r->template_read_length = strtoll(t[3], NULL, 10);
+        r->complement_read_length = strtoll(t[4], NULL, 10);
+        sa_strand_params_t *p[2] = {&r->template_params, &r->complement_params};
+        for (int s = 0; s < 2; s++) {
+            p[s]->scale = strtod(t[5 + 6 * s], NULL);
+            p[s]->shift = strtod(t[6 + 6 * s], NULL);
+            p[s]->var = strtod(t[7 + 6 * s], NULL);
+            p[s]->scale_sd = strtod(t[8 + 6 * s], NULL);
+            p[s]->var_sd = strtod(t[9 + 6 * s], NULL);
+            p[s]->drift = strtod(t[10 + 6 * s], NULL);
+            p[s]->shift_sd = 0.0;
+        }
+        r->two_d = (int) strtol(t[17], NULL, 10);
+        free(t);
+        free(h);
+    }
+    r->two_d_read = r->two_d ? first_token_copy(ln[1], r->read_length) : strdup("");
+    r->template_read = first_token_copy(ln[2], r->template_read_length);
+    if (parse_i64_line(ln[3], r->template_read_length, &r->template_strand_event_map)) goto done;
+    r->complement_read = r->two_d ? first_token_copy(ln[4], r->complement_read_length) : strdup("");
+    if (parse_i64_line(ln[5], r->complement_read_length, &r->complement_strand_event_map)) goto done;
+    if (parse_i64_line(ln[6], r->read_length, &r->template_event_map)) goto done;
+    r->template_events = parse_doubles(ln[7], r->n_template_events * 4);
+    if (!r->template_events && r->n_template_events) goto done;
+    if (parse_i64_line(ln[8], r->read_length, &r->complement_event_map)) goto done;
+    r->complement_events = parse_doubles(ln[9], r->n_complement_events * 4);
+    if (!r->complement_events && r->n_complement_events) goto done;
+    rc = SA_OK;
+done:
+    for (int i = 0; i < 14; i++) free(ln[i]);
+    fclose(f);
+    if (rc) { sa_npread_free(r); return rc; }
+    *out = r;
+    return SA_OK;
+}
+
+/* ---- cigar -------------------------------------------------------------------------------------- */
+void sa_cigar_free(sa_cigar_t *c) {
+    if (!c) return;
+    free(c->contig1); free(c->contig2); free(c->op_type); free(c->op_len);
+    free(c);
+}
+
+int sa_cigar_load(const char *path, sa_cigar_t **out) {
+    FILE *f = fopen(path, "r");
+    if (!f) return SA_EIO;
+    char *line = sa_read_line(f);
+    fclose(f);
+    if (!line) return SA_EIO;
+    char **t;
+    int64_t n = sa_split_ws(line, &t);
+    int rc = SA_EIO;
+    sa_cigar_t *c = calloc(1, sizeof(*c));
+    /* cigar: query qstart qend qstrand target tstart tend tstrand score (op len)* */
+    if (n >= 10 && strcmp(t[0], "cigar:") == 0 && (n - 10) % 2 == 0) {
+        c->contig2 = strdup(t[1]);
+        c->start2 = strtoll(t[2], NULL, 10);
+        c->end2 = strtoll(t[3], NULL, 10);
+        c->strand2 = t[4][0] == '+';
+        c->contig1 = strdup(t[5]);
+        c->start1 = strtoll(t[6], NULL, 10);
+        c->end1 = strtoll(t[7], NULL, 10);
+        c->strand1 = t[8][0] == '+';
+        c->score = strtod(t[9], NULL);
+        c->n_ops = (n - 10) / 2;
+        c->op_type = malloc(sizeof(int32_t) * (size_t) (c->n_ops > 0 ? c->n_ops : 1));
+        c->op_len = malloc(sizeof(int64_t) * (size_t) (c->n_ops > 0 ? c->n_ops : 1));
+        rc = SA_OK;
+        for (int64_t i = 0; i < c->n_ops; i++) {
+            char op = t[10 + 2 * i][0];
+            c->op_type[i] = op == 'M' ? 0 : (op == 'D' ? 1 : (op == 'I' ? 2 : -1));
+            c->op_len[i] = strtoll(t[11 + 2 * i], NULL, 10);
+            if (c->op_type[i] < 0 || c->op_len[i] < 0) rc = SA_EIO;
+        }
+    }
+    free(t);
+    free(line);
+    if (rc) { sa_cigar_free(c); return rc; }
+    *out = c;
+    return SA_OK;
+}
+
+/* ---- FASTA through its .fai index ---------------------------------------------------------------- */
+char *sa_fasta_fetch(const char *fasta_path, const char *name, int64_t start, int64_t end_incl, int *err) {
+    if (err) *err = 0;
+    size_t pl = strlen(fasta_path);
+    char *fai = malloc(pl + 5);
+    memcpy(fai, fasta_path, pl);
+    memcpy(fai + pl, ".fai", 5);
+    FILE *fi = fopen(fai, "r");
+    free(fai);
+    if (!fi) { if (err) *err = -1; return NULL; }
+    long long len = -1, off = 0, bases = 0, width = 0;
+    char *line;
+    while ((line = sa_read_line(fi)) != NULL) {
+        char **t;
+        int64_t n = sa_split_ws(line, &t);
+        if (n >= 5 && strcmp(t[0], name) == 0) {
+            len = strtoll(t[1], NULL, 10); off = strtoll(t[2], NULL, 10);
+            bases = strtoll(t[3], NULL, 10); width = strtoll(t[4], NULL, 10);
+            free(t); free(line);
+            break;
+        }
+        free(t);
+        free(line);
+    }
+    fclose(fi);
+    if (len < 0) { if (err) *err = -2; return NULL; }
+    if (start < 0) start = 0;
+    if (end_incl >= len) end_incl = len - 1;
+    int64_t n = end_incl >= start ? end_incl - start + 1 : 0;
+    char *seq = malloc((size_t) n + 1);
+    FILE *fa = fopen(fasta_path, "r");
+    if (!fa) { free(seq); if (err) *err = -1; return NULL; }
+    int64_t got = 0;
+    if (n > 0 && bases > 0) {
+        long long pos = off + (start / bases) * width + (start % bases);
+        fseek(fa, (long) pos, SEEK_SET);
+        int ch;
+        while (got < n && (ch = fgetc(fa)) != EOF) {
+            if (ch == '\n' || ch == '\r') continue;
+            seq[got++] = (char) ch;
+        }
+    }
+    fclose(fa);
+    seq[got] = 0;
+    return seq;
+}
+
+static char comp_char(char c) {
+    switch (c) {
+        case 'A': return 'T'; case 'T': return 'A'; case 'C': return 'G'; case 'G': return 'C';
+        case 'a': return 't'; case 't': return 'a'; case 'c': return 'g'; case 'g': return 'c';
+        default: return c;
+    }
+}
+char *sa_complement(const char *s) {
+    size_t n = strlen(s);
+    char *o = malloc(n + 1);
+    for (size_t i = 0; i < n; i++) o[i] = comp_char(s[i]);
+    o[n] = 0;
+    return o;
+}
+void sa_reverse_in_place(char *s) {
+    size_t n = strlen(s);
+    for (size_t i = 0; i + 1 < n - i; i++) { char t = s[i]; s[i] = s[n - 1 - i]; s[n - 1 - i] = t; }
+}
+char *sa_reverse_complement(const char *s) {
+    char *o = sa_complement(s);
+    sa_reverse_in_place(o);
+    return o;
+}

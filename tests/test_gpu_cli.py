@@ -1,0 +1,146 @@
+"""End-to-end test of the signalMachine drop-in: argv as src/signalalign/signalAlignment.py:450-463 builds it,
+real input files, TSV / stdout / stderr checked against the oracle plus the reference's format strings."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import sa_cases as cases
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "signalalign_amd", "bin", "signalMachine")
+
+
+def _write_fasta(path, name, seq, width=60):
+    with open(path, "w") as f:
+        f.write(">%s\n" % name)
+        for i in range(0, len(seq), width):
+            f.write(seq[i:i + width] + "\n")
+    with open(path + ".fai", "w") as f:
+        f.write("%s\t%d\t%d\t%d\t%d\n" % (name, len(seq), len(name) + 2, width, width + 1))
+
+
+def _expected_full_rows(oracle, model_path, npread_path, ref_name, label, ref_start, read_start, L, params):
+    """What writePosteriorProbsFull (impl/signalMachine.c:89-159) prints for a forward template alignment."""
+    r = oracle.parse_npread(npread_path)
+    om = oracle.Model.from_file(model_path)
+    ev = r["template_events"].copy()
+    read = r["template_read"]
+    pr = oracle.estimate_params(om, r["template_strand_event_map"], ev, read)
+    target = read[read_start:read_start + L]           # the reference IS the read here
+    gx, gy = oracle.guide_to_anchors(ref_start, ref_start + L, 1, read_start, [(0, L)], 14)
+    em = r["template_strand_event_map"]
+    ax, ay = oracle.remap_anchors(gx, gy, em, read_start)
+    lo, hi = int(em[read_start]), int(em[read_start + L - 1])
+    om.set_read_params(pr["scale"], pr["shift"], pr["var"])
+    pairs = oracle.align(om, target, ev[lo:hi], ax, ay, params)
+    tab = om.match_table()
+    k = om.k
+    alpha = om.alphabet
+    rows = []
+    for p in pairs:
+        x, y = int(p["x"]), int(p["y"]) + lo
+        kid = int(p["kmer_id"])
+        kmer = ""
+        t = kid
+        for _ in range(k):
+            kmer = alpha[t % len(alpha)] + kmer
+            t //= len(alpha)
+        e_mean, e_noise = tab[5 * kid], tab[5 * kid + 2]
+        desc = (ev[y, 0] + pr["var"] * e_mean - pr["scale"] * e_mean - pr["shift"]) / pr["var"]
+        rows.append("%s\t%d\t%s\t%s\t%s\t%d\t%f\t%f\t%f\t%s\t%f\t%f\t%f\t%f\t%f\t%s\n" % (
+            ref_name, x + ref_start, target[x:x + k], label, "t", y, ev[y, 0], ev[y, 1], ev[y, 2], target[x:x + k],
+            e_mean * pr["scale"] + pr["shift"], e_noise * pr["scale_sd"], int(p["prob_e7"]) / 1e7, desc, e_mean, kmer))
+    score = 100.0 * float(pairs["prob_e7"].astype(np.float64).sum()) / (len(pairs) * 1e7)
+    return rows, len(gx), len(pairs), score
+
+
+@pytest.mark.parametrize("npread,model", [("c2925_ecoli_ch34_read1023.npRead", cases.MODEL_5MER),
+                                          ("r9p4_oneD.npRead", cases.MODEL_6MER)])
+def test_signalmachine_full_tsv(oracle, tmp_path, npread, model):
+    assert os.path.exists(BIN), "signalMachine is not built"
+    npread_path = os.path.join(cases.GOLDEN, "npReads", npread)
+    r = oracle.parse_npread(npread_path)
+    read = r["template_read"]
+    # reference contig = 200 unrelated bases + the read + 150 bases; the guide alignment skips 10 read bases
+    rng = np.random.default_rng(1)
+    pre = "".join("ACGT"[i] for i in rng.integers(0, 4, 200))
+    post = "".join("ACGT"[i] for i in rng.integers(0, 4, 150))
+    read_start, L = 10, len(read) - 25
+    contig = pre + read[read_start:] + post
+    ref_start = len(pre)
+    fasta = str(tmp_path / "ref.fa")
+    _write_fasta(fasta, "chrTest", contig)
+    cigar = str(tmp_path / "guide.cigar")
+    with open(cigar, "w") as f:
+        f.write("cigar: read1 %d %d + chrTest %d %d + 1 M %d\n" % (read_start, read_start + L, ref_start, ref_start + L, L))
+    out = str(tmp_path / "out.tsv")
+    argv = [BIN, "--sm3Hdp"][:1] + ["-T", model, "-q", npread_path, "-f", fasta, "-n", "chrTest", "-p", cigar, "-u", out,
+                                    "-L", "read1", "-x", "50", "-D", "0.01", "-m", "14", "-g", "100", "-s", "0"]
+    pr = subprocess.run(argv, capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr
+    assert "SUCCESS" in pr.stderr  # what signalAlignment.py:480 keys on
+    assert "signalAlign - SUCCESS: finished alignment of query read1, exiting" in pr.stderr
+    params = oracle.default_params()
+    rows, n_anchors, n_pairs, score = _expected_full_rows(oracle, model, npread_path, "chrTest", "read1", ref_start,
+                                                          read_start, L, params)
+    got = open(out).readlines()
+    assert len(got) == len(rows)
+    bad = 0
+    for g, e in zip(got, rows):
+        if g != e:
+            gf, ef = g.rstrip("\n").split("\t"), e.rstrip("\n").split("\t")
+            # only the posterior column may differ, and by no more than 1e-5
+            assert gf[:12] == ef[:12] and gf[13:] == ef[13:], (g, e)
+            assert abs(float(gf[12]) - float(ef[12])) <= 1e-5
+            bad += 1
+    assert bad <= len(rows) // 100
+    # stdout summary line: "<label> <nAnchors>\t<nPairs>(<score %f>)\t\n"
+    head = pr.stdout.strip("\n").split("\t")
+    assert head[0] == "read1 %d" % n_anchors
+    assert head[1].startswith("%d(" % n_pairs)
+    assert abs(float(head[1][head[1].index("(") + 1:-1]) - score) < 1e-3
+    # appending, not truncating (fopen "a")
+    pr = subprocess.run(argv, capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0 and len(open(out).readlines()) == 2 * len(rows)
+
+
+def test_signalmachine_errors_like_the_reference(tmp_path):
+    pr = subprocess.run([BIN], capture_output=True, text=True)
+    assert pr.returncode != 0 and "Missing model files" in pr.stderr
+    pr = subprocess.run([BIN, "-T", cases.MODEL_5MER], capture_output=True, text=True)
+    assert pr.returncode != 0 and "Need to provide input guide alignments" in pr.stderr
+    pr = subprocess.run([BIN, "--help"], capture_output=True, text=True)
+    assert pr.returncode == 1 and "signalMachine - Align ONT ionic current" in pr.stderr
+
+
+def test_signalmachine_variant_caller_output(oracle, tmp_path):
+    # -s 1: only k-mers holding X are reported, one row per X position (impl/signalMachine.c:161-232)
+    npread_path = os.path.join(cases.GOLDEN, "npReads", "c2925_ecoli_ch34_read1023.npRead")
+    r = oracle.parse_npread(npread_path)
+    read = r["template_read"]
+    L = len(read) - 12
+    ref = list(read[:L])
+    for pos in (60, 61, 140, 200):
+        ref[pos] = "X"
+    ref = "".join(ref)
+    fasta = str(tmp_path / "ref.fa")
+    _write_fasta(fasta, "chrX", ref + "ACGTACGTAC")
+    cigar = str(tmp_path / "guide.cigar")
+    with open(cigar, "w") as f:
+        f.write("cigar: r 0 %d + chrX 0 %d + 1 M %d\n" % (L, L, L))
+    out = str(tmp_path / "vc.tsv")
+    pr = subprocess.run([BIN, "-T", cases.MODEL_5MER, "-q", npread_path, "-f", fasta, "-n", "chrX", "-p", cigar, "-u", out,
+                         "-L", "r", "-s", "1", "-g", "100"], capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr
+    rows = [l.rstrip("\n").split("\t") for l in open(out)]
+    assert rows, "no variant rows"
+    positions = {int(r[1]) for r in rows}
+    assert positions <= {60, 61, 140, 200} and {60, 140, 200} <= positions
+    assert all(r[2] in "ACGT" and r[4] == "t" and r[5] == "forward" and r[6] == "r" and r[8] == "chrX" for r in rows)
+    # per (event, position) the called bases' posteriors are probabilities
+    for r in rows:
+        assert 0.01 <= float(r[3]) <= 1.0
