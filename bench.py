@@ -77,10 +77,14 @@ def main():
     alpha, k, t10, tab = synth.parse_model_table(MODEL)
     pm = sa.Model.load(MODEL)
     params = sa.default_params(threshold=0.01, expansion=50, trace_back=100)
-    # every rank aligns its own reads: seeds are offset by rank
-    jobs = synth.make_jobs(args.reads, args.events, alpha, k, tab, first_index=rank * args.reads)
+    # reads are independent: the global read list is dealt to the ranks (no collective on the data path)
+    from signalalign_amd import shard
+    mine = shard.shard_indices([args.events] * (world * args.reads), rank, world)
+    jobs = [synth.make_read(int(i), args.events, alpha, k, tab) for i in mine]
     n_events_total = sum(len(j["events"]) for j in jobs)
-    batch = sa.Batch(pm, params, jobs, device=local_rank if world > 1 else 0)
+    t_create = time.perf_counter()
+    batch = sa.Batch(pm, params, jobs, device=local_rank if world > 1 else 0)  # planning + upload to HBM
+    t_create = time.perf_counter() - t_create
     st0 = batch.stats()
     cells = st0.cells_forward + st0.cells_backward
 
@@ -154,6 +158,8 @@ def main():
                 "pairs_rank0": n_pairs,
                 "regions_on_register_kernels": "%d/%d" % (st0.n_fast_regions, st0.n_regions),
                 "forward_storage_passes": int(st0.n_chunks),
+                "batch_create_s": t_create,
+                "value_if_planning_and_upload_charged_to_every_step": cells / (t_create + dt / K),
                 "kernel_ms": {"forward": ms_f, "backward_posterior": ms_b, "fold": ms_fold},
                 "kernel_cell_updates_per_s": {"forward": st0.cells_forward / (ms_f * 1e-3),
                                               "backward_posterior": st0.cells_backward / (ms_b * 1e-3)},

@@ -1,0 +1,34 @@
+"""Read sharding across the GPUs of one node.
+
+Reads are independent (the reference runs one process per read, src/signalalign/signalAlignment.py:694-737), so
+multi-GPU execution is a partition of the read list with no collective on the data path: each rank aligns its
+shard, results are concatenated in read order on the host.  This module only decides who aligns what.
+"""
+import numpy as np
+
+
+def shard_indices(costs, rank, world):
+    """Deal reads to ranks by descending cost, always to the currently least-loaded rank (longest-processing-time
+    first).  Deterministic; every read goes to exactly one rank.  costs: per-read work estimate (e.g. events)."""
+    costs = np.asarray(costs, dtype=np.float64)
+    order = np.argsort(-costs, kind="stable")
+    load = np.zeros(world, dtype=np.float64)
+    owner = np.empty(len(costs), dtype=np.int64)
+    for i in order:
+        r = int(np.argmin(load))
+        owner[i] = r
+        load[r] += costs[i]
+    return np.nonzero(owner == rank)[0]
+
+
+def merge_in_read_order(per_rank_indices, per_rank_results):
+    """Inverse of shard_indices: results[i] for read i, whatever rank produced it."""
+    n = sum(len(ix) for ix in per_rank_indices)
+    out = [None] * n
+    for ix, res in zip(per_rank_indices, per_rank_results):
+        assert len(ix) == len(res)
+        for i, r in zip(ix, res):
+            assert out[int(i)] is None, "read %d aligned twice" % int(i)
+            out[int(i)] = r
+    assert all(o is not None for o in out), "a read was not aligned by any rank"
+    return out

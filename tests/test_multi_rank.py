@@ -1,0 +1,38 @@
+"""N > 1 path on CPU: world_size 2, gloo.  Reads shard across ranks with no data-path collective; the only
+communication is gathering results (here: plan statistics, the GPU compute being unavailable on CPU)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+from signalalign_amd import shard
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_is_a_partition_and_balanced():
+    rng = np.random.default_rng(0)
+    costs = rng.integers(500, 20000, size=1000)
+    for world in (1, 2, 4, 8):
+        parts = [shard.shard_indices(costs, r, world) for r in range(world)]
+        allidx = np.sort(np.concatenate(parts))
+        assert np.array_equal(allidx, np.arange(1000))
+        loads = [costs[p].sum() for p in parts]
+        assert max(loads) <= 1.02 * min(loads)
+    res = shard.merge_in_read_order(parts, [[int(i) * 2 for i in p] for p in parts])
+    assert res == [2 * i for i in range(1000)]
+
+
+def test_two_rank_gloo_run():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_gloo_worker.py")]
+    pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert pr.returncode == 0, pr.stdout + pr.stderr
+    assert "GLOO_OK" in pr.stdout
