@@ -120,6 +120,8 @@ def lib():
     L.sa_remap_anchors.restype = C.c_int64
     L.sa_remap_anchors.argtypes = [ip, ip, C.c_int64, ip, C.c_int64, ip, ip]
     L.sa_estimate_params.argtypes = [C.c_void_p, dp, ip, dp, C.c_int64, C.c_char_p, C.c_int64, dp]
+    L.sa_expect_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Job), C.c_int64, C.POINTER(C.c_char_p),
+                                  C.c_int, C.c_uint, dp, dp, C.POINTER(C.c_void_p), ip]
     L.sa_free.argtypes = [C.c_void_p]
     _LIB = L
     return L
@@ -267,6 +269,29 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+def expect_batch(model, params, jobs, ambig=None, device=0, flags=0, pseudocount=0.0):
+    """sa_expect_batch: per job the 3x3 transition expectations (from*3+to), the summed log-likelihood and the HDP
+    assignments as (reference position, event index) arrays."""
+    n = len(jobs)
+    arr, keep = _make_jobs(jobs)
+    amb = ambig if ambig is not None else default_ambig()
+    trans = np.full((max(n, 1), 9), pseudocount, dtype=np.float64)
+    lik = np.zeros(max(n, 1), dtype=np.float64)
+    ptrs = (C.c_void_p * max(n, 1))()
+    cnt = np.zeros(max(n, 1), dtype=np.int64)
+    _chk(lib().sa_expect_batch(model._h, C.byref(params), arr, n, amb, device, flags, _dp(trans), _dp(lik), ptrs,
+                               _ip(cnt)), "sa_expect_batch")
+    assigns = []
+    for j in range(n):
+        a = np.zeros((int(cnt[j]), 2), dtype=np.int64)
+        if cnt[j]:
+            C.memmove(a.ctypes.data, ptrs[j], 16 * int(cnt[j]))
+        lib().sa_free(ptrs[j])
+        assigns.append(a)
+    del keep
+    return trans[:n], lik[:n], assigns
 
 
 def plan_describe(model, params, job, ambig=None, flags=0):

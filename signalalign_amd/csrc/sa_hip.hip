@@ -62,6 +62,8 @@ struct DevPlan {
     int *overflow;
     double *totals;
     double *bscratch;
+    double *gsum;     // EXPECT: 8 doubles per checkpoint group (7 live transitions)
+    double *gmc;      // EXPECT: the group's scaling maximum
     DevModel m;
     double log_thr;   // log(threshold)
     double threshold;
@@ -240,12 +242,25 @@ __global__ __launch_bounds__(64) void k_fwd_generic(DevPlan P, const int *region
     }
 }
 
+// EXPECT mode: close a checkpoint group -- lane 0 stores the wave sums of exp(term - Mc) and Mc itself; the host
+// rescales by exp(Mc - totalProbability) once the exact fold of the group's total is known.
+__device__ __forceinline__ void expect_flush(const DevPlan &P, long long ck, double Mc, double *acc, int lane) {
+    for (int k = 0; k < 7; k++) {
+        double v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) P.gsum[ck * 8 + k] = v;
+        acc[k] = 0.0;
+    }
+    if (lane == 0) { P.gsum[ck * 8 + 7] = 0.0; P.gmc[ck] = Mc; }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // generic backward + posterior numerators + checkpoint terms.
 // The reference scatters (doTransitionBackward, impl/pairwiseAligner.c:866-871); here each cell GATHERS
 // the same terms in the same order: first from (x+1,y+1) (it was that cell's "middle"), then from (x,y+1)
 // (its "upper"), then from (x+1,y) (its "lower").  Backward rows live in a 3-row ring in memory.
 // ---------------------------------------------------------------------------------------------------
+template <bool EXPECT>
 __global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_ids, int n) {
     int w = blockIdx.x;
     if (w >= n) return;
@@ -271,6 +286,7 @@ __global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_id
     }
     int count = 0;
     double Mc = NEG_INF;
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};  // EXPECT: sum of exp(term - Mc) per live transition, current checkpoint group
     for (long long e = start; e > to; e--) {
         sa_row_t re = rows[e];
         long long x0 = (e + re.xmyL) >> 1;
@@ -343,6 +359,7 @@ __global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_id
         if (e > from) continue;
         // ---- checkpoint: per-cell terms of diagonalCalculationTotalProbability (impl/pairwiseAligner.c:1335-1353)
         if ((from - e) % SA_CKPT_EVERY == 0) {
+            if (EXPECT && e != from) expect_flush(P, S->ck_base + (from - e) / SA_CKPT_EVERY - 1, Mc, acc, lane);
             const sa_ck_t ck = P.cks[S->ck_base + (from - e) / SA_CKPT_EVERY];
             double mx = NEG_INF;
             for (int i = lane; i < re.width; i += 64) {
@@ -374,6 +391,7 @@ __global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_id
             }
             Mc = wave_max(mx);
         }
+        if (!EXPECT) {
         // ---- posterior candidates of this diagonal (impl/pairwiseAligner.c:1355-1421); total >= Mc
         int nchunks = (re.width + 63) >> 6;
         for (int c = 0; c < nchunks; c++) {
@@ -411,7 +429,105 @@ __global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_id
                 }
             count += total;
         }
+        } else {
+        // ---- EXPECT: diagonalCalculation_Expectations (impl/pairwiseAligner.c:1423-1443): the cell calculation with
+        // current = backward diagonal e, lower/upper = forward diagonal e-1, middle = forward diagonal e-2, every
+        // transition adding exp(F[from] + B[to] + (eP + tP) - total) (cell_signal_updateExpectations :914-944).
+        // Forward diagonal e-2 has already been deleted for the first diagonal of a traceback (:1563-1578).
+        {
+            const sa_row_t rm1 = rows[e - 1];
+            const bool have2 = e - 2 >= to && e - 2 >= 0;
+            sa_row_t rm2 = {0, 0, 0, 0, 0};
+            if (have2) rm2 = rows[e - 2];
+            const long long x0m1 = (e - 1 + rm1.xmyL) >> 1, x0m2 = have2 ? (e - 2 + rm2.xmyL) >> 1 : 0;
+            const double lim = Mc + P.log_thr - SA_CAND_EPS;
+            const bool live = Mc > NEG_INF;
+            int nchunks = (re.width + 63) >> 6;
+            for (int c = 0; c < nchunks; c++) {
+                int i = c * 64 + lane;
+                bool in = live && i < re.width;
+                long long xmy = (long long) re.xmyL + 2 * (in ? i : 0);
+                long long x = x0 + (in ? i : 0), y = e - x;
+                int np = in ? poff[x + 1] - poff[x] : 0;
+                const int *idc = pid + poff[x];
+                const double *cb = Be + 3 * (poff[x] - poff[x0]);
+                long long il = xmy - 1 - rm1.xmyL, iu = xmy + 1 - rm1.xmyL, im = xmy - rm2.xmyL;
+                bool has_lo = in && il >= 0 && (il >> 1) < rm1.width && x >= 1;
+                bool has_up = in && iu >= 0 && (iu >> 1) < rm1.width && y >= 1;
+                bool has_mid = in && have2 && im >= 0 && (im >> 1) < rm2.width && x >= 1 && y >= 1;
+                int nl = (has_lo || has_mid) ? poff[x] - poff[x - 1] : 0;
+                const int *idl = pid + poff[x >= 1 ? x - 1 : 0];
+                const double *fl = has_lo ? F + 3 * (rm1.foff + poff[x - 1] - poff[x0m1]) : nullptr;
+                const double *fm = has_mid ? F + 3 * (rm2.foff + poff[x - 1] - poff[x0m2]) : nullptr;
+                const double *fu = has_up ? F + 3 * (rm1.foff + poff[x] - poff[x0m1]) : nullptr;
+                double e_cur = (y >= 1) ? ev[y - 1] : NEG_INF;  // NULLEVENT for y == 0 (impl/pairwiseAligner.c:509-512)
+                int mine = 0;
+                for (int p = 0; p < np; p++) {
+                    int idp = idc[p];
+                    if (has_lo) {
+                        double eP = (m.hdp || idp >= 0) ? SA_LOG_GAPX : NEG_INF;
+                        for (int q = 0; q < nl; q++)
+                            if (legal_step(m, idl[q], idp)) {
+                                acc[0] += exp(fl[3 * q + 0] + cb[3 * p + 1] + (eP + m.t_mx) - Mc);
+                                acc[1] += exp(fl[3 * q + 1] + cb[3 * p + 1] + (eP + m.t_xx) - Mc);
+                            }
+                    }
+                    if (has_mid) {
+                        double eP = emit_ref(m, rp, idp, e_cur, 1);
+                        for (int q = 0; q < nl; q++)
+                            if (legal_step(m, idl[q], idp)) {
+                                double v2 = fm[3 * q + 0] + cb[3 * p + 0] + (eP + m.t_mm);
+                                double v3 = fm[3 * q + 1] + cb[3 * p + 0] + (eP + m.t_xm);
+                                double v4 = fm[3 * q + 2] + cb[3 * p + 0] + (eP + m.t_ym);
+                                acc[2] += exp(v2 - Mc);
+                                acc[3] += exp(v3 - Mc);
+                                acc[4] += exp(v4 - Mc);
+                                if (m.hdp) mine += (v2 >= lim ? 1 : 0) + (v3 >= lim ? 1 : 0) + (v4 >= lim ? 1 : 0);
+                            }
+                    }
+                    if (has_up) {
+                        double eP = emit_ref(m, rp, idp, e_cur, 0);
+                        acc[5] += exp(fu[3 * p + 0] + cb[3 * p + 2] + (eP + m.t_my) - Mc);
+                        acc[6] += exp(fu[3 * p + 2] + cb[3 * p + 2] + (eP + m.t_yy) - Mc);
+                    }
+                }
+                if (!m.hdp) continue;
+                // assignment candidates (cell_signal_updateExpectationsAndAssignments :946-968), reference order
+                int incl = mine;
+                for (int off = 1; off < 64; off <<= 1) {
+                    int o = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += o;
+                }
+                int total = __shfl(incl, 63, 64);
+                int pos = count + incl - mine;
+                if (mine > 0)
+                    for (int p = 0; p < np; p++) {
+                        int idp = idc[p];
+                        double eP = emit_ref(m, rp, idp, e_cur, 1);
+                        for (int q = 0; q < nl; q++)
+                            if (legal_step(m, idl[q], idp)) {
+                                double v[3] = {fm[3 * q + 0] + cb[3 * p + 0] + (eP + m.t_mm),
+                                               fm[3 * q + 1] + cb[3 * p + 0] + (eP + m.t_xm),
+                                               fm[3 * q + 2] + cb[3 * p + 0] + (eP + m.t_ym)};
+                                for (int t = 0; t < 3; t++)
+                                    if (v[t] >= lim) {
+                                        if (pos < S->cand_cap) {
+                                            sa_cand_t cd;
+                                            cd.x = (int) (x - 1); cd.y = (int) (y - 1); cd.path = p; cd.pad = t; cd.fb = v[t];
+                                            P.cands[S->cand_off + pos] = cd;
+                                        } else {
+                                            P.overflow[0] = 1;
+                                        }
+                                        pos++;
+                                    }
+                            }
+                    }
+                count += total;
+            }
+        }
+        }
     }
+    if (EXPECT && S->n_ck > 0) expect_flush(P, S->ck_base + S->n_ck - 1, Mc, acc, lane);
     if (lane == 0) P.cand_count[seg] = count < S->cand_cap ? count : S->cand_cap;
 }
 
@@ -599,6 +715,8 @@ struct sa_batch {
     sa_seg_t *d_segs; sa_ck_t *d_cks;
     double *d_F; double *d_vbuf; sa_cand_t *d_cands; int *d_cand_count; int *d_overflow; double *d_totals;
     double *d_bscratch;
+    double *d_gsum, *d_gmc;  // expectation mode only
+    bool expect;
     double *d_tab6; int *d_hdp_slot; double *d_hdp_y, *d_hdp_slope, *d_hdp_grid;
     long long *d_prob; int *d_seg_pass; long long *d_seg_off; sa_pair_t *d_out;
     int *d_ids;  // region / segment id lists per launch
@@ -631,6 +749,7 @@ static DevPlan make_devplan(const sa_batch *b) {
     P.regions = b->d_regions; P.rows = b->d_rows; P.pk = b->d_pk; P.poff = b->d_poff; P.pid = b->d_pid; P.xc = b->d_xc; P.ev = b->d_ev;
     P.segs = b->d_segs; P.cks = b->d_cks; P.F = b->d_F; P.vbuf = b->d_vbuf; P.cands = b->d_cands;
     P.cand_count = b->d_cand_count; P.overflow = b->d_overflow; P.totals = b->d_totals; P.bscratch = b->d_bscratch;
+    P.gsum = b->d_gsum; P.gmc = b->d_gmc;
     P.m.t_mm = m->t_mm; P.m.t_mx = m->t_mx; P.m.t_my = m->t_my; P.m.t_xm = m->t_xm; P.m.t_xx = m->t_xx;
     P.m.t_ym = m->t_ym; P.m.t_yy = m->t_yy;
     P.m.tab6 = b->d_tab6; P.m.pow_km1 = m->pow_km1; P.m.n_alpha = m->n_alpha; P.m.hdp = m->hdp ? 1 : 0;
@@ -655,7 +774,7 @@ void sa_batch_destroy(sa_batch_t *b) {
     void *ptrs[] = {b->d_regions, b->d_rows, b->d_pk, b->d_poff, b->d_pid, b->d_xc, b->d_ev, b->d_segs, b->d_cks, b->d_F,
                     b->d_vbuf, b->d_cands, b->d_cand_count, b->d_overflow, b->d_totals, b->d_bscratch, b->d_tab6,
                     b->d_hdp_slot, b->d_hdp_y, b->d_hdp_slope, b->d_hdp_grid, b->d_prob, b->d_seg_pass, b->d_seg_off,
-                    b->d_out, b->d_ids};
+                    b->d_out, b->d_ids, b->d_gsum, b->d_gmc};
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
     for (int i = 0; i < 8; i++)
@@ -697,7 +816,8 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     b->d_cands = nullptr; b->d_cand_count = nullptr; b->d_overflow = nullptr; b->d_totals = nullptr;
     b->d_bscratch = nullptr; b->d_tab6 = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr;
     b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr;
-    b->d_seg_off = nullptr; b->d_out = nullptr; b->d_ids = nullptr;
+    b->d_seg_off = nullptr; b->d_out = nullptr; b->d_ids = nullptr; b->d_gsum = nullptr; b->d_gmc = nullptr;
+    b->expect = (flags & SA_FLAG_EXPECT_INTERNAL) != 0;
     b->cand_alloc = 0; b->out_alloc = 0;
     b->h_pairs = nullptr; b->h_pairs_cap = 0; b->n_pairs_total = 0;
     memset(&b->stats, 0, sizeof(b->stats));
@@ -761,6 +881,10 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     TRY(dalloc((void **) &b->d_overflow, 4));
     TRY(dalloc((void **) &b->d_totals, 8 * pl->n_cks));
     TRY(dalloc((void **) &b->d_bscratch, 8 * pl->n_bscratch));
+    if (b->expect) {
+        TRY(dalloc((void **) &b->d_gsum, 64 * pl->n_cks));
+        TRY(dalloc((void **) &b->d_gmc, 8 * pl->n_cks));
+    }
     // launch lists per chunk
     b->gen_regions.resize(pl->n_chunks); b->fast_regions.resize(pl->n_chunks);
     b->gen_segs.resize(pl->n_chunks); b->fast_segs.resize(pl->n_chunks);
@@ -824,7 +948,8 @@ static int run_once(sa_batch *b, bool *overflowed) {
         if (ngr) hipLaunchKernelGGL(k_fwd_generic, dim3(ngr), dim3(64), 0, st, P, ids_gr, ngr);
         if (nfr) launch_fwd_fast(P, ids_fr, nfr, st);
         HIPCHK(hipEventRecord(b->ev[2], st));
-        if (ngs) hipLaunchKernelGGL(k_bwd_generic, dim3(ngs), dim3(64), 0, st, P, ids_gs, ngs);
+        if (ngs && !b->expect) hipLaunchKernelGGL(k_bwd_generic<false>, dim3(ngs), dim3(64), 0, st, P, ids_gs, ngs);
+        if (ngs && b->expect) hipLaunchKernelGGL(k_bwd_generic<true>, dim3(ngs), dim3(64), 0, st, P, ids_gs, ngs);
         if (nfs) launch_bwd_fast(P, ids_fs, nfs, st);
         HIPCHK(hipEventRecord(b->ev[3], st));
         HIPCHK(hipEventSynchronize(b->ev[3]));
@@ -852,9 +977,7 @@ static int run_once(sa_batch *b, bool *overflowed) {
     return SA_OK;
 }
 
-int sa_batch_run(sa_batch_t *b) {
-    if (!b) return SA_EINVAL;
-    HIPCHK(hipSetDevice(b->device));
+static int run_passes(sa_batch_t *b) {
     sa_plan_t *pl = b->plan;
     bool ov = false;
     for (int attempt = 0; attempt < 6; attempt++) {
@@ -872,7 +995,16 @@ int sa_batch_run(sa_batch_t *b) {
         b->cand_alloc = pl->n_cand;
         HIPCHK(hipMemcpy(b->d_segs, pl->segs, sizeof(sa_seg_t) * (size_t) pl->n_segs, hipMemcpyHostToDevice));
     }
-    if (ov) return SA_ENOMEM;
+    return ov ? SA_ENOMEM : SA_OK;
+}
+
+int sa_batch_run(sa_batch_t *b) {
+    if (!b) return SA_EINVAL;
+    if (b->expect) return SA_ESTATE;
+    HIPCHK(hipSetDevice(b->device));
+    sa_plan_t *pl = b->plan;
+    int rcp0 = run_passes(b);
+    if (rcp0) return rcp0;
     long long n_segs = pl->n_segs;
     b->n_pairs_total = 0;
     b->job_off.assign((size_t) pl->n_jobs + 1, 0);
@@ -997,7 +1129,73 @@ int sa_align_batch(const sa_model_t *m, const sa_params_t *p, const sa_job_t *jo
     return rc;
 }
 
-int sa_expect_batch(const sa_model_t *, const sa_params_t *, const sa_job_t *, int64_t, const char *const *, int,
-                    unsigned, double *, double *, sa_assignment_t **, int64_t *) {
-    return SA_EUNSUPPORTED;  // EM mode: next row of the scope table
+// getExpectationsUsingAnchors for a batch of reads.  The pass runs on the memory-resident kernels (every region is
+// planned SA_KIND_GENERIC); the per-group sums are rescaled here with the exact totals of the fold kernel.
+int sa_expect_batch(const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs, int64_t n_jobs,
+                    const char *const *ambig, int device, unsigned flags, double *trans9_out, double *likelihood_out,
+                    sa_assignment_t **assign_out, int64_t *n_assign_out) {
+    if (!trans9_out || !likelihood_out) return SA_EINVAL;
+    sa_batch_t *b = nullptr;
+    int rc = sa_batch_create(&b, m, p, jobs, n_jobs, ambig, device,
+                             flags | SA_FLAG_FORCE_GENERIC | SA_FLAG_EXPECT_INTERNAL);
+    if (rc) return rc;
+    rc = run_passes(b);
+    if (rc) { sa_batch_destroy(b); return rc; }
+    const sa_plan_t *pl = b->plan;
+    std::vector<sa_cand_t> cands((size_t) (pl->n_cand > 0 ? pl->n_cand : 1));
+    std::vector<int> counts((size_t) (pl->n_segs > 0 ? pl->n_segs : 1));
+    std::vector<double> totals((size_t) (pl->n_cks > 0 ? pl->n_cks : 1)), gmc(totals.size()), gsum(8 * totals.size());
+    auto dl = [&](void *dst, const void *src, size_t bytes) -> int {
+        if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+        return SA_OK;
+    };
+    rc = dl(cands.data(), b->d_cands, sizeof(sa_cand_t) * (size_t) pl->n_cand);
+    if (!rc) rc = dl(counts.data(), b->d_cand_count, 4 * (size_t) pl->n_segs);
+    if (!rc) rc = dl(totals.data(), b->d_totals, 8 * (size_t) pl->n_cks);
+    if (!rc) rc = dl(gmc.data(), b->d_gmc, 8 * (size_t) pl->n_cks);
+    if (!rc) rc = dl(gsum.data(), b->d_gsum, 64 * (size_t) pl->n_cks);
+    if (rc) { sa_batch_destroy(b); return rc; }
+    // (from, to) slots of hmm->transitions[from * 3 + to] in the order the kernel accumulates them
+    static const int slot[7] = {0 * 3 + 1, 1 * 3 + 1, 0 * 3 + 0, 1 * 3 + 0, 2 * 3 + 0, 0 * 3 + 2, 2 * 3 + 2};
+    const double thr = pl->params.threshold;
+    for (int64_t j = 0; j < n_jobs; j++) {
+        const sa_jobinfo_t *J = &pl->jobs[j];
+        std::vector<sa_assignment_t> as;
+        for (long long r = J->region_off; r < J->region_off + J->n_regions; r++) {
+            const sa_region_t *R = &pl->regions[r];
+            for (long long sg = R->seg_off; sg < R->seg_off + R->n_seg; sg++) {
+                const sa_seg_t *S = &pl->segs[sg];
+                long long nrows = S->from - S->to;
+                for (int c = 0; c < S->n_ck; c++) {
+                    double total = totals[S->ck_base + c];
+                    long long rows_here = nrows - (long long) c * SA_CKPT_EVERY;
+                    if (rows_here > SA_CKPT_EVERY) rows_here = SA_CKPT_EVERY;
+                    for (long long k = 0; k < rows_here; k++) likelihood_out[j] += total;  // one add per diagonal (:1432)
+                    if (!(total > -INFINITY)) continue;
+                    double sc = exp(gmc[S->ck_base + c] - total);
+                    for (int k = 0; k < 7; k++) trans9_out[j * 9 + slot[k]] += gsum[8 * (S->ck_base + c) + k] * sc;
+                }
+                if (!assign_out) continue;
+                for (int i = 0; i < counts[sg]; i++) {
+                    const sa_cand_t &cd = cands[S->cand_off + i];
+                    long long e = (long long) cd.x + cd.y + 2;
+                    double total = totals[S->ck_base + (S->from - e) / SA_CKPT_EVERY];
+                    if (exp(cd.fb - total) >= thr) {
+                        sa_assignment_t a;
+                        a.ref_pos = cd.x + R->x1;
+                        a.event = cd.y + R->y1;
+                        as.push_back(a);
+                    }
+                }
+            }
+        }
+        if (assign_out) {
+            assign_out[j] = (sa_assignment_t *) malloc(sizeof(sa_assignment_t) * (as.size() ? as.size() : 1));
+            if (!assign_out[j]) { sa_batch_destroy(b); return SA_ENOMEM; }
+            if (!as.empty()) memcpy(assign_out[j], as.data(), sizeof(sa_assignment_t) * as.size());
+            if (n_assign_out) n_assign_out[j] = (int64_t) as.size();
+        }
+    }
+    sa_batch_destroy(b);
+    return SA_OK;
 }

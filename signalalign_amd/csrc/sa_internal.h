@@ -16,6 +16,7 @@ extern "C" {
 #define SA_CKPT_EVERY 10              /* totalProbability refresh period, impl/pairwiseAligner.c:1538 */
 #define SA_LOG_GAPX (-2.3025850929940455) /* log(0.1): impl/stateMachine.c:1584-1586, :1394 */
 #define SA_GAPY_SD_MULT 1.75          /* EXTRA_EVENT_NOISE_MULTIPLIER, inc/stateMachine.h:34 */
+#define SA_FLAG_EXPECT_INTERNAL 0x10000u /* sa_expect_batch: expectation pass instead of posteriors */
 #define SA_CAND_EPS 1e-6              /* slack of the on-device candidate filter (see sa_hip.hip) */
 
 /* ---- model (host) ---------------------------------------------------------------------------- */
