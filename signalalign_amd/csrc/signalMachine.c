@@ -5,7 +5,7 @@
  * stdout and the "SUCCESS" line on stderr that signalAlignment.py keys on (src/signalalign/signalAlignment.py:480).
  * The banded pair-HMM itself runs on the MI355X through libsignalalign_hip.so; there is no CPU fallback.
  *
- * Not supported (exits non-zero with a message): expectations mode (-t/-c) -- see DESIGN.md.
+ * Expectations mode (-t/-c) runs sa_expect_batch and writes the .expectations files of impl/continuousHmm.c.
  */
 #define _GNU_SOURCE
 #include <getopt.h>
@@ -186,6 +186,44 @@ static void output_alignment(int64_t fmt, const char *f1, const char *f2, const 
     }
 }
 
+/* continuousPairHmm_writeToFile (impl/continuousHmm.c:352-408) / hdpHmm_writeToFile (:572-623) */
+static void write_expectations(const char *path, const strand_model_t *sm, int hdp, const double *trans, double lik,
+                               const sa_job_t *job, const sa_assignment_t *as, int64_t n_as) {
+    for (int i = 0; i < 9; i++)
+        if (isnan(trans[i])) { /* hmmContinuous_checkTransitions: an empty file is left behind */
+            fprintf(stderr, "GOT NaN TRANS\n");
+            FILE *f0 = fopen(path, "w");
+            if (f0) fclose(f0);
+            return;
+        }
+    FILE *fh = fopen(path, "w");
+    if (!fh) die("signalMachine: cannot open %s for writing", path);
+    int64_t n_kmers = 1;
+    for (int i = 0; i < sm->k; i++) n_kmers *= sm->n_alpha;
+    fprintf(fh, "%d\t%d\t%s\t%d\t\n", 3, sm->n_alpha, sm->alphabet, sm->k);
+    for (int i = 0; i < 9; i++) fprintf(fh, "%f\t", trans[i]);
+    fprintf(fh, "%f\n", lik);
+    for (int64_t i = 0; i < n_kmers * 5; i++) fprintf(fh, "%lf\t", sm->table[i]);
+    fprintf(fh, "\n");
+    if (!hdp) {
+        for (int64_t i = 0; i < n_kmers * 2; i++) fprintf(fh, "%lf\t", 0.0);   /* eventExpectations: never updated */
+        fprintf(fh, "\n");
+        for (int64_t i = 0; i < n_kmers; i++) fprintf(fh, "%lf\t", 0.001);     /* posteriors = emissionsPseudocount */
+        fprintf(fh, "\n");
+        for (int64_t i = 0; i < n_kmers; i++) fprintf(fh, "%d\t", 0);          /* observed mask */
+        fprintf(fh, "\n");
+    } else {
+        for (int64_t i = 0; i < n_as; i++) fprintf(fh, "%lf\t", job->events[as[i].event * job->event_stride]);
+        fprintf(fh, "\n");
+        for (int64_t i = 0; i < n_as; i++) {
+            for (int n = 0; n < sm->k; n++) fputc(job->ref[as[i].ref_pos + n], fh);
+            fputc('\t', fh);
+        }
+        fprintf(fh, "\n");
+    }
+    fclose(fh);
+}
+
 static int load_strand_model(strand_model_t *sm, const char *model_path, const char *nhdp_path) {
     int rc = sa_model_load(&sm->model, model_path, nhdp_path);
     if (rc) return rc;
@@ -269,8 +307,7 @@ int main(int argc, char **argv) {
     if (sa_cigar_load(cigar_path, &pA) != SA_OK)
         die("[signalMachine]ERROR: Didn't find input alignment file, looked %s", cigar_path);
     fprintf(stderr, "[signalMachine]NOTICE: Using guide alignments from %s\n", cigar_path);
-    if (t_expect != NULL || c_expect != NULL)
-        die("[signalMachine]ERROR: expectations mode (-t/-c) is not available in the MI355X build yet", NULL);
+    const int expect_mode = t_expect != NULL || c_expect != NULL;
 
     sa_params_t p;
     p.threshold = threshold;
@@ -377,7 +414,8 @@ int main(int argc, char **argv) {
     }
 
     /* ---- per-strand work: estimate parameters, build the job ---- */
-    fprintf(stderr, "signalAlign - starting template alignment\n");
+    if (expect_mode) fprintf(stderr, "Starting expectations routine\n");
+    else fprintf(stderr, "signalAlign - starting template alignment\n");
     double est[7];
     if (sa_estimate_params(smt.model, smt.table, np->template_strand_event_map, np->template_events,
                            np->n_template_events, np->template_read, np->template_read_length, est) != SA_OK)
@@ -385,7 +423,7 @@ int main(int argc, char **argv) {
     np->template_params.scale = est[0]; np->template_params.shift = est[1]; np->template_params.var = est[2];
     np->template_params.drift = est[3]; np->template_params.scale_sd = est[4]; np->template_params.var_sd = est[5];
     np->template_params.shift_sd = est[6];
-    if (hdp) {
+    if (hdp && !expect_mode) {
         sa_model_set_to_hdp_expected_values(smt.model);
         int64_t n = 5;
         for (int i = 0; i < smt.k; i++) n *= smt.n_alpha;
@@ -414,7 +452,7 @@ int main(int argc, char **argv) {
         np->complement_params.scale = est[0]; np->complement_params.shift = est[1]; np->complement_params.var = est[2];
         np->complement_params.drift = est[3]; np->complement_params.scale_sd = est[4]; np->complement_params.var_sd = est[5];
         np->complement_params.shift_sd = est[6];
-        if (hdp) {
+        if (hdp && !expect_mode) {
             sa_model_set_to_hdp_expected_values(smc.model);
             int64_t n = 5;
             for (int i = 0; i < smc.k; i++) n *= smc.n_alpha;
@@ -432,6 +470,32 @@ int main(int argc, char **argv) {
         jobs[1].anchor_x = ax[1]; jobs[1].anchor_y = ay[1]; jobs[1].n_anchors = na1;
         jobs[1].scale = np->complement_params.scale; jobs[1].shift = np->complement_params.shift; jobs[1].var = np->complement_params.var;
         n_jobs = 2;
+    }
+
+    if (expect_mode) { /* impl/signalMachine.c:772-848 */
+        const char *paths[2] = {t_expect, c_expect};
+        for (int s = 0; s < n_jobs; s++) {
+            fprintf(stderr, "signalAlign - getting expectations for %s\n", s == 0 ? "template" : "complement");
+            double trans[9], lik = 0.0;
+            for (int i = 0; i < 9; i++) trans[i] = 0.001; /* transitionsPseudocount, :785 */
+            sa_assignment_t *as = NULL;
+            int64_t n_as = 0;
+            int rc = sa_expect_batch(sms[s]->model, &p, &jobs[s], 1, ambig, 0, 0, trans, &lik, &as, &n_as);
+            if (rc != SA_OK) {
+                fprintf(stderr, "signalMachine: expectations failed: %s\n", sa_strerror(rc));
+                return 1;
+            }
+            if (hdp)
+                fprintf(stderr, s == 0 ? "signalAlign - got %" PRId64 " template HDP assignments\n"
+                                       : "signalAlign - got %" PRId64 "complement HDP assignments\n", n_as);
+            if (paths[s] != NULL) {
+                fprintf(stderr, "signalAlign - writing expectations to file: %s\n", paths[s]);
+                write_expectations(paths[s], sms[s], hdp, trans, lik, &jobs[s], as, n_as);
+            }
+            sa_free(as);
+        }
+        fprintf(stderr, "signalAlign - SUCCESS: finished alignment of query %s, exiting\n", label);
+        return 0;
     }
 
     /* ---- the pair-HMM on the GPU: one batch per strand model ---- */

@@ -144,3 +144,47 @@ def test_signalmachine_variant_caller_output(oracle, tmp_path):
     # per (event, position) the called bases' posteriors are probabilities
     for r in rows:
         assert 0.01 <= float(r[3]) <= 1.0
+
+
+def test_signalmachine_expectations_file(oracle, tmp_path):
+    # -t: the .expectations file of continuousPairHmm_writeToFile (impl/continuousHmm.c:352-408)
+    model = cases.MODEL_6MER
+    npread_path = os.path.join(cases.GOLDEN, "npReads", "r9p4_oneD.npRead")
+    r = oracle.parse_npread(npread_path)
+    read = r["template_read"]
+    read_start, L = 5, len(read) - 20
+    fasta = str(tmp_path / "ref.fa")
+    _write_fasta(fasta, "chrE", "ACGT" * 10 + read[read_start:] + "TTTT")
+    cigar = str(tmp_path / "guide.cigar")
+    with open(cigar, "w") as f:
+        f.write("cigar: r %d %d + chrE 40 %d + 1 M %d\n" % (read_start, read_start + L, 40 + L, L))
+    out = str(tmp_path / "t.expectations")
+    pr = subprocess.run([BIN, "-T", model, "-q", npread_path, "-f", fasta, "-n", "chrE", "-p", cigar, "-t", out,
+                         "-L", "r", "-g", "100"], capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr
+    assert "signalAlign - writing expectations to file: %s" % out in pr.stderr and "SUCCESS" in pr.stderr
+    lines = open(out).read().split("\n")
+    om = oracle.Model.from_file(model)
+    assert lines[0] == "3\t%d\t%s\t%d\t" % (len(om.alphabet), om.alphabet, om.k)
+    # the oracle on the same inputs
+    ev = r["template_events"].copy()
+    pr_ = oracle.estimate_params(om, r["template_strand_event_map"], ev, read)
+    target = read[read_start:read_start + L]
+    gx, gy = oracle.guide_to_anchors(40, 40 + L, 1, read_start, [(0, L)], 14)
+    em = r["template_strand_event_map"]
+    ax, ay = oracle.remap_anchors(gx, gy, em, read_start)
+    lo, hi = int(em[read_start]), int(em[read_start + L - 1])
+    om.set_read_params(pr_["scale"], pr_["shift"], pr_["var"])
+    t, lik, _, _, _ = oracle.expectations(om, target, ev[lo:hi], ax, ay, oracle.default_params())
+    f1 = lines[1].split("\t")
+    assert len(f1) == 10
+    exp = ["%f" % (v + 0.001) for v in t] + ["%f" % lik]
+    for g, e in zip(f1, exp):
+        assert abs(float(g) - float(e)) <= 2e-6 * max(1.0, abs(float(e))), (f1, exp)
+    n_kmers = len(om.alphabet) ** om.k
+    tab = om.match_table()
+    f2 = lines[2].split("\t")
+    assert len(f2) == 5 * n_kmers + 1 and f2[-1] == "" and f2[:5] == ["%f" % v for v in tab[:5]]
+    assert lines[3] == "0.000000\t" * (2 * n_kmers)
+    assert lines[4] == "0.001000\t" * n_kmers
+    assert lines[5] == "0\t" * n_kmers
