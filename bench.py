@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--reads", type=int, default=2000, help="reads per GPU (BASELINE configs[1]: 2000)")
     ap.add_argument("--events", type=int, default=5000, help="events per read (BASELINE configs[1]: 5000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-reads-per-thread", type=int, default=10)
+    ap.add_argument("--cpu-reads-per-thread", type=int, default=30)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -123,7 +123,10 @@ def main():
     if rank == 0:
         K = args.steps
         ms_f, ms_b, ms_fold = ms_f / K, ms_b / K, ms_fold / K
-        # dominant kernel of rank 0, timed with HIP events on the library's own stream
+        # dominant kernel of rank 0, timed with HIP events on the library's own streams.  k_bwd_fast runs as
+        # n_groups launches per step that overlap pairwise on two streams: its duration here is
+        # the wall time of the whole traceback stage (end of forward -> end of the last k_bwd_fast), which also
+        # contains the fold/finalisation kernels of the earlier groups, and the bytes are those of all launches.
         if ms_b >= ms_f:
             dom, dom_ms, dom_cells = "k_bwd_fast", ms_b, st0.cells_backward
         else:
@@ -158,16 +161,18 @@ def main():
                 "pairs_rank0": n_pairs,
                 "regions_on_register_kernels": "%d/%d" % (st0.n_fast_regions, st0.n_regions),
                 "forward_storage_passes": int(st0.n_chunks),
+                "result_groups": int(st0.n_groups),
                 "batch_create_s": t_create,
                 "value_if_planning_and_upload_charged_to_every_step": cells / (t_create + dt / K),
-                "kernel_ms": {"forward": ms_f, "backward_posterior": ms_b, "fold": ms_fold},
+                "kernel_ms": {"forward": ms_f, "backward_posterior": ms_b, "fold_and_finalize": ms_fold},
                 "kernel_cell_updates_per_s": {"forward": st0.cells_forward / (ms_f * 1e-3),
                                               "backward_posterior": st0.cells_backward / (ms_b * 1e-3)},
             },
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL * dom_cells,
-                         "launch_ms": dom_ms},
+                         "algorithmic_bytes_per_step": ALGO_BYTES_PER_CELL * dom_cells,
+                         "stage_ms": dom_ms,
+                         "launches_per_step": int(st0.n_groups) if dom == "k_bwd_fast" else int(st0.n_chunks)},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(alpha, k, t10, tab, args.events, args.cpu_reads_per_thread,

@@ -88,13 +88,16 @@ typedef struct sa_batch_stats {
     double cells_forward;    /* sum over forward diagonals of width*paths           */
     double cells_backward;   /* ditto for backward diagonals actually computed      */
     double ms_forward;       /* HIP-event time of the forward kernels, last run     */
-    double ms_backward;      /* backward+posterior kernels                          */
-    double ms_fold;          /* total-probability fold kernel                       */
+    double ms_backward;      /* traceback stage: end of the forward sweep -> end of the last backward+posterior
+                                kernel (the groups' launches overlap on two streams; fold/finalisation kernels of
+                                earlier groups run inside this window)                                        */
+    double ms_fold;          /* rest of the pass: fold (+ on-device finalisation) of the last group          */
     double ms_total_device;  /* first launch -> last kernel end                     */
     double f_bytes;          /* bytes of forward storage written (== read back)     */
     int64_t n_regions, n_segments, n_checkpoints;
     int64_t n_fast_regions;  /* regions handled by the register-resident kernels    */
     int64_t n_chunks;        /* passes needed to fit forward storage in HBM         */
+    int64_t n_groups;        /* backward/posterior launches per pass (result copy of one overlaps the next) */
 } sa_batch_stats_t;
 
 /* ---- model -------------------------------------------------------------------------------------

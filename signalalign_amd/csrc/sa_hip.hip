@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <time.h>
 #include <vector>
 
 #include "sa_internal.h"
@@ -551,7 +552,7 @@ __device__ __forceinline__ double la_exact_bf(const double *tab, double x, doubl
 // vbuf; they are brought in with coalesced loads (one checkpoint per load instruction) and transposed through LDS so
 // that every lane then walks its own checkpoint sequentially.
 #define FOLD_LD 65
-__global__ __launch_bounds__(64) void k_fold(DevPlan P, long long n_ck) {
+__global__ __launch_bounds__(64) void k_fold(DevPlan P, long long ck0, long long ck1) {
     __shared__ double tile[64 * FOLD_LD];
     __shared__ __attribute__((aligned(32))) double LT[16];
     const int lane = threadIdx.x;
@@ -563,9 +564,9 @@ __global__ __launch_bounds__(64) void k_fold(DevPlan P, long long n_ck) {
         LT[4 * lane + 0] = (double) a3[lane]; LT[4 * lane + 1] = (double) a2[lane];
         LT[4 * lane + 2] = (double) a1[lane]; LT[4 * lane + 3] = (double) a0[lane];
     }
-    const long long ckid = (long long) blockIdx.x * 64 + lane;
+    const long long ckid = ck0 + (long long) blockIdx.x * 64 + lane;
     sa_ck_t ck = {0, 0, 0};
-    if (ckid < n_ck) ck = P.cks[ckid];
+    if (ckid < ck1) ck = P.cks[ckid];
     const int len = ck.nA + ck.nB;
     const int maxlen = wave_max_i(len);
     const int vo_lo = (int) (ck.voff & 0xffffffffll), vo_hi = (int) (ck.voff >> 32);
@@ -598,15 +599,15 @@ __global__ __launch_bounds__(64) void k_fold(DevPlan P, long long n_ck) {
         }
         __syncthreads();
     }
-    if (ckid < n_ck) P.totals[ckid] = (ck.nB > 0) ? la_exact_bf(LT, tA, tB) : tA;
+    if (ckid < ck1) P.totals[ckid] = (ck.nB > 0) ? la_exact_bf(LT, tA, tB) : tA;
 }
 
 // ---------------------------------------------------------------------------------------------------
 // finalize: posterior, threshold, floor; count survivors per segment
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_finalize(DevPlan P, int n_segs, long long *prob_e7, int *seg_pass) {
-    int seg = blockIdx.x;
-    if (seg >= n_segs) return;
+__global__ __launch_bounds__(64) void k_finalize(DevPlan P, int seg0, int n_segs, long long *prob_e7, int *seg_pass) {
+    if ((int) blockIdx.x >= n_segs) return;
+    int seg = seg0 + blockIdx.x;
     const sa_seg_t *S = &P.segs[seg];
     int n = P.cand_count[seg];
     int lane = threadIdx.x;
@@ -632,7 +633,9 @@ __global__ __launch_bounds__(64) void k_finalize(DevPlan P, int n_segs, long lon
 }
 
 // exclusive scan of seg_pass (single block)
-__global__ __launch_bounds__(1024) void k_scan(const int *in, long long *out, int n) {
+// out_host (pinned host memory, written straight from the kernel) spares a copy-engine transfer: a queued copy that
+// waits for a kernel blocks every later copy on the engine, including the pair copies of groups already finished
+__global__ __launch_bounds__(1024) void k_scan(const int *in, long long *out, long long *out_host, int n) {
     __shared__ long long part[1024];
     int t = threadIdx.x;
     int per = (n + 1023) / 1024;
@@ -650,24 +653,27 @@ __global__ __launch_bounds__(1024) void k_scan(const int *in, long long *out, in
     long long base = t ? part[t - 1] : 0;
     for (int i = lo; i < hi; i++) {
         out[i] = base;
+        out_host[i] = base;
         base += in[i];
     }
-    if (t == 1023) out[n] = part[1023];
+    if (t == 1023) { out[n] = part[1023]; out_host[n] = part[1023]; }
 }
 
 // gather survivors of a segment in REVERSE candidate order (=> ascending diagonals, x descending, path descending:
 // the order of stList_pop + stable sort by x+y, impl/pairwiseAligner.c:2043-2050, impl/signalMachine.c:872)
-__global__ __launch_bounds__(64) void k_gather(DevPlan P, int n_segs, const long long *prob_e7, const long long *seg_off,
-                                               sa_pair_t *out) {
-    int seg = blockIdx.x;
-    if (seg >= n_segs) return;
+// seg_off: exclusive scan over the n_segs segments starting at seg0 (indexed from 0); out: first slot of that range
+__global__ __launch_bounds__(64) void k_gather(DevPlan P, int seg0, int n_segs, const long long *prob_e7,
+                                               const long long *seg_off, sa_pair_t *out) {
+    if ((int) blockIdx.x >= n_segs) return;
+    const int lseg = blockIdx.x;
+    int seg = seg0 + lseg;
     const sa_seg_t *S = &P.segs[seg];
     const sa_region_t *R = &P.regions[S->region];
     const int *poff = P.poff + R->poff_off;
     const int *pid = P.pid + R->pid_off;
     int n = P.cand_count[seg];
     int lane = threadIdx.x;
-    long long total = seg_off[seg + 1] - seg_off[seg];
+    long long total = seg_off[lseg + 1] - seg_off[lseg];
     long long done = 0;
     for (int base = 0; base < n; base += 64) {
         int i = base + lane;
@@ -677,7 +683,7 @@ __global__ __launch_bounds__(64) void k_gather(DevPlan P, int n_segs, const long
         if (pass) {
             sa_cand_t c = P.cands[S->cand_off + i];
             long long k = done + rank;              // index in candidate order
-            long long pos = seg_off[seg] + (total - 1 - k);
+            long long pos = seg_off[lseg] + (total - 1 - k);
             sa_pair_t o;
             o.prob_e7 = prob_e7[S->cand_off + i];
             o.x = (int) (c.x + R->x1);
@@ -705,11 +711,23 @@ __global__ __launch_bounds__(64) void k_gather(DevPlan P, int n_segs, const long
         }                                                                                      \
     } while (0)
 
+struct sa_launch_chunk {
+    long long ids_gr, ids_fr;  // offsets into d_ids: memory-resident / register-kernel regions
+    int ngr, nfr;
+    int g0, g1;                // groups [g0, g1)
+};
+struct sa_launch_group {
+    long long seg0, seg1, ck0, ck1;
+    long long ids_gs, ids_fs;
+    int ngs, nfs;
+};
+
 struct sa_batch {
     sa_plan_t *plan;
     int device;
     unsigned flags;
-    hipStream_t stream;
+    hipStream_t stream;            // == cstream[0]
+    hipStream_t cstream[2];        // compute streams; groups alternate between them
     // device buffers
     sa_region_t *d_regions; sa_row_t *d_rows; int *d_pk; int *d_poff; int *d_pid; double *d_xc; double *d_ev;
     sa_seg_t *d_segs; sa_ck_t *d_cks;
@@ -722,10 +740,16 @@ struct sa_batch {
     int *d_ids;  // region / segment id lists per launch
     long long cand_alloc;
     long long out_alloc;
-    // launch lists (host)
-    std::vector<std::vector<int>> gen_regions, fast_regions, gen_segs, fast_segs;  // per chunk
+    // launch lists (host): a chunk is one forward-storage pass; its traceback segments are cut into groups of
+    // consecutive reads so that the result copy of one group overlaps the backward kernels of the next
+    std::vector<sa_launch_chunk> chunks;
+    std::vector<sa_launch_group> groups;
     std::vector<int> ids_flat;
-    std::vector<long long> ids_off;
+    hipStream_t pair_stream;       // the pairs themselves
+    std::vector<hipEvent_t> gev;   // per group: backward start, backward end, results ready, (unused)
+    std::vector<hipEvent_t> cev;   // per chunk: forward start, forward end
+    long long *h_seg_off;          // pinned: per group n+1 exclusive offsets
+    int *h_overflow;               // pinned
     // results
     sa_pair_t *h_pairs;      // pinned host copy of all pairs, job after job
     long long h_pairs_cap, n_pairs_total;
@@ -748,7 +772,7 @@ static DevPlan make_devplan(const sa_batch *b) {
     memset(&P, 0, sizeof(P));
     P.regions = b->d_regions; P.rows = b->d_rows; P.pk = b->d_pk; P.poff = b->d_poff; P.pid = b->d_pid; P.xc = b->d_xc; P.ev = b->d_ev;
     P.segs = b->d_segs; P.cks = b->d_cks; P.F = b->d_F; P.vbuf = b->d_vbuf; P.cands = b->d_cands;
-    P.cand_count = b->d_cand_count; P.overflow = b->d_overflow; P.totals = b->d_totals; P.bscratch = b->d_bscratch;
+    P.cand_count = b->d_cand_count; P.overflow = b->h_overflow; P.totals = b->d_totals; P.bscratch = b->d_bscratch;
     P.gsum = b->d_gsum; P.gmc = b->d_gmc;
     P.m.t_mm = m->t_mm; P.m.t_mx = m->t_mx; P.m.t_my = m->t_my; P.m.t_xm = m->t_xm; P.m.t_xx = m->t_xx;
     P.m.t_ym = m->t_ym; P.m.t_yy = m->t_yy;
@@ -779,8 +803,14 @@ void sa_batch_destroy(sa_batch_t *b) {
         if (p) (void) hipFree(p);
     for (int i = 0; i < 8; i++)
         if (b->ev[i]) (void) hipEventDestroy(b->ev[i]);
-    if (b->stream) (void) hipStreamDestroy(b->stream);
+    for (hipEvent_t e : b->gev) (void) hipEventDestroy(e);
+    for (hipEvent_t e : b->cev) (void) hipEventDestroy(e);
+    for (int i = 0; i < 2; i++)
+        if (b->cstream[i]) (void) hipStreamDestroy(b->cstream[i]);
+    if (b->pair_stream) (void) hipStreamDestroy(b->pair_stream);
     if (b->h_pairs) (void) hipHostFree(b->h_pairs);
+    if (b->h_seg_off) (void) hipHostFree(b->h_seg_off);
+    if (b->h_overflow) (void) hipHostFree(b->h_overflow);
     sa_plan_free(b->plan);
     delete b;
 }
@@ -810,6 +840,10 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     b->device = device;
     b->flags = flags;
     b->stream = nullptr;
+    b->cstream[0] = b->cstream[1] = nullptr;
+    b->pair_stream = nullptr;
+    b->h_seg_off = nullptr;
+    b->h_overflow = nullptr;
     b->ran = false;
     b->d_regions = nullptr; b->d_rows = nullptr; b->d_pk = nullptr; b->d_poff = nullptr; b->d_pid = nullptr; b->d_xc = nullptr;
     b->d_ev = nullptr; b->d_segs = nullptr; b->d_cks = nullptr; b->d_F = nullptr; b->d_vbuf = nullptr;
@@ -823,7 +857,20 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     memset(&b->stats, 0, sizeof(b->stats));
     for (int i = 0; i < 8; i++) b->ev[i] = nullptr;
 #define TRY(x) do { int rc_ = (x); if (rc_) { sa_batch_destroy(b); return rc_; } } while (0)
-    if (hipStreamCreate(&b->stream) != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
+    if (hipStreamCreateWithFlags(&b->cstream[0], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&b->cstream[1], hipStreamNonBlocking) != hipSuccess) {
+        sa_batch_destroy(b);
+        return SA_ENODEVICE;
+    }
+    b->stream = b->cstream[0];
+    {   // the copy stream outranks the compute streams
+        int prio_lo = 0, prio_hi = 0;
+        (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        if (hipStreamCreateWithPriority(&b->pair_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
+            sa_batch_destroy(b);
+            return SA_ENODEVICE;
+        }
+    }
     for (int i = 0; i < 8; i++)
         if (hipEventCreate(&b->ev[i]) != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
     TRY(upload(&b->d_regions, pl->regions, pl->n_regions));
@@ -877,7 +924,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     b->cand_alloc = pl->n_cand;
     TRY(dalloc((void **) &b->d_cand_count, 4 * pl->n_segs));
     TRY(dalloc((void **) &b->d_seg_pass, 4 * pl->n_segs));
-    TRY(dalloc((void **) &b->d_seg_off, 8 * (pl->n_segs + 1)));
+    TRY(dalloc((void **) &b->d_seg_off, 8 * (2 * pl->n_segs + 8)));  // n+1 offsets per group
     TRY(dalloc((void **) &b->d_overflow, 4));
     TRY(dalloc((void **) &b->d_totals, 8 * pl->n_cks));
     TRY(dalloc((void **) &b->d_bscratch, 8 * pl->n_bscratch));
@@ -885,34 +932,97 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
         TRY(dalloc((void **) &b->d_gsum, 64 * pl->n_cks));
         TRY(dalloc((void **) &b->d_gmc, 8 * pl->n_cks));
     }
-    // launch lists per chunk
-    b->gen_regions.resize(pl->n_chunks); b->fast_regions.resize(pl->n_chunks);
-    b->gen_segs.resize(pl->n_chunks); b->fast_segs.resize(pl->n_chunks);
-    for (long long r = 0; r < pl->n_regions; r++) {
-        const sa_region_t *R = &pl->regions[r];
-        auto &rl = (R->kind == SA_KIND_FAST) ? b->fast_regions[R->chunk] : b->gen_regions[R->chunk];
-        auto &sl = (R->kind == SA_KIND_FAST) ? b->fast_segs[R->chunk] : b->gen_segs[R->chunk];
-        rl.push_back((int) r);
-        for (long long s = R->seg_off; s < R->seg_off + R->n_seg; s++) sl.push_back((int) s);
-    }
-    // longest segments first inside each launch: the tail of a launch is then made of short waves
-    for (int c = 0; c < pl->n_chunks; c++) {
-        auto by_len_r = [&](int a, int d) { return pl->regions[a].N > pl->regions[d].N; };
-        auto by_len_s = [&](int a, int d) {
-            return pl->segs[a].start - pl->segs[a].to > pl->segs[d].start - pl->segs[d].to;
-        };
-        std::stable_sort(b->gen_regions[c].begin(), b->gen_regions[c].end(), by_len_r);
-        std::stable_sort(b->fast_regions[c].begin(), b->fast_regions[c].end(), by_len_r);
-        std::stable_sort(b->gen_segs[c].begin(), b->gen_segs[c].end(), by_len_s);
-        std::stable_sort(b->fast_segs[c].begin(), b->fast_segs[c].end(), by_len_s);
-    }
-    b->ids_flat.clear();
-    b->ids_off.clear();
-    for (int c = 0; c < pl->n_chunks; c++)
-        for (auto *v : {&b->gen_regions[c], &b->fast_regions[c], &b->gen_segs[c], &b->fast_segs[c]}) {
-            b->ids_off.push_back((long long) b->ids_flat.size());
-            b->ids_flat.insert(b->ids_flat.end(), v->begin(), v->end());
+    // launch lists: regions per chunk, traceback segments per group
+    {
+        const bool host_finalize = (flags & SA_FLAG_EXACT) || b->expect;
+        int want = 1;
+        const char *envg = getenv("SA_GROUPS");  // test hook
+        if (envg && atoi(envg) > 0) want = atoi(envg);
+        else if (!host_finalize) want = pl->n_chunks == 1 ? 8 : (pl->n_chunks < 4 ? 4 : 2);
+        b->ids_flat.clear();
+        long long r = 0;
+        for (int c = 0; c < pl->n_chunks; c++) {
+            long long ra = r;
+            while (r < pl->n_regions && pl->regions[r].chunk == c) r++;
+            long long rb = r;
+            sa_launch_chunk C;
+            std::vector<int> gr, fr;
+            double work = 0;
+            for (long long q = ra; q < rb; q++) {
+                (pl->regions[q].kind == SA_KIND_FAST ? fr : gr).push_back((int) q);
+                work += (double) pl->regions[q].N;
+            }
+            auto by_len_r = [&](int a, int d) { return pl->regions[a].N > pl->regions[d].N; };
+            // longest first inside each launch: the tail of a launch is then made of short waves
+            std::stable_sort(gr.begin(), gr.end(), by_len_r);
+            std::stable_sort(fr.begin(), fr.end(), by_len_r);
+            C.ids_gr = (long long) b->ids_flat.size(); C.ngr = (int) gr.size();
+            b->ids_flat.insert(b->ids_flat.end(), gr.begin(), gr.end());
+            C.ids_fr = (long long) b->ids_flat.size(); C.nfr = (int) fr.size();
+            b->ids_flat.insert(b->ids_flat.end(), fr.begin(), fr.end());
+            C.g0 = (int) b->groups.size();
+            // a group should still be a sizeable launch: at least 2048 segments each (measured optimum 6-8 groups
+            // for 18000 segments; 16 and more lose to launch gaps)
+            long long nseg_chunk = 0;
+            for (long long q = ra; q < rb; q++) nseg_chunk += pl->regions[q].n_seg;
+            int ng = want;
+            if (!(envg && atoi(envg) > 0))
+                while (ng > 1 && nseg_chunk / ng < 2048) ng--;
+            long long q = ra;
+            double acc = 0;
+            for (int g = 0; g < ng && q < rb; g++) {
+                long long qa = q;
+                double target = work * (double) (g + 1) / (double) ng;
+                while (q < rb && (g == ng - 1 || acc < target)) { acc += (double) pl->regions[q].N; q++; }
+                if (q == qa) continue;
+                // a read's regions stay in one group so that its pairs are contiguous in the output
+                while (q < rb && pl->regions[q].job == pl->regions[q - 1].job) { acc += (double) pl->regions[q].N; q++; }
+                sa_launch_group G;
+                G.seg0 = G.seg1 = G.ck0 = G.ck1 = 0;
+                std::vector<int> gs, fs;
+                bool any = false;
+                for (long long t = qa; t < q; t++) {
+                    const sa_region_t *R = &pl->regions[t];
+                    for (long long sg = R->seg_off; sg < R->seg_off + R->n_seg; sg++) {
+                        (R->kind == SA_KIND_FAST ? fs : gs).push_back((int) sg);
+                        const sa_seg_t *S = &pl->segs[sg];
+                        if (!any) { G.seg0 = sg; G.ck0 = S->ck_base; any = true; }
+                        G.seg1 = sg + 1;
+                        G.ck1 = S->ck_base + S->n_ck;
+                    }
+                }
+                if (!any) continue;
+                auto by_len_s = [&](int a, int d) {
+                    return pl->segs[a].start - pl->segs[a].to > pl->segs[d].start - pl->segs[d].to;
+                };
+                std::stable_sort(gs.begin(), gs.end(), by_len_s);
+                std::stable_sort(fs.begin(), fs.end(), by_len_s);
+                G.ids_gs = (long long) b->ids_flat.size(); G.ngs = (int) gs.size();
+                b->ids_flat.insert(b->ids_flat.end(), gs.begin(), gs.end());
+                G.ids_fs = (long long) b->ids_flat.size(); G.nfs = (int) fs.size();
+                b->ids_flat.insert(b->ids_flat.end(), fs.begin(), fs.end());
+                b->groups.push_back(G);
+            }
+            C.g1 = (int) b->groups.size();
+            b->chunks.push_back(C);
         }
+        b->gev.resize(4 * b->groups.size(), nullptr);
+        b->cev.resize(2 * b->chunks.size(), nullptr);
+        for (auto &e : b->gev)
+            if (hipEventCreate(&e) != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
+        for (auto &e : b->cev)
+            if (hipEventCreate(&e) != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
+        if (hipHostMalloc((void **) &b->h_seg_off, 8 * (size_t) (pl->n_segs + (long long) b->groups.size() + 1),
+                          hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **) &b->h_overflow, 64, hipHostMallocDefault) != hipSuccess) {
+            sa_batch_destroy(b);
+            return SA_ENOMEM;
+        }
+        if (!host_finalize) {
+            TRY(dalloc((void **) &b->d_out, (long long) sizeof(sa_pair_t) * pl->n_cand));
+            b->out_alloc = pl->n_cand;
+        }
+    }
     TRY(upload(&b->d_ids, b->ids_flat.data(), (long long) b->ids_flat.size()));
     b->stats.cells_forward = pl->cells_fwd;
     b->stats.cells_backward = pl->cells_bwd;
@@ -921,6 +1031,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     b->stats.n_checkpoints = pl->n_cks;
     b->stats.n_fast_regions = pl->n_fast_regions;
     b->stats.n_chunks = pl->n_chunks;
+    b->stats.n_groups = (int64_t) b->groups.size();
     double fb = 0;
     for (long long r = 0; r < pl->n_regions; r++) fb += 24.0 * (double) pl->regions[r].f_cellpaths;
     b->stats.f_bytes = fb;
@@ -929,73 +1040,134 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     return SA_OK;
 }
 
-static int run_once(sa_batch *b, bool *overflowed) {
+// One pass = per chunk the forward sweeps (stream 0), then per group the backward/posterior kernels, the exact fold
+// of its checkpoints and -- with `finalize` -- the on-device finalisation (k_scan also writes the segment offsets
+// straight into pinned host memory).  Consecutive groups alternate between two compute streams: the next group's
+// waves move in while the previous group's last waves drain, so cutting the traceback work into groups costs no
+// idle tail.  Everything is queued up front; `after_group` waits for one group and requests its pairs.  No copy that
+// depends on a kernel is ever queued: the copy engine works in order, and a transfer waiting for a kernel would hold
+// back the pair copies of groups that are already finished (measured: probes/copy_overlap.hip).
+static int submit_group(sa_batch *b, const DevPlan &P, int g, int which_stream, bool finalize) {
     sa_plan_t *pl = b->plan;
-    DevPlan P = make_devplan(b);
-    hipStream_t st = b->stream;
-    HIPCHK(hipMemsetAsync(b->d_cand_count, 0, 4 * (size_t) (pl->n_segs > 0 ? pl->n_segs : 1), st));
-    HIPCHK(hipMemsetAsync(b->d_overflow, 0, 4, st));
-    float ms_f = 0, ms_b = 0;
-    HIPCHK(hipEventRecord(b->ev[0], st));
-    for (int c = 0; c < pl->n_chunks; c++) {
-        const int *ids_gr = b->d_ids + b->ids_off[4 * c + 0];
-        const int *ids_fr = b->d_ids + b->ids_off[4 * c + 1];
-        const int *ids_gs = b->d_ids + b->ids_off[4 * c + 2];
-        const int *ids_fs = b->d_ids + b->ids_off[4 * c + 3];
-        int ngr = (int) b->gen_regions[c].size(), nfr = (int) b->fast_regions[c].size();
-        int ngs = (int) b->gen_segs[c].size(), nfs = (int) b->fast_segs[c].size();
-        HIPCHK(hipEventRecord(b->ev[1], st));
-        if (ngr) hipLaunchKernelGGL(k_fwd_generic, dim3(ngr), dim3(64), 0, st, P, ids_gr, ngr);
-        if (nfr) launch_fwd_fast(P, ids_fr, nfr, st);
-        HIPCHK(hipEventRecord(b->ev[2], st));
-        if (ngs && !b->expect) hipLaunchKernelGGL(k_bwd_generic<false>, dim3(ngs), dim3(64), 0, st, P, ids_gs, ngs);
-        if (ngs && b->expect) hipLaunchKernelGGL(k_bwd_generic<true>, dim3(ngs), dim3(64), 0, st, P, ids_gs, ngs);
-        if (nfs) launch_bwd_fast(P, ids_fs, nfs, st);
-        HIPCHK(hipEventRecord(b->ev[3], st));
-        HIPCHK(hipEventSynchronize(b->ev[3]));
-        float a = 0, d = 0;
-        HIPCHK(hipEventElapsedTime(&a, b->ev[1], b->ev[2]));
-        HIPCHK(hipEventElapsedTime(&d, b->ev[2], b->ev[3]));
-        ms_f += a;
-        ms_b += d;
+    const sa_launch_group &G = b->groups[g];
+    hipStream_t st = b->cstream[which_stream];
+    HIPCHK(hipEventRecord(b->gev[4 * g], st));
+    if (G.ngs && !b->expect)
+        hipLaunchKernelGGL(k_bwd_generic<false>, dim3(G.ngs), dim3(64), 0, st, P, b->d_ids + G.ids_gs, G.ngs);
+    if (G.ngs && b->expect)
+        hipLaunchKernelGGL(k_bwd_generic<true>, dim3(G.ngs), dim3(64), 0, st, P, b->d_ids + G.ids_gs, G.ngs);
+    if (G.nfs) launch_bwd_fast(P, b->d_ids + G.ids_fs, G.nfs, st);
+    HIPCHK(hipEventRecord(b->gev[4 * g + 1], st));
+    if (G.ck1 > G.ck0)
+        hipLaunchKernelGGL(k_fold, dim3((unsigned) ((G.ck1 - G.ck0 + 63) / 64)), dim3(64), 0, st, P, G.ck0, G.ck1);
+    if (finalize) {
+        const int n = (int) (G.seg1 - G.seg0);
+        long long *soff = b->d_seg_off + G.seg0 + g;
+        hipLaunchKernelGGL(k_finalize, dim3((unsigned) n), dim3(64), 0, st, P, (int) G.seg0, n, b->d_prob, b->d_seg_pass);
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, b->d_seg_pass + G.seg0, soff, b->h_seg_off + G.seg0 + g, n);
+        hipLaunchKernelGGL(k_gather, dim3((unsigned) n), dim3(64), 0, st, P, (int) G.seg0, n, b->d_prob, soff,
+                           b->d_out + pl->segs[G.seg0].cand_off);
+        HIPCHK(hipEventRecord(b->gev[4 * g + 2], st));
+    } else {
+        HIPCHK(hipEventRecord(b->gev[4 * g + 2], st));
     }
-    HIPCHK(hipEventRecord(b->ev[4], st));
-    if (pl->n_cks) hipLaunchKernelGGL(k_fold, dim3((unsigned) ((pl->n_cks + 63) / 64)), dim3(64), 0, st, P, (long long) pl->n_cks);
-    HIPCHK(hipEventRecord(b->ev[5], st));
-    HIPCHK(hipGetLastError());
-    int ov = 0;
-    HIPCHK(hipMemcpyAsync(&ov, b->d_overflow, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    float ms_fold = 0, ms_tot = 0;
-    HIPCHK(hipEventElapsedTime(&ms_fold, b->ev[4], b->ev[5]));
-    HIPCHK(hipEventElapsedTime(&ms_tot, b->ev[0], b->ev[5]));
-    b->stats.ms_forward = ms_f;
-    b->stats.ms_backward = ms_b;
-    b->stats.ms_fold = ms_fold;
-    b->stats.ms_total_device = ms_tot;
-    *overflowed = ov != 0;
     return SA_OK;
 }
 
-static int run_passes(sa_batch_t *b) {
+template <typename AfterGroup>
+static int enqueue_pass(sa_batch *b, bool finalize, AfterGroup after_group) {
     sa_plan_t *pl = b->plan;
-    bool ov = false;
-    for (int attempt = 0; attempt < 6; attempt++) {
-        int rc = run_once(b, &ov);
-        if (rc) return rc;
-        if (!ov) break;
-        // a traceback segment produced more candidates than planned: enlarge and redo the pass
-        sa_plan_grow_candidates(pl, 4);
-        HIPCHK(hipFree(b->d_cands));
-        HIPCHK(hipFree(b->d_prob));
-        b->d_cands = nullptr;
-        b->d_prob = nullptr;
-        HIPCHK(hipMalloc((void **) &b->d_cands, sizeof(sa_cand_t) * (size_t) pl->n_cand));
-        HIPCHK(hipMalloc((void **) &b->d_prob, 8 * (size_t) pl->n_cand));
-        b->cand_alloc = pl->n_cand;
-        HIPCHK(hipMemcpy(b->d_segs, pl->segs, sizeof(sa_seg_t) * (size_t) pl->n_segs, hipMemcpyHostToDevice));
+    DevPlan P = make_devplan(b);
+    hipStream_t s0 = b->cstream[0], s1 = b->cstream[1];
+    HIPCHK(hipMemsetAsync(b->d_cand_count, 0, 4 * (size_t) (pl->n_segs > 0 ? pl->n_segs : 1), s0));
+    b->h_overflow[0] = 0;  // pinned host word the kernels raise directly
+    HIPCHK(hipEventRecord(b->ev[0], s0));
+    for (size_t c = 0; c < b->chunks.size(); c++) {
+        const sa_launch_chunk &C = b->chunks[c];
+        HIPCHK(hipEventRecord(b->cev[2 * c], s0));
+        if (C.ngr) hipLaunchKernelGGL(k_fwd_generic, dim3(C.ngr), dim3(64), 0, s0, P, b->d_ids + C.ids_gr, C.ngr);
+        if (C.nfr) launch_fwd_fast(P, b->d_ids + C.ids_fr, C.nfr, s0);
+        HIPCHK(hipEventRecord(b->cev[2 * c + 1], s0));
+        if (C.g1 - C.g0 > 1) HIPCHK(hipStreamWaitEvent(s1, b->cev[2 * c + 1], 0));
+        int submitted = C.g0, completed = C.g0;
+        while (completed < C.g1) {
+            while (submitted < C.g1) {
+                int rc = submit_group(b, P, submitted, (submitted - C.g0) & 1, finalize);
+                if (rc) return rc;
+                submitted++;
+            }
+            int rcg = after_group((size_t) completed);
+            if (rcg) return rcg;
+            completed++;
+        }
+        // the next chunk's forward sweep reuses the forward storage: both streams must be done with it
+        for (int g = C.g0; g < C.g1; g++)
+            if ((g - C.g0) & 1) HIPCHK(hipStreamWaitEvent(s0, b->gev[4 * g + 2], 0));
     }
-    return ov ? SA_ENOMEM : SA_OK;
+    HIPCHK(hipEventRecord(b->ev[5], s0));
+    HIPCHK(hipGetLastError());
+    return SA_OK;
+}
+
+// after the stream has drained: kernel times from the events
+static int collect_times(sa_batch *b) {
+    float ms_f = 0, ms_b = 0, ms_tot = 0, t = 0;
+    for (size_t c = 0; c < b->chunks.size(); c++) {
+        const sa_launch_chunk &C = b->chunks[c];
+        HIPCHK(hipEventElapsedTime(&t, b->cev[2 * c], b->cev[2 * c + 1]));
+        ms_f += t;
+        // backward stage of the chunk: from the end of its forward sweep to the last backward kernel's end (the
+        // groups' kernels overlap on two streams; finalisation kernels of earlier groups run inside this window)
+        float last = 0;
+        for (int g = C.g0; g < C.g1; g++) {
+            HIPCHK(hipEventElapsedTime(&t, b->cev[2 * c + 1], b->gev[4 * g + 1]));
+            last = t > last ? t : last;
+        }
+        ms_b += last;
+    }
+    HIPCHK(hipEventElapsedTime(&ms_tot, b->ev[0], b->ev[5]));
+    b->stats.ms_forward = ms_f;
+    b->stats.ms_backward = ms_b;
+    b->stats.ms_fold = ms_tot - ms_f - ms_b;  // what follows the last backward kernel: fold (+ finalisation) of the last group
+    b->stats.ms_total_device = ms_tot;
+    return SA_OK;
+}
+
+static int grow_after_overflow(sa_batch *b) {
+    sa_plan_t *pl = b->plan;
+    // a traceback segment produced more candidates than planned: enlarge and redo the pass
+    sa_plan_grow_candidates(pl, 4);
+    HIPCHK(hipFree(b->d_cands));
+    HIPCHK(hipFree(b->d_prob));
+    b->d_cands = nullptr;
+    b->d_prob = nullptr;
+    HIPCHK(hipMalloc((void **) &b->d_cands, sizeof(sa_cand_t) * (size_t) pl->n_cand));
+    HIPCHK(hipMalloc((void **) &b->d_prob, 8 * (size_t) pl->n_cand));
+    b->cand_alloc = pl->n_cand;
+    if (b->d_out) {
+        HIPCHK(hipFree(b->d_out));
+        b->d_out = nullptr;
+        HIPCHK(hipMalloc((void **) &b->d_out, sizeof(sa_pair_t) * (size_t) pl->n_cand));
+        b->out_alloc = pl->n_cand;
+    }
+    HIPCHK(hipMemcpy(b->d_segs, pl->segs, sizeof(sa_seg_t) * (size_t) pl->n_segs, hipMemcpyHostToDevice));
+    return SA_OK;
+}
+
+// kernels only (host finalisation follows): SA_FLAG_EXACT and the expectation pass
+static int run_passes(sa_batch_t *b) {
+    for (int attempt = 0; attempt < 6; attempt++) {
+        int rc = enqueue_pass(b, false, [](size_t) { return (int) SA_OK; });
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(b->cstream[1]));
+        HIPCHK(hipStreamSynchronize(b->cstream[0]));
+        rc = collect_times(b);
+        if (rc) return rc;
+        if (!b->h_overflow[0]) return SA_OK;
+        rc = grow_after_overflow(b);
+        if (rc) return rc;
+    }
+    return SA_ENOMEM;
 }
 
 int sa_batch_run(sa_batch_t *b) {
@@ -1003,8 +1175,6 @@ int sa_batch_run(sa_batch_t *b) {
     if (b->expect) return SA_ESTATE;
     HIPCHK(hipSetDevice(b->device));
     sa_plan_t *pl = b->plan;
-    int rcp0 = run_passes(b);
-    if (rcp0) return rcp0;
     long long n_segs = pl->n_segs;
     b->n_pairs_total = 0;
     b->job_off.assign((size_t) pl->n_jobs + 1, 0);
@@ -1019,6 +1189,8 @@ int sa_batch_run(sa_batch_t *b) {
         return SA_OK;
     };
     if (b->flags & SA_FLAG_EXACT) {
+        int rcp0 = run_passes(b);
+        if (rcp0) return rcp0;
         // host finalisation with the C library's exp(): bit-identical to the reference's posterior arithmetic
         std::vector<sa_cand_t> cands((size_t) (pl->n_cand > 0 ? pl->n_cand : 1));
         std::vector<int> counts((size_t) (n_segs > 0 ? n_segs : 1));
@@ -1043,42 +1215,85 @@ int sa_batch_run(sa_batch_t *b) {
         }
         b->job_off[pl->n_jobs] = total;
         b->n_pairs_total = total;
-    } else if (n_segs > 0) {
-        DevPlan P = make_devplan(b);
-        hipStream_t st = b->stream;
-        hipLaunchKernelGGL(k_finalize, dim3((unsigned) n_segs), dim3(64), 0, st, P, (int) n_segs, b->d_prob, b->d_seg_pass);
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, b->d_seg_pass, b->d_seg_off, (int) n_segs);
-        std::vector<long long> seg_off((size_t) n_segs + 1);
-        HIPCHK(hipMemcpyAsync(seg_off.data(), b->d_seg_off, 8 * (size_t) (n_segs + 1), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        long long total = seg_off[n_segs];
-        if (total > b->out_alloc) {
-            if (b->d_out) HIPCHK(hipFree(b->d_out));
-            b->d_out = nullptr;
-            HIPCHK(hipMalloc((void **) &b->d_out, sizeof(sa_pair_t) * (size_t) (total + total / 8 + 64)));
-            b->out_alloc = total + total / 8 + 64;
-        }
-        if (total > 0) {
-            hipLaunchKernelGGL(k_gather, dim3((unsigned) n_segs), dim3(64), 0, st, P, (int) n_segs, b->d_prob, b->d_seg_off, b->d_out);
-            int rcp = reserve_pairs(total);
-            if (rcp) return rcp;
-            HIPCHK(hipMemcpyAsync(b->h_pairs, b->d_out, sizeof(sa_pair_t) * (size_t) total, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-        }
-        HIPCHK(hipGetLastError());
-        for (long long j = 0; j < pl->n_jobs; j++) {
-            const sa_jobinfo_t *J = &pl->jobs[j];
-            long long first_seg = n_segs;
-            if (J->n_regions > 0) first_seg = pl->regions[J->region_off].seg_off;
-            else {
-                // jobs without regions: position of the next job's first segment
-                for (long long k = j + 1; k < pl->n_jobs; k++)
-                    if (pl->jobs[k].n_regions > 0) { first_seg = pl->regions[pl->jobs[k].region_off].seg_off; break; }
+        b->ran = true;
+        return SA_OK;
+    }
+    // default: finalisation on the device, group after group; the pairs of group g travel to the pinned host buffer
+    // on the copy stream while the kernels of group g+1 run
+    const size_t ng = b->groups.size();
+    std::vector<long long> gbase(ng + 1, 0);
+    bool done = false;
+    const bool trace = getenv("SA_TRACE") != nullptr;
+    auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    for (int attempt = 0; attempt < 6 && !done; attempt++) {
+        double t0 = now_ms();
+        bool piped = true;
+        long long running = 0;
+        auto after_group = [&](size_t g) -> int {
+            const sa_launch_group &G = b->groups[g];
+            HIPCHK(hipEventSynchronize(b->gev[4 * g + 2]));
+            long long tg = b->h_seg_off[G.seg0 + g + (G.seg1 - G.seg0)];
+            if (trace) fprintf(stderr, "[trace] group %zu ready at %.3f ms, %lld pairs\n", g, now_ms() - t0, tg);
+            gbase[g] = running;
+            if (piped && running + tg <= b->h_pairs_cap) {
+                if (tg > 0)
+                    HIPCHK(hipMemcpyAsync(b->h_pairs + running, b->d_out + pl->segs[G.seg0].cand_off,
+                                          sizeof(sa_pair_t) * (size_t) tg, hipMemcpyDeviceToHost, b->pair_stream));
+            } else {
+                piped = false;  // first run (or a larger result than last time): size the pinned buffer afterwards
             }
-            b->job_off[j] = seg_off[first_seg];
+            running += tg;
+            return SA_OK;
+        };
+        int rc = enqueue_pass(b, true, after_group);
+        if (rc) return rc;
+        gbase[ng] = running;
+        HIPCHK(hipStreamSynchronize(b->cstream[1]));
+        HIPCHK(hipStreamSynchronize(b->cstream[0]));
+        if (trace) fprintf(stderr, "[trace] compute stream drained at %.3f ms\n", now_ms() - t0);
+        HIPCHK(hipStreamSynchronize(b->pair_stream));
+        if (trace) fprintf(stderr, "[trace] copies drained at %.3f ms (piped %d)\n", now_ms() - t0, (int) piped);
+        rc = collect_times(b);
+        if (rc) return rc;
+        if (b->h_overflow[0]) {
+            rc = grow_after_overflow(b);
+            if (rc) return rc;
+            continue;
         }
-        b->job_off[pl->n_jobs] = total;
-        b->n_pairs_total = total;
+        if (!piped) {
+            rc = reserve_pairs(running);
+            if (rc) return rc;
+            for (size_t g = 0; g < ng; g++) {
+                const sa_launch_group &G = b->groups[g];
+                long long tg = gbase[g + 1] - gbase[g];
+                if (tg > 0)
+                    HIPCHK(hipMemcpyAsync(b->h_pairs + gbase[g], b->d_out + pl->segs[G.seg0].cand_off,
+                                          sizeof(sa_pair_t) * (size_t) tg, hipMemcpyDeviceToHost, b->pair_stream));
+            }
+            HIPCHK(hipStreamSynchronize(b->pair_stream));
+        }
+        done = true;
+    }
+    if (!done) return SA_ENOMEM;
+    // job offsets: a job's pairs start where its first segment's do
+    {
+        std::vector<int> seg_group((size_t) (n_segs > 0 ? n_segs : 1), 0);
+        for (size_t g = 0; g < ng; g++)
+            for (long long sg = b->groups[g].seg0; sg < b->groups[g].seg1; sg++) seg_group[sg] = (int) g;
+        long long next = gbase[ng];
+        for (long long j = pl->n_jobs - 1; j >= 0; j--) {
+            const sa_jobinfo_t *J = &pl->jobs[j];
+            long long first_seg = -1;
+            for (long long r = J->region_off; r < J->region_off + J->n_regions && first_seg < 0; r++)
+                if (pl->regions[r].n_seg > 0) first_seg = pl->regions[r].seg_off;
+            if (first_seg >= 0) {
+                int g = seg_group[first_seg];
+                next = gbase[g] + b->h_seg_off[first_seg + g];
+            }
+            b->job_off[j] = next;  // jobs without segments are empty ranges in front of the next job
+        }
+        b->job_off[pl->n_jobs] = gbase[ng];
+        b->n_pairs_total = gbase[ng];
     }
     b->ran = true;
     return SA_OK;

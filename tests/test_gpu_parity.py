@@ -214,6 +214,19 @@ def test_split_regions_and_chunked_forward_storage(oracle, monkeypatch):
     assert st2.n_chunks > 1
     for j in range(len(jobs)):
         assert np.array_equal(got2[j], got[j])
+    # several result groups per pass (pipelined result copy), alone and combined with several passes; a second
+    # run() of the same batch takes the overlapped-copy path (the pinned buffer is sized by the first)
+    for env in ({"SA_GROUPS": "3"}, {"SA_GROUPS": "2", "SA_F_BUDGET_CELLPATHS": "200000"}):
+        monkeypatch.delenv("SA_F_BUDGET_CELLPATHS", raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        b = sa.Batch(pm, p, jobs + [dict(ref="ACGTACGT", events=np.zeros(0), ax=[], ay=[])])
+        for _ in range(2):
+            b.run()
+            for j in range(len(jobs)):
+                assert np.array_equal(b.pairs(j), got[j]), (env, j)
+            assert b.n_pairs(len(jobs)) == 0
+        b.close()
 
 
 def test_round_trip_properties_full_size(oracle):
