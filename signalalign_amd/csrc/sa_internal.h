@@ -78,13 +78,19 @@ typedef struct sa_region {
     int64_t f_cellpaths;
 } sa_region_t;
 
-/* packed band word (register kernels): width | flags | ((x-y+K)>>1 of the first cell) << SA_PK_SHIFT */
+/* packed band word (register kernels): width | flags | ((x-y+K)>>1 of the first cell) << SA_PK_SHIFT.
+ * Everything wave-uniform the inner loops would otherwise derive from neighbouring words is a flag here. */
 #define SA_PK_WIDTH_MASK 127
-#define SA_PK_FWD 128   /* diagonal d, d-1, d-2 (+1 cell each side) fit in 64 lanes        */
-#define SA_PK_BWD 256   /* diagonal e, e+1, e+2 fit in 64 lanes                            */
-#define SA_PK_FULL 512  /* all three forward planes of this diagonal are read back (checkpoint diagonal) */
-#define SA_PK_SHIFT 10
-#define SA_PK_PAD 64    /* readable words in front of diagonal 0; 96 behind diagonal N     */
+#define SA_PK_FWD 128        /* diagonal d, d-1, d-2 (+1 cell each side) fit in 64 lanes                       */
+#define SA_PK_BWD 256        /* diagonal e, e+1, e+2 fit in 64 lanes                                           */
+#define SA_PK_FULL 512       /* forward sweep stores all three planes of this diagonal: it is a checkpoint, or
+                                one of the next two diagonals is memory-resident, or the matrix ends            */
+#define SA_PK_FWD_MORE 1024  /* d < N and diagonal d+1 has SA_PK_FWD                                           */
+#define SA_PK_BWD_MORE 2048  /* diagonal e-1 has SA_PK_BWD                                                     */
+#define SA_PK_CK 4096        /* total-probability checkpoint of the traceback that owns this diagonal          */
+#define SA_PK_SHIFT 13
+#define SA_PK_PAD 64         /* readable (zero) words in front of diagonal 0; 96 behind diagonal N             */
+#define SA_FAST_MAX_CELLS (1ll << 27) /* register kernels address a region's forward planes with 32-bit byte offsets */
 
 typedef struct sa_seg {
     int32_t region, at_end;

@@ -484,11 +484,12 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
         }
         pl->n_pk += N + 1 + SA_PK_PAD + 96;
     }
-    R->f_cellpaths = foff;
+    R->f_cellpaths = foff + 1; /* last cell of the match plane: a -inf sentinel the backward kernel reads for lanes without a cell */
     R->max_rowpaths = (int32_t) max_rowpaths;
     R->slots = (int32_t) ((span + 63) / 64);
     if (span > pl->max_span) pl->max_span = span;
     int fast_ok = maxP == 1 && m->hdp == NULL && !(pl->flags & (SA_FLAG_EXACT | SA_FLAG_FORCE_GENERIC));
+    if (foff + 1 > SA_FAST_MAX_CELLS || ((lX + lY + K) >> 1) >= (1ll << (31 - SA_PK_SHIFT))) fast_ok = 0;
     R->kind = fast_ok ? SA_KIND_FAST : SA_KIND_GENERIC;
     if (fast_ok) pl->n_fast_regions++;
 
@@ -525,7 +526,7 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
             int64_t e = S->from - SA_CKPT_EVERY * c;
             sa_ck_t *ck = &pl->cks[pl->n_cks++];
             ck->voff = pl->n_vbuf;
-            pl->pk[R->pk_off + SA_PK_PAD + e] |= SA_PK_FULL; /* dot(F,B) over all three states is taken here */
+            pl->pk[R->pk_off + SA_PK_PAD + e] |= SA_PK_CK; /* dot(F,B) over all three states is taken here */
             ck->nA = rows[e].width;
             ck->nB = e < S->start ? rows[e + 1].width : 0;
             pl->n_vbuf += ck->nA + ck->nB;
@@ -547,6 +548,15 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
         traced_to = S->from;
     }
     R->n_seg = (int32_t) (pl->n_segs - R->seg_off);
+    {   /* derived flags (the words behind diagonal N are zero) */
+        int32_t *pk = pl->pk + R->pk_off + SA_PK_PAD;
+        for (int64_t d = 0; d <= N; d++) {
+            if ((pk[d] & SA_PK_CK) || !(pk[d + 1] & SA_PK_FWD) || !(pk[d + 2] & SA_PK_FWD) || d + 2 > N)
+                pk[d] |= SA_PK_FULL;
+            if (d < N && (pk[d + 1] & SA_PK_FWD)) pk[d] |= SA_PK_FWD_MORE;
+            if (d >= 1 && (pk[d - 1] & SA_PK_BWD)) pk[d] |= SA_PK_BWD_MORE;
+        }
+    }
     free(lo);
     free(hi);
     pl->jobs[job].cells_fwd += cf;
