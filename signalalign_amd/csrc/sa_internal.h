@@ -89,7 +89,8 @@ typedef struct sa_region {
 #define SA_PK_BWD_MORE 2048  /* diagonal e-1 has SA_PK_BWD                                                     */
 #define SA_PK_CK 4096        /* total-probability checkpoint of the traceback that owns this diagonal          */
 #define SA_PK_SHIFT 13
-#define SA_PK_PAD 64         /* readable (zero) words in front of diagonal 0; 96 behind diagonal N             */
+#define SA_PK_PAD 64         /* readable (zero) words in front of diagonal 0; 160 behind diagonal N             */
+#define SA_FAST_ROW_ALIGN 1 /* cells; 16 (128-byte rows) was measured: no gain, packed rows write better (probes/store_probe.hip) */
 #define SA_FAST_MAX_CELLS (1ll << 27) /* register kernels address a region's forward planes with 32-bit byte offsets */
 
 typedef struct sa_seg {

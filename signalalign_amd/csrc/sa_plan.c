@@ -445,6 +445,10 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
     R->K = (int32_t) K;
     int64_t foff = 0, max_rowpaths = 0, span = 0;
     double cf = 0;
+    /* register-kernel regions start every diagonal on a 128-byte boundary of its plane: a cache line then belongs to
+     * one store instruction of one diagonal and never has to be merged with the next diagonal's bytes */
+    int fast_ok = maxP == 1 && m->hdp == NULL && !(pl->flags & (SA_FLAG_EXACT | SA_FLAG_FORCE_GENERIC));
+    const int64_t row_align = fast_ok ? SA_FAST_ROW_ALIGN : 1;
     for (int64_t d = 0; d <= N; d++) {
         int64_t w = (hi[d] - lo[d]) / 2 + 1;
         int64_t x0 = (d + lo[d]) / 2, xe = x0 + w; /* cells cover x0 .. xe-1 */
@@ -452,7 +456,7 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
         rows[d].xmyL = (int32_t) lo[d];
         rows[d].width = (int32_t) w;
         rows[d].foff = foff;
-        foff += paths;
+        foff += (paths + row_align - 1) / row_align * row_align;
         if (paths > max_rowpaths) max_rowpaths = paths;
         if (d >= 1) cf += (double) paths;
         /* widest window of (x-y+K)>>1 over three consecutive diagonals plus one neighbour each side */
@@ -468,11 +472,11 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
         if (wr - wl + 1 > span) span = wr - wl + 1;
     }
     /* packed band words for the register kernels */
-    GROW(pl, pk, n_pk, cap_pk, N + 1 + SA_PK_PAD + 96, int32_t);
+    GROW(pl, pk, n_pk, cap_pk, N + 1 + SA_PK_PAD + 160, int32_t);
     R->pk_off = pl->n_pk;
     {
         int32_t *pk = pl->pk + pl->n_pk;
-        memset(pk, 0, sizeof(int32_t) * (size_t) (N + 1 + SA_PK_PAD + 96));
+        memset(pk, 0, sizeof(int32_t) * (size_t) (N + 1 + SA_PK_PAD + 160));
         rows = pl->rows + R->row_off;
         for (int64_t d = 0; d <= N; d++) {
             int64_t uL = ((int64_t) rows[d].xmyL + K) >> 1;
@@ -482,13 +486,12 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
             if (rows[d + 2 <= N ? d + 2 : N].span3 <= 64) word |= SA_PK_BWD;
             pk[SA_PK_PAD + d] = word;
         }
-        pl->n_pk += N + 1 + SA_PK_PAD + 96;
+        pl->n_pk += N + 1 + SA_PK_PAD + 160;
     }
     R->f_cellpaths = foff + 1; /* last cell of the match plane: a -inf sentinel the backward kernel reads for lanes without a cell */
     R->max_rowpaths = (int32_t) max_rowpaths;
     R->slots = (int32_t) ((span + 63) / 64);
     if (span > pl->max_span) pl->max_span = span;
-    int fast_ok = maxP == 1 && m->hdp == NULL && !(pl->flags & (SA_FLAG_EXACT | SA_FLAG_FORCE_GENERIC));
     if (foff + 1 > SA_FAST_MAX_CELLS || ((lX + lY + K) >> 1) >= (1ll << (31 - SA_PK_SHIFT))) fast_ok = 0;
     R->kind = fast_ok ? SA_KIND_FAST : SA_KIND_GENERIC;
     if (fast_ok) pl->n_fast_regions++;
