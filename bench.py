@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=2000, help="reads per GPU (BASELINE configs[1]: 2000)")
     ap.add_argument("--events", type=int, default=5000, help="events per read (BASELINE configs[1]: 5000)")
+    ap.add_argument("--workload", choices=["gaussian", "cpg", "hdp"], default="gaussian",
+                    help="gaussian = BASELINE configs[1] (the headline); cpg = configs[2] (ACEGT model, every CpG cytosine "
+                         "ambiguous C/E); hdp = configs[3] (HDP emissions).  The last two run on the memory-resident kernels.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reads-per-thread", type=int, default=30)
     args = ap.parse_args()
@@ -74,16 +77,28 @@ def main():
     import signalalign_amd as sa
     from signalalign_amd import synth
 
-    alpha, k, t10, tab = synth.parse_model_table(MODEL)
-    pm = sa.Model.load(MODEL)
+    gold = os.path.join(ROOT, "tests", "golden", "models")
+    model_path, nhdp, ambig, read_kw, wl_name = MODEL, None, None, {}, "BASELINE configs[1]: R9.4 6-mer template Gaussian HMM"
+    if args.workload == "cpg":
+        model_path = os.path.join(gold, "testModelR9.4_450bps.cpg.6mer.template.model")
+        ambig, read_kw = sa.default_ambig({"X": "CE"}), {"cpg_ambiguous": True}
+        wl_name = "BASELINE configs[2]: R9.4 6-mer CpG model (ACEGT), every CpG cytosine ambiguous (C/E)"
+    elif args.workload == "hdp":
+        model_path = os.path.join(gold, "testModelR73_acegot_template.model")
+        nhdp = os.path.join(gold, "templateSingleLevelFixed.nhdp")
+        wl_name = "BASELINE configs[3]: HDP emissions (templateSingleLevelFixed.nhdp, R7.3 ACEGOT 6-mer model)"
+    alpha, k, t10, tab = synth.parse_model_table(model_path)
+    pm = sa.Model.load(model_path, nhdp)
+    if nhdp:
+        pm.set_to_hdp_expected_values()
     params = sa.default_params(threshold=0.01, expansion=50, trace_back=100)
     # reads are independent: the global read list is dealt to the ranks (no collective on the data path)
     from signalalign_amd import shard
     mine = shard.shard_indices([args.events] * (world * args.reads), rank, world)
-    jobs = [synth.make_read(int(i), args.events, alpha, k, tab) for i in mine]
+    jobs = [synth.make_read(int(i), args.events, alpha, k, tab, **read_kw) for i in mine]
     n_events_total = sum(len(j["events"]) for j in jobs)
     t_create = time.perf_counter()
-    batch = sa.Batch(pm, params, jobs, device=local_rank if world > 1 else 0)  # planning + upload to HBM
+    batch = sa.Batch(pm, params, jobs, ambig=ambig, device=local_rank if world > 1 else 0)  # planning + upload to HBM
     t_create = time.perf_counter() - t_create
     st0 = batch.stats()
     cells = st0.cells_forward + st0.cells_backward
@@ -127,10 +142,11 @@ def main():
         # n_groups launches per step that overlap pairwise on two streams: its duration here is
         # the wall time of the whole traceback stage (end of forward -> end of the last k_bwd_fast), which also
         # contains the fold/finalisation kernels of the earlier groups, and the bytes are those of all launches.
+        fam = "fast" if st0.n_fast_regions == st0.n_regions else "generic"
         if ms_b >= ms_f:
-            dom, dom_ms, dom_cells = "k_bwd_fast", ms_b, st0.cells_backward
+            dom, dom_ms, dom_cells = "k_bwd_" + fam, ms_b, st0.cells_backward
         else:
-            dom, dom_ms, dom_cells = "k_fwd_fast", ms_f, st0.cells_forward
+            dom, dom_ms, dom_cells = "k_fwd_" + fam, ms_f, st0.cells_forward
         achieved = ALGO_BYTES_PER_CELL * dom_cells / (dom_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")  # written from the rocprofv3 --pmc passes, see DESIGN.md
@@ -153,8 +169,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: R9.4 6-mer template Gaussian HMM, %d synthetic %d-event reads per GPU, "
-                            "band=50, threshold 0.01, traceBackDiagonals 100" % (args.reads, args.events),
+                "workload": "%s, %d synthetic %d-event reads per GPU, band=50, threshold 0.01, traceBackDiagonals 100"
+                            % (wl_name, args.reads, args.events),
                 "reads_per_gpu": args.reads, "events_per_read": args.events,
                 "events_per_s": events_all * K / dt,
                 "cells_per_event": cells / max(n_events_total, 1),
@@ -172,9 +188,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_step": ALGO_BYTES_PER_CELL * dom_cells,
                          "stage_ms": dom_ms,
-                         "launches_per_step": int(st0.n_groups) if dom == "k_bwd_fast" else int(st0.n_chunks)},
+                         "launches_per_step": int(st0.n_groups) if dom.startswith("k_bwd") else int(st0.n_chunks)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.workload == "gaussian":
             out["cpu_baseline"] = cpu_baseline(alpha, k, t10, tab, args.events, args.cpu_reads_per_thread,
                                                first_index=10 ** 6)
         print(json.dumps(out))
