@@ -6,6 +6,13 @@
  * The banded pair-HMM itself runs on the MI355X through libsignalalign_hip.so; there is no CPU fallback.
  *
  * Expectations mode (-t/-c) runs sa_expect_batch and writes the .expectations files of impl/continuousHmm.c.
+ *
+ * Batch front door (not in the reference): --batch <manifest> aligns many reads in ONE
+ * process and ONE GPU batch per strand model -- models are parsed once, HIP is initialised once, and the reads run
+ * side by side on the device.  Manifest: one read per line, tab separated, '#' comments,
+ *     label  npRead  cigar_file  posteriors_out  [posteriors_out2|-]  [sequence_name|-]  [template_expectations|-]  [complement_expectations|-]
+ * Everything else (models, references, thresholds, output format) comes from the usual options.  Per read the same
+ * files, stdout summary line and stderr SUCCESS line are produced as by one single-read invocation.
  */
 #define _GNU_SOURCE
 #include <getopt.h>
@@ -58,7 +65,8 @@ static double descale(double e, double level, double scale, double shift, double
 
 typedef struct {
     sa_model_t *model;
-    double *table;          /* working copy of EMISSION_MATCH_MATRIX (noise columns rescaled per read) */
+    double *table;          /* EMISSION_MATCH_MATRIX as the DP uses it (HDP expected means once they are set)  */
+    double *table_orig;     /* as loaded: what the per-read parameter estimation starts from                  */
     char alphabet[64];
     int n_alpha, k;
 } strand_model_t;
@@ -106,7 +114,9 @@ static void write_full(const char *path, const out_ctx_t *o) {
         memcpy(k_i, o->target + p->x, k);
         k_i[k] = 0;
         kmer_string(o->sm, p->kmer_id, path_kmer);
-        double E_mean = o->sm->table[(int64_t) p->kmer_id * 5], E_noise = o->sm->table[(int64_t) p->kmer_id * 5 + 2];
+        double E_mean = o->sm->table[(int64_t) p->kmer_id * 5];
+        /* emissions_signal_scaleNoise (impl/stateMachine.c:721-741) rescales the table per read; applied on the fly here */
+        double E_noise = o->sm->table[(int64_t) p->kmer_id * 5 + 2] * o->npp.scale_sd;
         double scaled_Emean = E_mean * o->npp.scale + o->npp.shift;
         double scaled_Enoise = E_noise * o->npp.scale_sd;
         double descaled = descale(ev_mean, E_mean, o->npp.scale, o->npp.shift, o->npp.var);
@@ -187,8 +197,9 @@ static void output_alignment(int64_t fmt, const char *f1, const char *f2, const 
 }
 
 /* continuousPairHmm_writeToFile (impl/continuousHmm.c:352-408) / hdpHmm_writeToFile (:572-623) */
-static void write_expectations(const char *path, const strand_model_t *sm, int hdp, const double *trans, double lik,
-                               const sa_job_t *job, const sa_assignment_t *as, int64_t n_as) {
+static void write_expectations(const char *path, const strand_model_t *sm, const sa_strand_params_t *npp, int hdp,
+                               const double *trans, double lik, const sa_job_t *job, const sa_assignment_t *as,
+                               int64_t n_as) {
     for (int i = 0; i < 9; i++)
         if (isnan(trans[i])) { /* hmmContinuous_checkTransitions: an empty file is left behind */
             fprintf(stderr, "GOT NaN TRANS\n");
@@ -203,7 +214,12 @@ static void write_expectations(const char *path, const strand_model_t *sm, int h
     fprintf(fh, "%d\t%d\t%s\t%d\t\n", 3, sm->n_alpha, sm->alphabet, sm->k);
     for (int i = 0; i < 9; i++) fprintf(fh, "%f\t", trans[i]);
     fprintf(fh, "%f\n", lik);
-    for (int64_t i = 0; i < n_kmers * 5; i++) fprintf(fh, "%lf\t", sm->table[i]);
+    /* the event model is the state machine's table after this read's emissions_signal_scaleNoise
+     * (impl/stateMachine.c:721-741: noise_mean *= scale_sd, noise_lambda *= var_sd, noise_sd = sqrt(mean^3 / lambda)) */
+    for (int64_t i = 0; i < n_kmers * 5; i += 5) {
+        double nm = sm->table[i + 2] * npp->scale_sd, nl = sm->table[i + 4] * npp->var_sd;
+        fprintf(fh, "%lf\t%lf\t%lf\t%lf\t%lf\t", sm->table[i], sm->table[i + 1], nm, sqrt(pow(nm, 3.0) / nl), nl);
+    }
     fprintf(fh, "\n");
     if (!hdp) {
         for (int64_t i = 0; i < n_kmers * 2; i++) fprintf(fh, "%lf\t", 0.0);   /* eventExpectations: never updated */
@@ -231,17 +247,243 @@ static int load_strand_model(strand_model_t *sm, const char *model_path, const c
     int64_t n = 5;
     for (int i = 0; i < sm->k; i++) n *= sm->n_alpha;
     sm->table = malloc(sizeof(double) * (size_t) n);
+    sm->table_orig = malloc(sizeof(double) * (size_t) n);
     memcpy(sm->table, sa_model_table5(sm->model), sizeof(double) * (size_t) n);
+    memcpy(sm->table_orig, sm->table, sizeof(double) * (size_t) n);
     return SA_OK;
 }
 
+/* options shared by every read of a run */
+typedef struct {
+    int hdp, two_d, rna, expect_mode;
+    int64_t out_fmt, constraint_trim;
+    const char *fwd_ref, *bwd_ref;
+    sa_params_t p;
+    strand_model_t smt, smc;
+    const char *ambig[256];
+} run_t;
+
+/* one read: its inputs, the two alignment jobs, where its outputs go */
+typedef struct {
+    char *label, *npread_path, *cigar_path, *post_path, *post_path2, *seq_name, *t_expect, *c_expect;
+    sa_cigar_t *pA;
+    sa_npread_t *np;
+    char *forward_seq, *backward_seq;
+    const char *template_target, *complement_target;
+    int64_t t_lo, t_hi, c_lo, c_hi, r_shift_t, r_shift_c, n_guide;
+    int forward;
+    int64_t *ax[2], *ay[2];
+    sa_job_t jobs[2];
+    int failed;
+    char err[512];
+} read_t;
+
+/* single-read mode keeps the reference's abort-with-message behaviour; in batch mode a bad read is reported and skipped */
+static int fail(read_t *rd, int fatal, const char *fmt, const char *a) {
+    if (fatal) die(fmt, a);
+    snprintf(rd->err, sizeof(rd->err), fmt, a ? a : "");
+    rd->failed = 1;
+    return -1;
+}
+
+static int estimate_strand(const strand_model_t *sm, const int64_t *strand_map, double *events, int64_t n_events,
+                           const char *read, int64_t read_len, sa_strand_params_t *out) {
+    int64_t n = 5;
+    for (int i = 0; i < sm->k; i++) n *= sm->n_alpha;
+    double *scratch = malloc(sizeof(double) * (size_t) n); /* the estimation rescales the noise columns in place */
+    if (!scratch) return SA_ENOMEM;
+    memcpy(scratch, sm->table_orig, sizeof(double) * (size_t) n);
+    double est[7];
+    int rc = sa_estimate_params(sm->model, scratch, strand_map, events, n_events, read, read_len, est);
+    free(scratch);
+    if (rc != SA_OK) return rc;
+    out->scale = est[0]; out->shift = est[1]; out->var = est[2]; out->drift = est[3];
+    out->scale_sd = est[4]; out->var_sd = est[5]; out->shift_sd = est[6];
+    return SA_OK;
+}
+
+/* everything of impl/signalMachine.c:main between option parsing and performSignalAlignment, for one read */
+static int prepare_read(const run_t *R, read_t *rd, int fatal) {
+    if (rd->cigar_path == NULL) return fail(rd, fatal, "[signalMachine]ERROR: Need to provide input guide alignments, exiting", NULL);
+    if (sa_cigar_load(rd->cigar_path, &rd->pA) != SA_OK)
+        return fail(rd, fatal, "[signalMachine]ERROR: Didn't find input alignment file, looked %s", rd->cigar_path);
+    fprintf(stderr, "[signalMachine]NOTICE: Using guide alignments from %s\n", rd->cigar_path);
+    sa_cigar_t *pA = rd->pA;
+    if (rd->npread_path == NULL || sa_npread_load(rd->npread_path, &rd->np) != SA_OK)
+        return fail(rd, fatal, "signalMachine: could not load the nanopore read %s", rd->npread_path);
+    sa_npread_t *np = rd->np;
+    if (pA->start2 < 0 || pA->end2 <= pA->start2 || pA->end2 > (R->two_d ? np->read_length : np->template_read_length))
+        return fail(rd, fatal, "signalMachine: guide alignment of %s does not fit the read", rd->label);
+    if (R->rna) {
+        int64_t tmp = pA->start2;
+        pA->start2 = np->template_read_length - pA->end2;
+        pA->end2 = np->template_read_length - tmp;
+    }
+    const char *seq_name = rd->seq_name ? rd->seq_name : pA->contig1;
+    if (R->fwd_ref == NULL || seq_name == NULL)
+        return fail(rd, fatal, "[signalMachine] ERROR: need -f <fasta> and -n <sequence name>", NULL);
+
+    /* fastaHandler_ReferenceSequenceConstructFull, impl/fasta_handler.c:47-102 */
+    if (R->rna) { /* listReverse(pA->operationList) */
+        for (int64_t i = 0, j = pA->n_ops - 1; i < j; i++, j--) {
+            int32_t t = pA->op_type[i]; pA->op_type[i] = pA->op_type[j]; pA->op_type[j] = t;
+            int64_t l = pA->op_len[i]; pA->op_len[i] = pA->op_len[j]; pA->op_len[j] = l;
+        }
+    }
+    int ferr = 0;
+    rd->forward_seq = pA->strand1 ? sa_fasta_fetch(R->fwd_ref, seq_name, pA->start1, pA->end1 - 1, &ferr)
+                                  : sa_fasta_fetch(R->fwd_ref, seq_name, pA->end1, pA->start1 - 1, &ferr);
+    if (ferr == -2) {
+        fprintf(stderr, "[signalMachine] ERROR %d: sequence name: %s is not in reference fasta: %s \n", ferr, seq_name, R->fwd_ref);
+        if (fatal) exit(1);
+        return fail(rd, 0, "sequence name %s is not in the reference fasta", seq_name);
+    }
+    if (rd->forward_seq == NULL) return fail(rd, fatal, "[signalMachine] ERROR: Unable to fetch reference sequence.  ", NULL);
+    if (R->bwd_ref) {
+        rd->backward_seq = pA->strand1 ? sa_fasta_fetch(R->bwd_ref, seq_name, pA->start1, pA->end1 - 1, &ferr)
+                                       : sa_fasta_fetch(R->bwd_ref, seq_name, pA->end1, pA->start1 - 1, &ferr);
+        if (rd->backward_seq == NULL) return fail(rd, fatal, "[signalMachine] ERROR: Unable to fetch reference sequence.  ", NULL);
+        sa_reverse_in_place(rd->backward_seq);
+    } else {
+        rd->backward_seq = sa_complement(rd->forward_seq);
+        sa_reverse_in_place(rd->backward_seq);
+    }
+    int strand1 = pA->strand1;
+    if (R->rna) {
+        char *tmp = rd->backward_seq;
+        rd->backward_seq = strdup(rd->forward_seq);
+        sa_reverse_in_place(rd->backward_seq);
+        free(rd->forward_seq);
+        rd->forward_seq = tmp;
+        sa_reverse_in_place(rd->forward_seq);
+        int64_t t2 = pA->start1;
+        pA->start1 = pA->end1;
+        pA->end1 = t2;
+        pA->strand1 = !pA->strand1;
+        strand1 = pA->strand1;
+    }
+    rd->template_target = strand1 ? rd->forward_seq : rd->backward_seq;
+    rd->complement_target = strand1 ? rd->backward_seq : rd->forward_seq;
+
+    /* event slices and coordinate shifts (impl/signalMachine.c:726-750) */
+    const int64_t *t_map = R->two_d ? np->template_event_map : np->template_strand_event_map;
+    rd->t_lo = t_map[pA->start2];
+    rd->t_hi = t_map[pA->end2 - 1];
+    if (R->two_d) { rd->c_lo = np->complement_event_map[pA->start2]; rd->c_hi = np->complement_event_map[pA->end2 - 1]; }
+    rd->r_shift_t = pA->start1;
+    rd->r_shift_c = R->two_d ? pA->end1 : 0;
+    rd->forward = pA->strand1;
+
+    /* anchors from the guide alignment (pA is rebased inside, impl/signalMachineUtils.c:142-164) */
+    int64_t cap = 0;
+    for (int64_t i = 0; i < pA->n_ops; i++) cap += pA->op_len[i];
+    int64_t *gx = malloc(sizeof(int64_t) * (size_t) (cap + 1)), *gy = malloc(sizeof(int64_t) * (size_t) (cap + 1));
+    rd->n_guide = sa_guide_to_anchors(pA->start1, pA->end1, pA->strand1, pA->start2, pA->op_type, pA->op_len, pA->n_ops,
+                                      R->constraint_trim, gx, gy, cap + 1);
+    if (rd->n_guide < 0) { free(gx); free(gy); return fail(rd, fatal, "signalMachine: could not convert the guide alignment", NULL); }
+
+    /* per-strand: estimate the read's parameters (signalUtils_estimateNanoporeParams), build the job */
+    if (estimate_strand(&R->smt, np->template_strand_event_map, np->template_events, np->n_template_events,
+                        np->template_read, np->template_read_length, &np->template_params) != SA_OK) {
+        free(gx); free(gy);
+        return fail(rd, fatal, "Cannot get scale params with no assignments", NULL);
+    }
+    memset(rd->jobs, 0, sizeof(rd->jobs));
+    rd->ax[0] = malloc(sizeof(int64_t) * (size_t) (rd->n_guide + 1));
+    rd->ay[0] = malloc(sizeof(int64_t) * (size_t) (rd->n_guide + 1));
+    int64_t na0 = sa_remap_anchors(gx, gy, rd->n_guide, t_map, pA->start2, rd->ax[0], rd->ay[0]);
+    rd->jobs[0].ref = rd->template_target;
+    rd->jobs[0].ref_len = (int64_t) strlen(rd->template_target);
+    rd->jobs[0].events = np->template_events + 4 * rd->t_lo;
+    rd->jobs[0].event_stride = 4;
+    rd->jobs[0].n_events = rd->t_hi - rd->t_lo;
+    rd->jobs[0].anchor_x = rd->ax[0]; rd->jobs[0].anchor_y = rd->ay[0]; rd->jobs[0].n_anchors = na0;
+    rd->jobs[0].scale = np->template_params.scale; rd->jobs[0].shift = np->template_params.shift;
+    rd->jobs[0].var = np->template_params.var;
+    if (R->two_d) {
+        if (estimate_strand(&R->smc, np->complement_strand_event_map, np->complement_events, np->n_complement_events,
+                            np->complement_read, np->complement_read_length, &np->complement_params) != SA_OK) {
+            free(gx); free(gy);
+            return fail(rd, fatal, "Cannot get scale params with no assignments", NULL);
+        }
+        rd->ax[1] = malloc(sizeof(int64_t) * (size_t) (rd->n_guide + 1));
+        rd->ay[1] = malloc(sizeof(int64_t) * (size_t) (rd->n_guide + 1));
+        int64_t na1 = sa_remap_anchors(gx, gy, rd->n_guide, np->complement_event_map, pA->start2, rd->ax[1], rd->ay[1]);
+        rd->jobs[1].ref = rd->complement_target;
+        rd->jobs[1].ref_len = (int64_t) strlen(rd->complement_target);
+        rd->jobs[1].events = np->complement_events + 4 * rd->c_lo;
+        rd->jobs[1].event_stride = 4;
+        rd->jobs[1].n_events = rd->c_hi - rd->c_lo;
+        rd->jobs[1].anchor_x = rd->ax[1]; rd->jobs[1].anchor_y = rd->ay[1]; rd->jobs[1].n_anchors = na1;
+        rd->jobs[1].scale = np->complement_params.scale; rd->jobs[1].shift = np->complement_params.shift;
+        rd->jobs[1].var = np->complement_params.var;
+    }
+    free(gx);
+    free(gy);
+    return 0;
+}
+
+static void set_hdp_expected(strand_model_t *sm) { /* stateMachine3_setModelToHdpExpectedValues, once per run */
+    sa_model_set_to_hdp_expected_values(sm->model);
+    int64_t n = 5;
+    for (int i = 0; i < sm->k; i++) n *= sm->n_alpha;
+    const double *mt = sa_model_table5(sm->model);
+    for (int64_t i = 0; i < n; i += 5) { sm->table[i] = mt[i]; sm->table[i + 1] = mt[i + 1]; }
+}
+
+static char *dup_field(const char *s) { return (s == NULL || s[0] == 0 || strcmp(s, "-") == 0) ? NULL : strdup(s); }
+
+/* manifest of --batch: label, npRead, cigar, posteriors [, posteriors2, sequence_name, template expectations, complement expectations] */
+static int64_t load_manifest(const char *path, read_t **out) {
+    FILE *fh = fopen(path, "r");
+    if (!fh) return -1;
+    int64_t n = 0, cap = 0;
+    read_t *reads = NULL;
+    char *line = NULL;
+    size_t lcap = 0;
+    while (getline(&line, &lcap, fh) >= 0) {
+        size_t len = strlen(line);
+        while (len && (line[len - 1] == '\n' || line[len - 1] == '\r')) line[--len] = 0;
+        if (len == 0 || line[0] == '#') continue;
+        char *f[8] = {0};
+        int nf = 0;
+        for (char *tok = line; tok && nf < 8;) {
+            char *tab = strchr(tok, '\t');
+            if (tab) *tab = 0;
+            f[nf++] = tok;
+            tok = tab ? tab + 1 : NULL;
+        }
+        if (nf < 4) { fprintf(stderr, "[signalMachine] batch manifest: line with %d fields ignored (need at least 4)\n", nf); continue; }
+        if (n == cap) {
+            cap = cap ? cap * 2 : 64;
+            reads = realloc(reads, sizeof(read_t) * (size_t) cap);
+        }
+        read_t *rd = &reads[n++];
+        memset(rd, 0, sizeof(*rd));
+        rd->label = strdup(f[0]);
+        rd->npread_path = dup_field(f[1]);
+        rd->cigar_path = dup_field(f[2]);
+        rd->post_path = dup_field(f[3]);
+        rd->post_path2 = dup_field(f[4]);
+        rd->seq_name = dup_field(f[5]);
+        rd->t_expect = dup_field(f[6]);
+        rd->c_expect = dup_field(f[7]);
+    }
+    free(line);
+    fclose(fh);
+    *out = reads;
+    return n;
+}
+
 int main(int argc, char **argv) {
-    int hdp = 0, two_d = 0, rna = 0;
-    int64_t diag_expansion = 50, constraint_trim = 14, trace_back = 50, out_fmt = 0;
+    run_t R;
+    memset(&R, 0, sizeof(R));
+    int64_t diag_expansion = 50, trace_back = 50;
     double threshold = 0.01;
+    R.constraint_trim = 14;
     char *t_model = NULL, *c_model = NULL, *label = NULL, *npread_path = NULL, *cigar_path = NULL, *post_path = NULL;
     char *t_expect = NULL, *c_expect = NULL, *t_hdp = NULL, *c_hdp = NULL, *fwd_ref = NULL, *bwd_ref = NULL,
-         *post_path2 = NULL, *seq_name = NULL, *ambig_model = NULL;
+         *post_path2 = NULL, *seq_name = NULL, *ambig_model = NULL, *manifest = NULL;
     static struct option long_options[] = {{"help", no_argument, 0, 'h'},
                                            {"sm3Hdp", no_argument, 0, 'd'},
                                            {"sparse_output", no_argument, 0, 's'},
@@ -266,6 +508,7 @@ int main(int argc, char **argv) {
                                            {"traceBackDiagonals", optional_argument, 0, 'g'},
                                            {"posteriorProbsFile2", optional_argument, 0, 'i'},
                                            {"ambig_model", optional_argument, 0, 'a'},
+                                           {"batch", required_argument, 0, 1000},
                                            {0, 0, 0, 0}};
     for (;;) {
         int idx = 0;
@@ -273,11 +516,11 @@ int main(int argc, char **argv) {
         if (key == -1) break;
         switch (key) {
             case 'h': usage(); return 1;
-            case 's': if (optarg) sscanf(optarg, "%" SCNd64, &out_fmt); break;
-            case 'e': two_d = 1; break;
+            case 's': if (optarg) sscanf(optarg, "%" SCNd64, &R.out_fmt); break;
+            case 'e': R.two_d = 1; break;
             case 'a': ambig_model = optarg ? strdup(optarg) : NULL; break;
-            case 'r': rna = 1; break;
-            case 'd': hdp = 1; break;
+            case 'r': R.rna = 1; break;
+            case 'd': R.hdp = 1; break;
             case 'T': t_model = strdup(optarg); break;
             case 'C': c_model = strdup(optarg); break;
             case 'L': label = strdup(optarg); break;
@@ -290,247 +533,191 @@ int main(int argc, char **argv) {
             case 'w': c_hdp = strdup(optarg); break;
             case 'x': sscanf(optarg, "%" SCNd64, &diag_expansion); break;
             case 'D': sscanf(optarg, "%lf", &threshold); break;
-            case 'm': sscanf(optarg, "%" SCNd64, &constraint_trim); break;
+            case 'm': sscanf(optarg, "%" SCNd64, &R.constraint_trim); break;
             case 'f': fwd_ref = strdup(optarg); break;
             case 'b': bwd_ref = optarg ? strdup(optarg) : NULL; break;
             case 'n': seq_name = strdup(optarg); break;
             case 'g': if (optarg) sscanf(optarg, "%" SCNd64, &trace_back); break;
             case 'i': post_path2 = optarg ? strdup(optarg) : NULL; break;
+            case 1000: manifest = strdup(optarg); break;
             default: usage(); return 1;
         }
     }
     if (!label) label = strdup("");
-    if (t_model == NULL || (c_model == NULL && two_d)) die("Missing model files, exiting", NULL);
-    if (out_fmt == 3 && post_path2 == NULL) die("Must pass in posteriorProbsFile2 if using 'both' outFmt", NULL);
-    if (cigar_path == NULL) die("[signalMachine]ERROR: Need to provide input guide alignments, exiting", NULL);
-    sa_cigar_t *pA = NULL;
-    if (sa_cigar_load(cigar_path, &pA) != SA_OK)
-        die("[signalMachine]ERROR: Didn't find input alignment file, looked %s", cigar_path);
-    fprintf(stderr, "[signalMachine]NOTICE: Using guide alignments from %s\n", cigar_path);
-    const int expect_mode = t_expect != NULL || c_expect != NULL;
+    if (t_model == NULL || (c_model == NULL && R.two_d)) die("Missing model files, exiting", NULL);
+    if (R.out_fmt == 3 && post_path2 == NULL && manifest == NULL) die("Must pass in posteriorProbsFile2 if using 'both' outFmt", NULL);
+    if (cigar_path == NULL && manifest == NULL) die("[signalMachine]ERROR: Need to provide input guide alignments, exiting", NULL);
+    R.fwd_ref = fwd_ref;
+    R.bwd_ref = bwd_ref;
 
-    sa_params_t p;
-    p.threshold = threshold;
-    p.diagonal_expansion = diag_expansion % 2 == 0 ? diag_expansion : diag_expansion + 1;
-    p.trace_back_diagonals = trace_back;
-    p.min_diags_between_trace_back = 1000;
-    p.split_matrix_bigger_than_this = (int64_t) 3000 * 3000;
+    /* the reads of this run */
+    read_t *reads = NULL;
+    int64_t n_reads = 0;
+    const int batch_mode = manifest != NULL;
+    if (batch_mode) {
+        n_reads = load_manifest(manifest, &reads);
+        if (n_reads < 0) die("[signalMachine]ERROR: cannot read the batch manifest %s", manifest);
+        for (int64_t i = 0; i < n_reads; i++) {
+            if (reads[i].seq_name == NULL && seq_name != NULL) reads[i].seq_name = strdup(seq_name);
+            if (reads[i].t_expect != NULL || reads[i].c_expect != NULL) R.expect_mode = 1;
+        }
+        if (R.expect_mode)
+            for (int64_t i = 0; i < n_reads; i++)
+                if (reads[i].t_expect == NULL && reads[i].c_expect == NULL)
+                    die("[signalMachine]ERROR: batch manifest mixes expectation and alignment reads (%s)", reads[i].label);
+    } else {
+        reads = calloc(1, sizeof(read_t));
+        n_reads = 1;
+        reads[0].label = label; reads[0].npread_path = npread_path; reads[0].cigar_path = cigar_path;
+        reads[0].post_path = post_path; reads[0].post_path2 = post_path2; reads[0].seq_name = seq_name;
+        reads[0].t_expect = t_expect; reads[0].c_expect = c_expect;
+        R.expect_mode = t_expect != NULL || c_expect != NULL;
+        if (fwd_ref == NULL || seq_name == NULL) {
+            /* the reference needs -n; kept after the cigar check so that the error order matches (impl/signalMachine.c:642-663) */
+            sa_cigar_t *probe = NULL;
+            if (sa_cigar_load(cigar_path, &probe) != SA_OK)
+                die("[signalMachine]ERROR: Didn't find input alignment file, looked %s", cigar_path);
+            sa_cigar_free(probe);
+            die("[signalMachine] ERROR: need -f <fasta> and -n <sequence name>", NULL);
+        }
+    }
+
+    R.p.threshold = threshold;
+    R.p.diagonal_expansion = diag_expansion % 2 == 0 ? diag_expansion : diag_expansion + 1;
+    R.p.trace_back_diagonals = trace_back;
+    R.p.min_diags_between_trace_back = 1000;
+    R.p.split_matrix_bigger_than_this = (int64_t) 3000 * 3000;
 
     if (t_hdp != NULL || c_hdp != NULL) {
-        if (t_hdp == NULL || (c_hdp == NULL && two_d)) die("Need to have template and complement HDPs", NULL);
-        if (!hdp) {
-            hdp = 1;
+        if (t_hdp == NULL || (c_hdp == NULL && R.two_d)) die("Need to have template and complement HDPs", NULL);
+        if (!R.hdp) {
+            R.hdp = 1;
             fprintf(stderr, "[signalAlign] - Using threeStateHdp stateMachine since you pass in an HDP file\n");
         } else {
             fprintf(stderr, "[signalAlign] - using NanoporeHDPs\n");
         }
     }
-    if (hdp && t_hdp == NULL) die("signalAlign - ERROR: --sm3Hdp needs -v <template .nhdp>", NULL);
+    if (R.hdp && t_hdp == NULL) die("signalAlign - ERROR: --sm3Hdp needs -v <template .nhdp>", NULL);
 
-    strand_model_t smt, smc;
-    memset(&smt, 0, sizeof(smt));
-    memset(&smc, 0, sizeof(smc));
-    if (load_strand_model(&smt, t_model, hdp ? t_hdp : NULL) != SA_OK)
+    if (load_strand_model(&R.smt, t_model, R.hdp ? t_hdp : NULL) != SA_OK)
         die("signalAlign - ERROR: couldn't find model file here: %s", t_model);
-    if (two_d && load_strand_model(&smc, c_model, hdp ? c_hdp : NULL) != SA_OK)
+    if (R.two_d && load_strand_model(&R.smc, c_model, R.hdp ? c_hdp : NULL) != SA_OK)
         die("signalAlign - ERROR: couldn't find model file here: %s", c_model);
-
-    sa_npread_t *np = NULL;
-    if (npread_path == NULL || sa_npread_load(npread_path, &np) != SA_OK)
-        die("signalMachine: could not load the nanopore read %s", npread_path);
-    if (rna) {
-        int64_t tmp = pA->start2;
-        pA->start2 = np->template_read_length - pA->end2;
-        pA->end2 = np->template_read_length - tmp;
-    }
-    if (fwd_ref == NULL || seq_name == NULL) die("[signalMachine] ERROR: need -f <fasta> and -n <sequence name>", NULL);
-
-    /* fastaHandler_ReferenceSequenceConstructFull, impl/fasta_handler.c:47-102 */
-    if (rna) { /* listReverse(pA->operationList) */
-        for (int64_t i = 0, j = pA->n_ops - 1; i < j; i++, j--) {
-            int32_t t = pA->op_type[i]; pA->op_type[i] = pA->op_type[j]; pA->op_type[j] = t;
-            int64_t l = pA->op_len[i]; pA->op_len[i] = pA->op_len[j]; pA->op_len[j] = l;
-        }
-    }
-    int ferr = 0;
-    char *forward_seq = pA->strand1 ? sa_fasta_fetch(fwd_ref, seq_name, pA->start1, pA->end1 - 1, &ferr)
-                                    : sa_fasta_fetch(fwd_ref, seq_name, pA->end1, pA->start1 - 1, &ferr);
-    if (ferr == -2) {
-        fprintf(stderr, "[signalMachine] ERROR %d: sequence name: %s is not in reference fasta: %s \n", ferr, seq_name, fwd_ref);
-        return 1;
-    }
-    if (forward_seq == NULL) die("[signalMachine] ERROR: Unable to fetch reference sequence.  ", NULL);
-    char *backward_seq;
-    if (bwd_ref) {
-        backward_seq = pA->strand1 ? sa_fasta_fetch(bwd_ref, seq_name, pA->start1, pA->end1 - 1, &ferr)
-                                   : sa_fasta_fetch(bwd_ref, seq_name, pA->end1, pA->start1 - 1, &ferr);
-        if (backward_seq == NULL) die("[signalMachine] ERROR: Unable to fetch reference sequence.  ", NULL);
-        sa_reverse_in_place(backward_seq);
-    } else {
-        backward_seq = sa_complement(forward_seq);
-        sa_reverse_in_place(backward_seq);
-    }
-    int strand1 = pA->strand1;
-    if (rna) {
-        char *tmp = backward_seq;
-        backward_seq = strdup(forward_seq);
-        sa_reverse_in_place(backward_seq);
-        free(forward_seq);
-        forward_seq = tmp;
-        sa_reverse_in_place(forward_seq);
-        int64_t t2 = pA->start1;
-        pA->start1 = pA->end1;
-        pA->end1 = t2;
-        pA->strand1 = !pA->strand1;
-        strand1 = pA->strand1;
-    }
-    const char *template_target = strand1 ? forward_seq : backward_seq;
-    const char *complement_target = strand1 ? backward_seq : forward_seq;
-
-    /* event slices and coordinate shifts (impl/signalMachine.c:726-750) */
-    const int64_t *t_map = two_d ? np->template_event_map : np->template_strand_event_map;
-    int64_t t_lo = t_map[pA->start2], t_hi = t_map[pA->end2 - 1];
-    int64_t c_lo = 0, c_hi = 0;
-    if (two_d) { c_lo = np->complement_event_map[pA->start2]; c_hi = np->complement_event_map[pA->end2 - 1]; }
-    int64_t r_shift_t = pA->start1, r_shift_c = two_d ? pA->end1 : 0;
-    int forward = pA->strand1;
-
-    /* anchors from the guide alignment (pA is rebased inside, impl/signalMachineUtils.c:142-164) */
-    int64_t cap = 0;
-    for (int64_t i = 0; i < pA->n_ops; i++) cap += pA->op_len[i];
-    int64_t *gx = malloc(sizeof(int64_t) * (size_t) (cap + 1)), *gy = malloc(sizeof(int64_t) * (size_t) (cap + 1));
-    int64_t n_guide = sa_guide_to_anchors(pA->start1, pA->end1, pA->strand1, pA->start2, pA->op_type, pA->op_len,
-                                          pA->n_ops, constraint_trim, gx, gy, cap + 1);
-    if (n_guide < 0) die("signalMachine: could not convert the guide alignment", NULL);
-
-    const char *ambig[256];
     if (ambig_model) {
-        if (sa_load_ambig(ambig_model, ambig) != SA_OK) {
+        if (sa_load_ambig(ambig_model, R.ambig) != SA_OK) {
             printf("Couldn't open %s for reading\n", ambig_model);
             return 1;
         }
     } else {
-        sa_default_ambig(ambig);
+        sa_default_ambig(R.ambig);
     }
 
-    /* ---- per-strand work: estimate parameters, build the job ---- */
-    if (expect_mode) fprintf(stderr, "Starting expectations routine\n");
-    else fprintf(stderr, "signalAlign - starting template alignment\n");
-    double est[7];
-    if (sa_estimate_params(smt.model, smt.table, np->template_strand_event_map, np->template_events,
-                           np->n_template_events, np->template_read, np->template_read_length, est) != SA_OK)
-        die("Cannot get scale params with no assignments", NULL);
-    np->template_params.scale = est[0]; np->template_params.shift = est[1]; np->template_params.var = est[2];
-    np->template_params.drift = est[3]; np->template_params.scale_sd = est[4]; np->template_params.var_sd = est[5];
-    np->template_params.shift_sd = est[6];
-    if (hdp && !expect_mode) {
-        sa_model_set_to_hdp_expected_values(smt.model);
-        int64_t n = 5;
-        for (int i = 0; i < smt.k; i++) n *= smt.n_alpha;
-        const double *mt = sa_model_table5(smt.model);
-        for (int64_t i = 0; i < n; i += 5) { smt.table[i] = mt[i]; smt.table[i + 1] = mt[i + 1]; }
+    /* ---- host side of every read ---- */
+    int64_t n_ok = 0;
+    for (int64_t i = 0; i < n_reads; i++) {
+        if (prepare_read(&R, &reads[i], !batch_mode) == 0) n_ok++;
+        else fprintf(stderr, "[signalMachine] ERROR: read %s skipped: %s\n", reads[i].label, reads[i].err);
     }
-    sa_job_t jobs[2];
-    const strand_model_t *sms[2] = {&smt, &smc};
-    int n_jobs = 1;
-    int64_t *ax[2] = {NULL, NULL}, *ay[2] = {NULL, NULL};
-    ax[0] = malloc(sizeof(int64_t) * (size_t) (n_guide + 1));
-    ay[0] = malloc(sizeof(int64_t) * (size_t) (n_guide + 1));
-    int64_t na0 = sa_remap_anchors(gx, gy, n_guide, t_map, pA->start2, ax[0], ay[0]);
-    memset(jobs, 0, sizeof(jobs));
-    jobs[0].ref = template_target;
-    jobs[0].ref_len = (int64_t) strlen(template_target);
-    jobs[0].events = np->template_events + 4 * t_lo;
-    jobs[0].event_stride = 4;
-    jobs[0].n_events = t_hi - t_lo;
-    jobs[0].anchor_x = ax[0]; jobs[0].anchor_y = ay[0]; jobs[0].n_anchors = na0;
-    jobs[0].scale = np->template_params.scale; jobs[0].shift = np->template_params.shift; jobs[0].var = np->template_params.var;
-    if (two_d) {
-        if (sa_estimate_params(smc.model, smc.table, np->complement_strand_event_map, np->complement_events,
-                               np->n_complement_events, np->complement_read, np->complement_read_length, est) != SA_OK)
-            die("Cannot get scale params with no assignments", NULL);
-        np->complement_params.scale = est[0]; np->complement_params.shift = est[1]; np->complement_params.var = est[2];
-        np->complement_params.drift = est[3]; np->complement_params.scale_sd = est[4]; np->complement_params.var_sd = est[5];
-        np->complement_params.shift_sd = est[6];
-        if (hdp && !expect_mode) {
-            sa_model_set_to_hdp_expected_values(smc.model);
-            int64_t n = 5;
-            for (int i = 0; i < smc.k; i++) n *= smc.n_alpha;
-            const double *mt = sa_model_table5(smc.model);
-            for (int64_t i = 0; i < n; i += 5) { smc.table[i] = mt[i]; smc.table[i + 1] = mt[i + 1]; }
-        }
-        ax[1] = malloc(sizeof(int64_t) * (size_t) (n_guide + 1));
-        ay[1] = malloc(sizeof(int64_t) * (size_t) (n_guide + 1));
-        int64_t na1 = sa_remap_anchors(gx, gy, n_guide, np->complement_event_map, pA->start2, ax[1], ay[1]);
-        jobs[1].ref = complement_target;
-        jobs[1].ref_len = (int64_t) strlen(complement_target);
-        jobs[1].events = np->complement_events + 4 * c_lo;
-        jobs[1].event_stride = 4;
-        jobs[1].n_events = c_hi - c_lo;
-        jobs[1].anchor_x = ax[1]; jobs[1].anchor_y = ay[1]; jobs[1].n_anchors = na1;
-        jobs[1].scale = np->complement_params.scale; jobs[1].shift = np->complement_params.shift; jobs[1].var = np->complement_params.var;
-        n_jobs = 2;
+    if (R.hdp && !R.expect_mode) { /* the alignment branch sets the HDP expected values (impl/signalMachine.c:861-863), the expectation branch does not */
+        set_hdp_expected(&R.smt);
+        if (R.two_d) set_hdp_expected(&R.smc);
     }
+    const strand_model_t *sms[2] = {&R.smt, &R.smc};
+    const int n_strands = R.two_d ? 2 : 1;
 
-    if (expect_mode) { /* impl/signalMachine.c:772-848 */
-        const char *paths[2] = {t_expect, c_expect};
-        for (int s = 0; s < n_jobs; s++) {
+    /* ---- the pair-HMM on the GPU: one batch per strand model, all reads side by side ---- */
+    sa_job_t *bj = malloc(sizeof(sa_job_t) * (size_t) (n_ok > 0 ? n_ok : 1));
+    int64_t *who = malloc(sizeof(int64_t) * (size_t) (n_ok > 0 ? n_ok : 1));
+    int64_t k = 0;
+    for (int64_t i = 0; i < n_reads; i++)
+        if (!reads[i].failed) who[k++] = i;
+
+    if (R.expect_mode) { /* impl/signalMachine.c:772-848 */
+        if (n_ok > 0) fprintf(stderr, "Starting expectations routine\n");
+        for (int s = 0; s < n_strands && n_ok > 0; s++) {
             fprintf(stderr, "signalAlign - getting expectations for %s\n", s == 0 ? "template" : "complement");
-            double trans[9], lik = 0.0;
-            for (int i = 0; i < 9; i++) trans[i] = 0.001; /* transitionsPseudocount, :785 */
-            sa_assignment_t *as = NULL;
-            int64_t n_as = 0;
-            int rc = sa_expect_batch(sms[s]->model, &p, &jobs[s], 1, ambig, 0, 0, trans, &lik, &as, &n_as);
+            for (int64_t j = 0; j < n_ok; j++) bj[j] = reads[who[j]].jobs[s];
+            double *trans = malloc(sizeof(double) * 9 * (size_t) n_ok), *lik = calloc((size_t) n_ok, sizeof(double));
+            for (int64_t j = 0; j < 9 * n_ok; j++) trans[j] = 0.001; /* transitionsPseudocount, :785 */
+            sa_assignment_t **as = calloc((size_t) n_ok, sizeof(*as));
+            int64_t *n_as = calloc((size_t) n_ok, sizeof(int64_t));
+            int rc = sa_expect_batch(sms[s]->model, &R.p, bj, n_ok, R.ambig, 0, 0, trans, lik, as, n_as);
             if (rc != SA_OK) {
                 fprintf(stderr, "signalMachine: expectations failed: %s\n", sa_strerror(rc));
                 return 1;
             }
-            if (hdp)
-                fprintf(stderr, s == 0 ? "signalAlign - got %" PRId64 " template HDP assignments\n"
-                                       : "signalAlign - got %" PRId64 "complement HDP assignments\n", n_as);
-            if (paths[s] != NULL) {
-                fprintf(stderr, "signalAlign - writing expectations to file: %s\n", paths[s]);
-                write_expectations(paths[s], sms[s], hdp, trans, lik, &jobs[s], as, n_as);
+            for (int64_t j = 0; j < n_ok; j++) {
+                read_t *rd = &reads[who[j]];
+                const char *path = s == 0 ? rd->t_expect : rd->c_expect;
+                if (R.hdp)
+                    fprintf(stderr, s == 0 ? "signalAlign - got %" PRId64 " template HDP assignments\n"
+                                           : "signalAlign - got %" PRId64 "complement HDP assignments\n", n_as[j]);
+                if (path != NULL) {
+                    fprintf(stderr, "signalAlign - writing expectations to file: %s\n", path);
+                    write_expectations(path, sms[s], s == 0 ? &rd->np->template_params : &rd->np->complement_params, R.hdp,
+                                       trans + 9 * j, lik[j], &rd->jobs[s], as[j], n_as[j]);
+                }
+                sa_free(as[j]);
             }
-            sa_free(as);
+            free(trans); free(lik); free(as); free(n_as);
         }
-        fprintf(stderr, "signalAlign - SUCCESS: finished alignment of query %s, exiting\n", label);
-        return 0;
+        for (int64_t j = 0; j < n_ok; j++)
+            fprintf(stderr, "signalAlign - SUCCESS: finished alignment of query %s, exiting\n", reads[who[j]].label);
+        return n_ok == n_reads ? 0 : 1;
     }
 
-    /* ---- the pair-HMM on the GPU: one batch per strand model ---- */
-    sa_pair_t *pairs[2] = {NULL, NULL};
-    int64_t n_pairs[2] = {0, 0};
-    for (int s = 0; s < n_jobs; s++) {
-        if (s == 1) fprintf(stderr, "signalAlign - starting complement alignment\n");
-        int rc = sa_align_batch(sms[s]->model, &p, &jobs[s], 1, ambig, 0, 0, &pairs[s], &n_pairs[s]);
+    sa_pair_t **pairs[2] = {NULL, NULL};
+    int64_t *n_pairs[2] = {NULL, NULL};
+    for (int s = 0; s < n_strands; s++) {
+        pairs[s] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(sa_pair_t *));
+        n_pairs[s] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(int64_t));
+        if (n_ok == 0) continue;
+        fprintf(stderr, s == 0 ? "signalAlign - starting template alignment\n" : "signalAlign - starting complement alignment\n");
+        for (int64_t j = 0; j < n_ok; j++) bj[j] = reads[who[j]].jobs[s];
+        int rc = sa_align_batch(sms[s]->model, &R.p, bj, n_ok, R.ambig, 0, 0, pairs[s], n_pairs[s]);
         if (rc != SA_OK) {
             fprintf(stderr, "signalMachine: alignment failed: %s\n", sa_strerror(rc));
             return 1;
         }
     }
-    double score[2] = {0, 0};
-    for (int s = 0; s < n_jobs; s++) {
-        double tot = 0.0;
-        for (int64_t i = 0; i < n_pairs[s]; i++) tot += (double) pairs[s][i].prob_e7;
-        score[s] = 100.0 * tot / ((double) n_pairs[s] * PROB_1); /* scoreByPosteriorProbabilityIgnoringGaps :407-412 */
-    }
-    if (post_path != NULL) {
-        out_ctx_t o;
-        o.label = label; o.contig = pA->contig1; o.sm = &smt; o.npp = np->template_params; o.events = np->template_events;
-        o.target = template_target; o.forward = forward; o.is_template = 1; o.rna = rna; o.event_offset = t_lo;
-        o.ref_offset = r_shift_t; o.pairs = pairs[0]; o.n_pairs = n_pairs[0]; o.score = score[0];
-        output_alignment(out_fmt, post_path, post_path2, &o);
-        if (two_d) {
-            o.sm = &smc; o.npp = np->complement_params; o.events = np->complement_events; o.target = complement_target;
-            o.is_template = 0; o.event_offset = c_lo; o.ref_offset = r_shift_c; o.pairs = pairs[1];
-            o.n_pairs = n_pairs[1]; o.score = score[1];
-            output_alignment(out_fmt, post_path, post_path2, &o);
+
+    /* ---- outputs, read by read ---- */
+    for (int64_t j = 0; j < n_ok; j++) {
+        read_t *rd = &reads[who[j]];
+        if (R.out_fmt == 3 && rd->post_path2 == NULL) {
+            fprintf(stderr, "[signalMachine] ERROR: read %s: 'both' output format needs a second output file\n", rd->label);
+            rd->failed = 1;
+            continue;
         }
+        double score[2] = {0, 0};
+        for (int s = 0; s < n_strands; s++) {
+            double tot = 0.0;
+            for (int64_t i = 0; i < n_pairs[s][j]; i++) tot += (double) pairs[s][j][i].prob_e7;
+            score[s] = 100.0 * tot / ((double) n_pairs[s][j] * PROB_1); /* scoreByPosteriorProbabilityIgnoringGaps :407-412 */
+        }
+        if (rd->post_path != NULL) {
+            out_ctx_t o;
+            o.label = rd->label; o.contig = rd->pA->contig1; o.sm = &R.smt; o.npp = rd->np->template_params;
+            o.events = rd->np->template_events; o.target = rd->template_target; o.forward = rd->forward; o.is_template = 1;
+            o.rna = R.rna; o.event_offset = rd->t_lo; o.ref_offset = rd->r_shift_t; o.pairs = pairs[0][j];
+            o.n_pairs = n_pairs[0][j]; o.score = score[0];
+            output_alignment(R.out_fmt, rd->post_path, rd->post_path2, &o);
+            if (R.two_d) {
+                o.sm = &R.smc; o.npp = rd->np->complement_params; o.events = rd->np->complement_events;
+                o.target = rd->complement_target; o.is_template = 0; o.event_offset = rd->c_lo; o.ref_offset = rd->r_shift_c;
+                o.pairs = pairs[1][j]; o.n_pairs = n_pairs[1][j]; o.score = score[1];
+                output_alignment(R.out_fmt, rd->post_path, rd->post_path2, &o);
+            }
+        }
+        fprintf(stdout, "%s %" PRId64 "\t%" PRId64 "(%f)\t", rd->label, rd->n_guide, n_pairs[0][j], score[0]);
+        if (R.two_d) fprintf(stdout, "%" PRId64 "(%f)\n", n_pairs[1][j], score[1]);
+        else fprintf(stdout, "\n");
+        fprintf(stderr, "signalAlign - SUCCESS: finished alignment of query %s, exiting\n", rd->label);
+        for (int s = 0; s < n_strands; s++) sa_free(pairs[s][j]);
     }
-    fprintf(stdout, "%s %" PRId64 "\t%" PRId64 "(%f)\t", label, n_guide, n_pairs[0], score[0]);
-    if (two_d) fprintf(stdout, "%" PRId64 "(%f)\n", n_pairs[1], score[1]);
-    else fprintf(stdout, "\n");
-    fprintf(stderr, "signalAlign - SUCCESS: finished alignment of query %s, exiting\n", label);
-    return 0;
+    int64_t n_failed = 0;
+    for (int64_t i = 0; i < n_reads; i++) n_failed += reads[i].failed ? 1 : 0;
+    if (batch_mode)
+        fprintf(stderr, "[signalMachine] batch: %" PRId64 " of %" PRId64 " reads aligned\n", n_reads - n_failed, n_reads);
+    return n_failed == 0 ? 0 : 1;
 }

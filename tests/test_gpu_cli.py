@@ -188,3 +188,41 @@ def test_signalmachine_expectations_file(oracle, tmp_path):
     assert lines[3] == "0.000000\t" * (2 * n_kmers)
     assert lines[4] == "0.001000\t" * n_kmers
     assert lines[5] == "0\t" * n_kmers
+
+
+def test_signalmachine_batch_front_door(oracle, tmp_path):
+    # --batch: several reads in one process / one GPU batch; every read's files and log lines must be what single-read
+    # invocations produce
+    model = cases.MODEL_6MER
+    npread_path = os.path.join(cases.GOLDEN, "npReads", "r9p4_oneD.npRead")
+    r = oracle.parse_npread(npread_path)
+    read = r["template_read"]
+    fasta = str(tmp_path / "ref.fa")
+    _write_fasta(fasta, "chrB", "ACGTTGCA" * 20 + read + "GATTACA" * 10)
+    specs = [("readA", 0, len(read) - 30), ("readB", 400, 1500), ("readC", 2000, 2500)]
+    single_out, manifest_rows = {}, []
+    common = ["-T", model, "-f", fasta, "-n", "chrB", "-g", "100", "-x", "50", "-D", "0.01", "-m", "14"]
+    for name, start, L in specs:
+        cigar = str(tmp_path / (name + ".cigar"))
+        with open(cigar, "w") as f:
+            f.write("cigar: %s %d %d + chrB %d %d + 1 M %d\n" % (name, start, start + L, 160 + start, 160 + start + L, L))
+        out1 = str(tmp_path / (name + ".single.tsv"))
+        pr = subprocess.run([BIN] + common + ["-q", npread_path, "-p", cigar, "-u", out1, "-L", name],
+                            capture_output=True, text=True, timeout=300)
+        assert pr.returncode == 0, pr.stderr
+        single_out[name] = (open(out1).read(), pr.stdout)
+        manifest_rows.append("\t".join([name, npread_path, cigar, str(tmp_path / (name + ".batch.tsv"))]))
+    manifest_rows.insert(1, "# a comment line")
+    manifest_rows.append("\t".join(["broken", str(tmp_path / "missing.npRead"), str(tmp_path / "readA.cigar"),
+                                    str(tmp_path / "broken.tsv")]))
+    manifest = str(tmp_path / "manifest.tsv")
+    with open(manifest, "w") as f:
+        f.write("\n".join(manifest_rows) + "\n")
+    pr = subprocess.run([BIN] + common + ["--batch", manifest], capture_output=True, text=True, timeout=600)
+    assert pr.returncode == 1  # one read of the manifest is broken; the others are done
+    assert "read broken skipped" in pr.stderr and "3 of 4 reads aligned" in pr.stderr
+    for name, _, _ in specs:
+        assert open(str(tmp_path / (name + ".batch.tsv"))).read() == single_out[name][0], name
+        assert single_out[name][1] in pr.stdout
+        assert "signalAlign - SUCCESS: finished alignment of query %s, exiting" % name in pr.stderr
+    assert not os.path.exists(str(tmp_path / "broken.tsv"))
