@@ -167,6 +167,12 @@ int sa_plan_describe(const sa_model_t *m, const sa_params_t *p, const sa_job_t *
                      int64_t *rows3_out, int64_t rows_cap,         /* region,xmyL,xmyR per diagonal      */
                      int64_t *segs4_out, int64_t segs_cap);        /* region,start,from,to per traceback */
 
+/* Plans a whole batch on the host (no GPU needed) with `threads` planner threads (0 = as sa_batch_create would) and
+ * returns aggregate geometry plus a 64-bit FNV-1a digest over every array that would be uploaded.  The digest must
+ * not depend on the number of threads: the CPU test-suite checks exactly that. */
+int sa_plan_digest(const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs, int64_t n_jobs,
+                   const char *const *ambig256, unsigned flags, int threads, sa_plan_info_t *info, uint64_t *digest);
+
 /* ---- host-side helpers that signalMachine needs around the seam --------------------------------- */
 /* signalUtils_guideAlignmentToRebasedAnchorPairs (impl/signalMachineUtils.c:142-164). op types:
  * 0 = match, 1 = reference-only (PAIRWISE_INDEL_X), 2 = read-only (PAIRWISE_INDEL_Y). */

@@ -61,7 +61,7 @@ PAIR_DTYPE = np.dtype([("prob_e7", "<i8"), ("x", "<i4"), ("y", "<i4"), ("path", 
 EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alphabet", "sa_model_table5",
            "sa_model_set_to_hdp_expected_values", "sa_kmer_id", "sa_default_ambig", "sa_load_ambig",
            "sa_batch_create", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_stats",
-           "sa_batch_job_cells", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_plan_describe",
+           "sa_batch_job_cells", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_plan_describe", "sa_plan_digest",
            "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_device_count", "sa_strerror",
            "sa_version", "sa_free"]
 
@@ -115,6 +115,8 @@ def lib():
     L.sa_batch_destroy.argtypes = [C.c_void_p]
     L.sa_plan_describe.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Job), C.POINTER(C.c_char_p), C.c_uint,
                                    C.POINTER(PlanInfo), ip, C.c_int64, ip, C.c_int64, ip, C.c_int64]
+    L.sa_plan_digest.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Job), C.c_int64, C.POINTER(C.c_char_p), C.c_uint,
+                                 C.c_int, C.POINTER(PlanInfo), C.POINTER(C.c_uint64)]
     L.sa_guide_to_anchors.restype = C.c_int64
     L.sa_guide_to_anchors.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int64, C.POINTER(C.c_int32), ip, C.c_int64,
                                       C.c_int64, ip, ip, C.c_int64]
@@ -313,6 +315,17 @@ def plan_describe(model, params, job, ambig=None, flags=0):
     for r in reg:
         nrow += (r[2] - r[0]) + (r[3] - r[1]) + 1
     return info, reg, rows[:3 * nrow].reshape(-1, 3), segs[:4 * info.n_segments].reshape(-1, 4)
+
+
+def plan_digest(model, params, jobs, ambig=None, flags=0, threads=0):
+    """Host-only: plan a batch with `threads` planner threads; returns (PlanInfo, digest of everything uploaded)."""
+    arr, keep = _make_jobs(jobs)
+    amb = ambig if ambig is not None else default_ambig()
+    info, dig = PlanInfo(), C.c_uint64()
+    _chk(lib().sa_plan_digest(model._h, C.byref(params), arr, len(jobs), amb, flags, threads, C.byref(info), C.byref(dig)),
+         "sa_plan_digest")
+    del keep
+    return info, dig.value
 
 
 def guide_to_anchors(start1, end1, strand1, start2, ops, trim):

@@ -832,9 +832,13 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     const char *envb = getenv("SA_F_BUDGET_CELLPATHS");  // test hook: force several passes
     if (envb && atoll(envb) > 0) budget = atoll(envb);
 
+    const bool trace_c = getenv("SA_TRACE") != nullptr;
+    auto now_ms_c = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double tc0 = now_ms_c();
     sa_plan_t *pl = nullptr;
     int rc = sa_plan_build(&pl, m, p, jobs, n_jobs, ambig, flags, budget);
     if (rc) return rc;
+    if (trace_c) fprintf(stderr, "[trace] create: planned at %.1f ms\n", now_ms_c() - tc0);
     sa_batch *b = new sa_batch();
     b->plan = pl;
     b->device = device;
@@ -912,6 +916,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
             TRY(upload(&b->d_hdp_grid, h->grid, h->grid_length));
         }
     }
+    if (trace_c) fprintf(stderr, "[trace] create: inputs uploaded at %.1f ms\n", now_ms_c() - tc0);
     // working buffers
     auto dalloc = [&](void **p_, long long bytes) -> int {
         HIPCHK(hipMalloc(p_, (size_t) (bytes > 0 ? bytes : 8)));
@@ -1024,6 +1029,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
         }
     }
     TRY(upload(&b->d_ids, b->ids_flat.data(), (long long) b->ids_flat.size()));
+    if (trace_c) fprintf(stderr, "[trace] create: buffers allocated at %.1f ms\n", now_ms_c() - tc0);
     b->stats.cells_forward = pl->cells_fwd;
     b->stats.cells_backward = pl->cells_bwd;
     b->stats.n_regions = pl->n_regions;

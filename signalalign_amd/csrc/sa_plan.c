@@ -19,9 +19,11 @@
  */
 #define _GNU_SOURCE
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "sa_internal.h"
 
@@ -534,7 +536,7 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
             ck->nB = e < S->start ? rows[e + 1].width : 0;
             pl->n_vbuf += ck->nA + ck->nB;
         }
-        int64_t cap = 4 * (S->from - S->to) + 64;
+        int64_t cap = 2 * (S->from - S->to) + 64; /* measured: 0.54 pairs per diagonal at threshold 0.01; overflow re-runs with 4x */
         if (p->threshold <= 0.0) { /* everything passes: every cell-path of the posterior diagonals */
             cap = 64;
             for (int64_t e = S->to + 1; e <= S->from; e++) {
@@ -606,6 +608,114 @@ static int fill_xc(sa_plan_t *pl) {
     return SA_OK;
 }
 
+/* plans job jb as job number j of pl (appends its regions, rows, segments ... to pl's arrays) */
+static int plan_job(sa_plan_t *pl, int64_t j, const sa_job_t *jb, const char *const *ambig) {
+    const sa_model_t *m = pl->model;
+    const sa_params_t *p = &pl->params;
+    if (!jb->ref || jb->ref_len < 0 || jb->n_events < 0 || jb->n_anchors < 0 || (jb->n_events && !jb->events) ||
+        (jb->n_anchors && (!jb->anchor_x || !jb->anchor_y)) || !(jb->var > 0.0))
+        return SA_EINVAL;
+    int64_t lX = jb->ref_len == 0 ? 0 : jb->ref_len - (m->k - 1); /* sequence_correctSeqLength */
+    if (lX < 0) lX = 0;
+    int64_t lY = jb->n_events;
+    for (int64_t i = 0; i < jb->n_anchors; i++)
+        if (jb->anchor_x[i] < 0 || jb->anchor_y[i] < 0 || jb->anchor_x[i] >= lX || jb->anchor_y[i] >= lY ||
+            (i > 0 && (jb->anchor_x[i] <= jb->anchor_x[i - 1] || jb->anchor_y[i] <= jb->anchor_y[i - 1])))
+            return SA_EBAND;
+    /* events: keep only the mean column */
+    if (pl->n_ev + lY + 1 > pl->cap_ev) {
+        int64_t nc = pl->cap_ev ? pl->cap_ev * 2 : 4096;
+        while (nc < pl->n_ev + lY + 1) nc *= 2;
+        void *np_ = realloc(pl->ev, sizeof(double) * (size_t) nc);
+        if (!np_) return SA_ENOMEM;
+        pl->ev = np_;
+        pl->cap_ev = nc;
+    }
+    pl->jobs[j].ev_off = pl->n_ev;
+    pl->jobs[j].n_events = lY;
+    int64_t st = jb->event_stride > 0 ? jb->event_stride : 1;
+    for (int64_t i = 0; i < lY; i++) pl->ev[pl->n_ev + i] = jb->events[i * st];
+    pl->n_ev += lY;
+    pl->jobs[j].region_off = pl->n_regions;
+
+    rect_t *rects = malloc(sizeof(rect_t) * (size_t) (jb->n_anchors + 2));
+    int64_t *sx = malloc(sizeof(int64_t) * (size_t) (jb->n_anchors + 1));
+    int64_t *sy = malloc(sizeof(int64_t) * (size_t) (jb->n_anchors + 1));
+    if (!rects || !sx || !sy) {
+        free(rects); free(sx); free(sy);
+        return SA_ENOMEM;
+    }
+    /* signalMachine always calls with ragged left and right ends (impl/signalMachine.c:436-437) */
+    int64_t nr = split_regions(jb->anchor_x, jb->anchor_y, jb->n_anchors, lX, lY, p->split_matrix_bigger_than_this, 1, 1,
+                               rects);
+    int rc = SA_OK;
+    int64_t a = 0;
+    for (int64_t i = 0; i < nr && rc == SA_OK; i++) {
+        int64_t a0 = a;
+        while (a < jb->n_anchors && jb->anchor_x[a] + jb->anchor_y[a] < rects[i].x2 + rects[i].y2) a++;
+        for (int64_t t = a0; t < a; t++) {
+            sx[t - a0] = jb->anchor_x[t] - rects[i].x1;
+            sy[t - a0] = jb->anchor_y[t] - rects[i].y1;
+        }
+        rc = add_region(pl, j, jb, rects[i], sx, sy, a - a0, 1, 1, ambig, pl->jobs[j].ev_off);
+    }
+    free(rects); free(sx); free(sy);
+    pl->jobs[j].n_regions = (int32_t) (pl->n_regions - pl->jobs[j].region_off);
+    return rc;
+}
+
+static sa_plan_t *plan_new(const sa_model_t *m, const sa_params_t *p, unsigned flags, int64_t n_jobs) {
+    sa_plan_t *pl = calloc(1, sizeof(*pl));
+    if (!pl) return NULL;
+    pl->model = m;
+    pl->params = *p;
+    pl->flags = flags;
+    pl->n_jobs = n_jobs;
+    pl->jobs = calloc(n_jobs > 0 ? n_jobs : 1, sizeof(sa_jobinfo_t));
+    if (!pl->jobs) { free(pl); return NULL; }
+    return pl;
+}
+
+/* planning is integer work per read and the reads are independent: worker t plans a contiguous range of jobs into
+ * a plan of its own, the ranges are then concatenated (every cross-array offset shifts by what precedes the range) */
+typedef struct {
+    sa_plan_t *pl;
+    const sa_job_t *jobs;
+    int64_t n;
+    const char *const *ambig;
+    int rc;
+} plan_worker_t;
+
+static void *plan_worker(void *arg) {
+    plan_worker_t *w = arg;
+    w->rc = SA_OK;
+    for (int64_t j = 0; j < w->n && w->rc == SA_OK; j++) w->rc = plan_job(w->pl, j, &w->jobs[j], w->ambig);
+    if (w->rc == SA_OK) w->rc = fill_xc(w->pl);
+    return NULL;
+}
+
+#define CAT(dst, field, count, type)                                                                    \
+    do {                                                                                                \
+        int64_t tot_ = 0;                                                                               \
+        for (int t_ = 0; t_ < T; t_++) tot_ += W[t_].pl->count;                                         \
+        dst->field = malloc(sizeof(type) * (size_t) (tot_ > 0 ? tot_ : 1));                             \
+        if (!dst->field) { rc = SA_ENOMEM; break; }                                                     \
+        int64_t o_ = 0;                                                                                 \
+        for (int t_ = 0; t_ < T; t_++) {                                                                \
+            if (W[t_].pl->count) memcpy(dst->field + o_, W[t_].pl->field, sizeof(type) * (size_t) W[t_].pl->count); \
+            o_ += W[t_].pl->count;                                                                      \
+        }                                                                                               \
+    } while (0)
+
+static __thread int plan_threads_override = 0; /* sa_plan_digest */
+static int plan_threads(int64_t n_jobs) {
+    const char *e = getenv("SA_PLAN_THREADS");
+    long t = plan_threads_override > 0 ? plan_threads_override : (e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN));
+    if (t > 32) t = 32;
+    if (t > n_jobs / 4) t = n_jobs / 4; /* a handful of reads is not worth a thread */
+    return t < 1 ? 1 : (int) t;
+}
+
 int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs, int64_t n_jobs,
                   const char *const *ambig, unsigned flags, int64_t chunk_budget) {
     if (!out || !m || !p || (!jobs && n_jobs > 0) || n_jobs < 0) return SA_EINVAL;
@@ -613,72 +723,114 @@ int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, co
         p->min_diags_between_trace_back < 2 || p->trace_back_diagonals + 1 >= p->min_diags_between_trace_back ||
         !(p->threshold >= 0.0 && p->threshold <= 1.0))
         return SA_EINVAL; /* the asserts of impl/pairwiseAligner.c:1460-1464, :1358-1359 */
-    sa_plan_t *pl = calloc(1, sizeof(*pl));
-    if (!pl) return SA_ENOMEM;
-    pl->model = m;
-    pl->params = *p;
-    pl->flags = flags;
-    pl->n_jobs = n_jobs;
-    pl->jobs = calloc(n_jobs > 0 ? n_jobs : 1, sizeof(sa_jobinfo_t));
+    const int T = plan_threads(n_jobs);
+    sa_plan_t *pl = NULL;
     int rc = SA_OK;
-    for (int64_t j = 0; j < n_jobs && rc == SA_OK; j++) {
-        const sa_job_t *jb = &jobs[j];
-        if (!jb->ref || jb->ref_len < 0 || jb->n_events < 0 || jb->n_anchors < 0 || (jb->n_events && !jb->events) ||
-            (jb->n_anchors && (!jb->anchor_x || !jb->anchor_y)) || !(jb->var > 0.0)) {
-            rc = SA_EINVAL;
-            break;
-        }
-        int64_t lX = jb->ref_len == 0 ? 0 : jb->ref_len - (m->k - 1); /* sequence_correctSeqLength */
-        if (lX < 0) lX = 0;
-        int64_t lY = jb->n_events;
-        for (int64_t i = 0; i < jb->n_anchors; i++)
-            if (jb->anchor_x[i] < 0 || jb->anchor_y[i] < 0 || jb->anchor_x[i] >= lX || jb->anchor_y[i] >= lY ||
-                (i > 0 && (jb->anchor_x[i] <= jb->anchor_x[i - 1] || jb->anchor_y[i] <= jb->anchor_y[i - 1]))) {
-                rc = SA_EBAND;
-                break;
+    if (T == 1) {
+        pl = plan_new(m, p, flags, n_jobs);
+        if (!pl) return SA_ENOMEM;
+        plan_worker_t w = {pl, jobs, n_jobs, ambig, SA_OK};
+        plan_worker(&w);
+        rc = w.rc;
+    } else {
+        /* contiguous ranges balanced by events (planning cost ~ diagonals ~ events) */
+        plan_worker_t *W = calloc((size_t) T, sizeof(*W));
+        pthread_t *th = calloc((size_t) T, sizeof(*th));
+        int *started = calloc((size_t) T, sizeof(int));
+        if (!W || !th || !started) { free(W); free(th); free(started); return SA_ENOMEM; }
+        double total = 0, acc = 0;
+        for (int64_t j = 0; j < n_jobs; j++) total += (double) (jobs[j].n_events > 0 ? jobs[j].n_events : 0) + 64.0;
+        int64_t j = 0;
+        for (int t = 0; t < T; t++) {
+            int64_t j0 = j;
+            double target = total * (double) (t + 1) / (double) T;
+            while (j < n_jobs && (t == T - 1 || acc < target)) {
+                acc += (double) (jobs[j].n_events > 0 ? jobs[j].n_events : 0) + 64.0;
+                j++;
             }
-        if (rc) break;
-        /* events: keep only the mean column */
-        if (pl->n_ev + lY + 1 > pl->cap_ev) {
-            int64_t nc = pl->cap_ev ? pl->cap_ev * 2 : 4096;
-            while (nc < pl->n_ev + lY + 1) nc *= 2;
-            void *np_ = realloc(pl->ev, sizeof(double) * (size_t) nc);
-            if (!np_) { rc = SA_ENOMEM; break; }
-            pl->ev = np_;
-            pl->cap_ev = nc;
+            W[t].jobs = jobs + j0;
+            W[t].n = j - j0;
+            W[t].ambig = ambig;
+            W[t].pl = plan_new(m, p, flags, W[t].n);
+            if (!W[t].pl) rc = SA_ENOMEM;
         }
-        pl->jobs[j].ev_off = pl->n_ev;
-        pl->jobs[j].n_events = lY;
-        int64_t st = jb->event_stride > 0 ? jb->event_stride : 1;
-        for (int64_t i = 0; i < lY; i++) pl->ev[pl->n_ev + i] = jb->events[i * st];
-        pl->n_ev += lY;
-        pl->jobs[j].region_off = pl->n_regions;
-
-        rect_t *rects = malloc(sizeof(rect_t) * (size_t) (jb->n_anchors + 2));
-        int64_t *sx = malloc(sizeof(int64_t) * (size_t) (jb->n_anchors + 1));
-        int64_t *sy = malloc(sizeof(int64_t) * (size_t) (jb->n_anchors + 1));
-        if (!rects || !sx || !sy) {
-            free(rects); free(sx); free(sy);
-            rc = SA_ENOMEM;
-            break;
+        for (int t = 0; t < T && rc == SA_OK; t++) {
+            if (pthread_create(&th[t], NULL, plan_worker, &W[t]) == 0) started[t] = 1;
+            else plan_worker(&W[t]); /* no thread to be had: do it here */
         }
-        /* signalMachine always calls with ragged left and right ends (impl/signalMachine.c:436-437) */
-        int64_t nr = split_regions(jb->anchor_x, jb->anchor_y, jb->n_anchors, lX, lY, p->split_matrix_bigger_than_this,
-                                   1, 1, rects);
-        int64_t a = 0;
-        for (int64_t i = 0; i < nr && rc == SA_OK; i++) {
-            int64_t a0 = a;
-            while (a < jb->n_anchors && jb->anchor_x[a] + jb->anchor_y[a] < rects[i].x2 + rects[i].y2) a++;
-            for (int64_t t = a0; t < a; t++) {
-                sx[t - a0] = jb->anchor_x[t] - rects[i].x1;
-                sy[t - a0] = jb->anchor_y[t] - rects[i].y1;
+        for (int t = 0; t < T; t++)
+            if (started[t]) pthread_join(th[t], NULL);
+        for (int t = 0; t < T && rc == SA_OK; t++) rc = W[t].rc; /* the first failing job in job order decides */
+        if (rc == SA_OK) {
+            pl = plan_new(m, p, flags, n_jobs);
+            if (!pl) rc = SA_ENOMEM;
+        }
+        if (rc == SA_OK) {
+            free(pl->jobs);
+            pl->jobs = NULL;
+            do {
+                CAT(pl, jobs, n_jobs, sa_jobinfo_t);
+                CAT(pl, regions, n_regions, sa_region_t);
+                CAT(pl, rows, n_rows, sa_row_t);
+                CAT(pl, pk, n_pk, int32_t);
+                CAT(pl, poff, n_poff, int32_t);
+                CAT(pl, pid, n_pid, int32_t);
+                CAT(pl, ev, n_ev, double);
+                CAT(pl, segs, n_segs, sa_seg_t);
+                CAT(pl, cks, n_cks, sa_ck_t);
+                {   /* xc: four doubles per pid entry */
+                    int64_t tot = 0;
+                    for (int t = 0; t < T; t++) tot += W[t].pl->n_pid;
+                    pl->xc = malloc(sizeof(double) * 4 * (size_t) (tot > 0 ? tot : 1));
+                    if (!pl->xc) { rc = SA_ENOMEM; break; }
+                    int64_t o = 0;
+                    for (int t = 0; t < T; t++) {
+                        if (W[t].pl->n_pid) memcpy(pl->xc + 4 * o, W[t].pl->xc, sizeof(double) * 4 * (size_t) W[t].pl->n_pid);
+                        o += W[t].pl->n_pid;
+                    }
+                }
+            } while (0);
+        }
+        if (rc == SA_OK) {
+            sa_plan_t b; /* running bases */
+            memset(&b, 0, sizeof(b));
+            int64_t job_base = 0;
+            for (int t = 0; t < T; t++) {
+                const sa_plan_t *s = W[t].pl;
+                for (int64_t i = 0; i < s->n_jobs; i++) {
+                    sa_jobinfo_t *J = &pl->jobs[job_base + i];
+                    J->region_off += b.n_regions;
+                    J->ev_off += b.n_ev;
+                }
+                for (int64_t i = 0; i < s->n_regions; i++) {
+                    sa_region_t *R = &pl->regions[b.n_regions + i];
+                    R->job += (int32_t) job_base;
+                    R->row_off += b.n_rows; R->pk_off += b.n_pk; R->poff_off += b.n_poff; R->pid_off += b.n_pid;
+                    R->ev_off += b.n_ev; R->seg_off += b.n_segs;
+                }
+                for (int64_t i = 0; i < s->n_segs; i++) {
+                    sa_seg_t *S = &pl->segs[b.n_segs + i];
+                    S->region += (int32_t) b.n_regions;
+                    S->ck_base += b.n_cks; S->cand_off += b.n_cand; S->bscratch_off += b.n_bscratch;
+                }
+                for (int64_t i = 0; i < s->n_cks; i++) pl->cks[b.n_cks + i].voff += b.n_vbuf;
+                job_base += s->n_jobs;
+                b.n_regions += s->n_regions; b.n_rows += s->n_rows; b.n_pk += s->n_pk; b.n_poff += s->n_poff;
+                b.n_pid += s->n_pid; b.n_ev += s->n_ev; b.n_segs += s->n_segs; b.n_cks += s->n_cks;
+                b.n_vbuf += s->n_vbuf; b.n_cand += s->n_cand; b.n_bscratch += s->n_bscratch;
+                b.cells_fwd += s->cells_fwd; b.cells_bwd += s->cells_bwd; b.n_fast_regions += s->n_fast_regions;
+                if (s->max_span > b.max_span) b.max_span = s->max_span;
             }
-            rc = add_region(pl, j, jb, rects[i], sx, sy, a - a0, 1, 1, ambig, pl->jobs[j].ev_off);
+            pl->n_regions = pl->cap_regions = b.n_regions; pl->n_rows = pl->cap_rows = b.n_rows;
+            pl->n_pk = pl->cap_pk = b.n_pk; pl->n_poff = pl->cap_poff = b.n_poff; pl->n_pid = pl->cap_pid = b.n_pid;
+            pl->n_ev = pl->cap_ev = b.n_ev; pl->n_segs = pl->cap_segs = b.n_segs; pl->n_cks = pl->cap_cks = b.n_cks;
+            pl->n_vbuf = b.n_vbuf; pl->n_cand = b.n_cand; pl->n_bscratch = b.n_bscratch;
+            pl->cells_fwd = b.cells_fwd; pl->cells_bwd = b.cells_bwd; pl->n_fast_regions = b.n_fast_regions;
+            pl->max_span = b.max_span;
         }
-        free(rects); free(sx); free(sy);
-        pl->jobs[j].n_regions = (int32_t) (pl->n_regions - pl->jobs[j].region_off);
+        for (int t = 0; t < T; t++) sa_plan_free(W[t].pl);
+        free(W); free(th); free(started);
     }
-    if (rc == SA_OK) rc = fill_xc(pl);
     if (rc != SA_OK) {
         sa_plan_free(pl);
         return rc;
@@ -804,6 +956,52 @@ int sa_plan_describe(const sa_model_t *m, const sa_params_t *p, const sa_job_t *
             segs4[4 * s] = pl->segs[s].region; segs4[4 * s + 1] = pl->segs[s].start;
             segs4[4 * s + 2] = pl->segs[s].from; segs4[4 * s + 3] = pl->segs[s].to;
         }
+    sa_plan_free(pl);
+    return SA_OK;
+}
+
+static uint64_t fnv1a(uint64_t h, const void *data, size_t n) {
+    const unsigned char *b = data;
+    for (size_t i = 0; i < n; i++) {
+        h ^= b[i];
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+int sa_plan_digest(const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs, int64_t n_jobs,
+                   const char *const *ambig, unsigned flags, int threads, sa_plan_info_t *info, uint64_t *digest) {
+    sa_plan_t *pl = NULL;
+    plan_threads_override = threads;
+    int rc = sa_plan_build(&pl, m, p, jobs, n_jobs, ambig, flags, 0);
+    plan_threads_override = 0;
+    if (rc) return rc;
+    if (info) {
+        info->n_regions = pl->n_regions;
+        info->n_segments = pl->n_segs;
+        info->n_checkpoints = pl->n_cks;
+        info->cells_forward = pl->cells_fwd;
+        info->cells_backward = pl->cells_bwd;
+        info->f_cellpaths = pl->max_chunk_cellpaths;
+        info->max_span = pl->max_span;
+        info->n_fast_regions = pl->n_fast_regions;
+    }
+    if (digest) {
+        uint64_t h = 1469598103934665603ull;
+        h = fnv1a(h, pl->jobs, sizeof(sa_jobinfo_t) * (size_t) pl->n_jobs);
+        h = fnv1a(h, pl->regions, sizeof(sa_region_t) * (size_t) pl->n_regions);
+        h = fnv1a(h, pl->rows, sizeof(sa_row_t) * (size_t) pl->n_rows);
+        h = fnv1a(h, pl->pk, sizeof(int32_t) * (size_t) pl->n_pk);
+        h = fnv1a(h, pl->poff, sizeof(int32_t) * (size_t) pl->n_poff);
+        h = fnv1a(h, pl->pid, sizeof(int32_t) * (size_t) pl->n_pid);
+        h = fnv1a(h, pl->xc, sizeof(double) * 4 * (size_t) pl->n_pid);
+        h = fnv1a(h, pl->ev, sizeof(double) * (size_t) pl->n_ev);
+        h = fnv1a(h, pl->segs, sizeof(sa_seg_t) * (size_t) pl->n_segs);
+        h = fnv1a(h, pl->cks, sizeof(sa_ck_t) * (size_t) pl->n_cks);
+        int64_t tail[4] = {pl->n_vbuf, pl->n_cand, pl->n_bscratch, pl->n_chunks};
+        h = fnv1a(h, tail, sizeof(tail));
+        *digest = h;
+    }
     sa_plan_free(pl);
     return SA_OK;
 }

@@ -143,3 +143,29 @@ def test_estimate_params_matches_oracle(oracle, name, model):
     assert got == exp
     assert np.array_equal(ev_p, ev_o)
     assert np.array_equal(tab, om.match_table())
+
+
+def test_threaded_planner_is_deterministic():
+    # the planner cuts the job list into ranges, plans them in threads and concatenates: every uploaded array must be
+    # bit-identical to what one thread produces, whatever the thread count and wherever the cuts fall
+    pm = sa.Model.load(cases.MODEL_6MER)
+    p = sa.default_params()
+    jobs = cases.synthetic_jobs(cases.MODEL_6MER, 23, 600) + cases.synthetic_jobs(cases.MODEL_6MER, 3, 2600, 100)
+    jobs.insert(5, dict(ref="ACGTACGT", events=np.zeros(0), ax=[], ay=[]))  # a job without events in the middle
+    alpha, k, t10, tab = synth.parse_model_table(cases.MODEL_6MER)
+    big = synth.make_read(7, 9000, alpha, k, tab)
+    hole = (big["ax"] > 1500) & (big["ax"] < 5500)
+    big["ax"], big["ay"] = big["ax"][~hole], big["ay"][~hole]
+    jobs.insert(11, big)  # splits into two regions
+    ref_info, ref_digest = sa.plan_digest(pm, p, jobs, threads=1)
+    assert ref_info.n_regions == len(jobs)  # 28 with events + 1 extra region of the split read - 1 empty job
+    for t in (2, 3, 5, 7):
+        info, digest = sa.plan_digest(pm, p, jobs, threads=t)
+        assert digest == ref_digest, t
+        assert (info.n_regions, info.n_segments, info.n_checkpoints) == (ref_info.n_regions, ref_info.n_segments,
+                                                                          ref_info.n_checkpoints)
+        assert info.cells_forward == ref_info.cells_forward and info.cells_backward == ref_info.cells_backward
+    # the memory-resident variant lays its rows out differently: a different digest, equally stable
+    g1 = sa.plan_digest(pm, p, jobs, flags=sa.FLAG_FORCE_GENERIC, threads=1)[1]
+    g4 = sa.plan_digest(pm, p, jobs, flags=sa.FLAG_FORCE_GENERIC, threads=4)[1]
+    assert g1 == g4
