@@ -43,6 +43,9 @@ struct DevModel {
     int hdp;
     const int *hdp_slot;    // per k-mer: row of y/slope tables of the first observed ancestor, -1 if none
     const double *hdp_y, *hdp_slope, *hdp_grid;
+    const double *hdp_tab;  // register kernels: {y[i], slope[i]} interleaved, one row per observed process
+    double hdp_g0, hdp_gN, hdp_dx;
+    unsigned hdp_tab_bytes;
     int grid_len;
 };
 
@@ -735,7 +738,7 @@ struct sa_batch {
     double *d_bscratch;
     double *d_gsum, *d_gmc;  // expectation mode only
     bool expect;
-    double *d_tab6; int *d_hdp_slot; double *d_hdp_y, *d_hdp_slope, *d_hdp_grid;
+    double *d_tab6; int *d_hdp_slot; double *d_hdp_y, *d_hdp_slope, *d_hdp_grid, *d_hdp_tab;
     long long *d_prob; int *d_seg_pass; long long *d_seg_off; sa_pair_t *d_out;
     int *d_ids;  // region / segment id lists per launch
     long long cand_alloc;
@@ -779,6 +782,14 @@ static DevPlan make_devplan(const sa_batch *b) {
     P.m.tab6 = b->d_tab6; P.m.pow_km1 = m->pow_km1; P.m.n_alpha = m->n_alpha; P.m.hdp = m->hdp ? 1 : 0;
     P.m.hdp_slot = b->d_hdp_slot; P.m.hdp_y = b->d_hdp_y; P.m.hdp_slope = b->d_hdp_slope; P.m.hdp_grid = b->d_hdp_grid;
     P.m.grid_len = m->hdp ? (int) m->hdp->grid_length : 0;
+    if (m->hdp) {
+        const sa_hdp_t *h = m->hdp;
+        P.m.hdp_tab = b->d_hdp_tab;
+        P.m.hdp_g0 = h->grid[0];
+        P.m.hdp_gN = h->grid[h->grid_length - 1];
+        P.m.hdp_dx = h->grid[1] - h->grid[0];  // grid_spline_interp: dx = x[1] - x[0]
+        P.m.hdp_tab_bytes = (unsigned) (h->n_slots * h->grid_length * 16);
+    }
     P.threshold = pl->params.threshold;
     P.log_thr = log(pl->params.threshold);
     return P;
@@ -797,7 +808,7 @@ void sa_batch_destroy(sa_batch_t *b) {
     if (b->device >= 0) (void) hipSetDevice(b->device);
     void *ptrs[] = {b->d_regions, b->d_rows, b->d_pk, b->d_poff, b->d_pid, b->d_xc, b->d_ev, b->d_segs, b->d_cks, b->d_F,
                     b->d_vbuf, b->d_cands, b->d_cand_count, b->d_overflow, b->d_totals, b->d_bscratch, b->d_tab6,
-                    b->d_hdp_slot, b->d_hdp_y, b->d_hdp_slope, b->d_hdp_grid, b->d_prob, b->d_seg_pass, b->d_seg_off,
+                    b->d_hdp_slot, b->d_hdp_y, b->d_hdp_slope, b->d_hdp_grid, b->d_hdp_tab, b->d_prob, b->d_seg_pass, b->d_seg_off,
                     b->d_out, b->d_ids, b->d_gsum, b->d_gmc};
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
@@ -853,7 +864,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     b->d_ev = nullptr; b->d_segs = nullptr; b->d_cks = nullptr; b->d_F = nullptr; b->d_vbuf = nullptr;
     b->d_cands = nullptr; b->d_cand_count = nullptr; b->d_overflow = nullptr; b->d_totals = nullptr;
     b->d_bscratch = nullptr; b->d_tab6 = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr;
-    b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr;
+    b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr; b->d_hdp_tab = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr;
     b->d_seg_off = nullptr; b->d_out = nullptr; b->d_ids = nullptr; b->d_gsum = nullptr; b->d_gmc = nullptr;
     b->expect = (flags & SA_FLAG_EXPECT_INTERNAL) != 0;
     b->cand_alloc = 0; b->out_alloc = 0;
@@ -914,6 +925,12 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
             TRY(upload(&b->d_hdp_y, h->y, h->n_slots * h->grid_length));
             TRY(upload(&b->d_hdp_slope, h->slope, h->n_slots * h->grid_length));
             TRY(upload(&b->d_hdp_grid, h->grid, h->grid_length));
+            std::vector<double> tab((size_t) (h->n_slots * h->grid_length * 2));
+            for (long long i = 0; i < h->n_slots * h->grid_length; i++) {
+                tab[2 * i] = h->y[i];
+                tab[2 * i + 1] = h->slope[i];
+            }
+            TRY(upload(&b->d_hdp_tab, tab.data(), (long long) tab.size()));
         }
     }
     if (trace_c) fprintf(stderr, "[trace] create: inputs uploaded at %.1f ms\n", now_ms_c() - tc0);

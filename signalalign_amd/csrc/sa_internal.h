@@ -91,6 +91,7 @@ typedef struct sa_region {
 #define SA_PK_SHIFT 13
 #define SA_PK_PAD 64         /* readable (zero) words in front of diagonal 0; 160 behind diagonal N             */
 #define SA_FAST_ROW_ALIGN 1 /* cells; 16 (128-byte rows) was measured: no gain, packed rows write better (probes/store_probe.hip) */
+#define SA_HDP_FAST_MAX_BYTES 0x7f000000ll /* {y, slope} table of the observed processes, register kernels */
 #define SA_FAST_MAX_CELLS (1ll << 27) /* register kernels address a region's forward planes with 32-bit byte offsets */
 
 typedef struct sa_seg {

@@ -449,7 +449,10 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
     double cf = 0;
     /* register-kernel regions start every diagonal on a 128-byte boundary of its plane: a cache line then belongs to
      * one store instruction of one diagonal and never has to be merged with the next diagonal's bytes */
-    int fast_ok = maxP == 1 && m->hdp == NULL && !(pl->flags & (SA_FLAG_EXACT | SA_FLAG_FORCE_GENERIC));
+    int fast_ok = maxP == 1 && !(pl->flags & (SA_FLAG_EXACT | SA_FLAG_FORCE_GENERIC));
+    /* HDP emissions on the register kernels: the {y, slope} table is addressed with 32-bit byte offsets */
+    if (m->hdp != NULL && (m->hdp->grid_length < 2 || m->hdp->n_slots * m->hdp->grid_length * 16 >= SA_HDP_FAST_MAX_BYTES))
+        fast_ok = 0;
     const int64_t row_align = fast_ok ? SA_FAST_ROW_ALIGN : 1;
     for (int64_t d = 0; d <= N; d++) {
         int64_t w = (hi[d] - lo[d]) / 2 + 1;
@@ -590,6 +593,21 @@ static int fill_xc(sa_plan_t *pl) {
         for (int64_t i = 0; i < n; i++) {
             int32_t id = pl->pid[R->pid_off + i];
             double *o = pl->xc + 4 * (R->pid_off + i);
+            if (m->hdp != NULL) {
+                /* HDP (register kernels only): e' = e/var - o[0]; o[1] = byte offset of the k-mer's {y, slope} row, or
+                 * an offset beyond the table when there is no density (NULL k-mer, no observed ancestor) */
+                const sa_hdp_t *h = m->hdp;
+                int64_t slot = -1;
+                if (id >= 0) {
+                    int64_t rs = h->resolved[id];
+                    slot = rs >= 0 ? h->slot[rs] : -1;
+                }
+                double mu = id >= 0 ? m->table5[5 * (int64_t) id] : 0.0;
+                o[0] = ((R->scale - R->var) * mu + R->shift) / R->var;
+                o[1] = slot >= 0 ? (double) (slot * h->grid_length * 16) : (double) SA_HDP_FAST_MAX_BYTES;
+                o[2] = 0.0; o[3] = 0.0;
+                continue;
+            }
             if (id < 0) { /* NULL k-mer: both emissions are log(0); inv_s = 1 keeps (e - m) * inv_s finite */
                 o[0] = 0.0; o[1] = 1.0; o[2] = SA_NEG_INF; o[3] = SA_NEG_INF;
                 continue;
