@@ -156,15 +156,57 @@ __device__ __forceinline__ int wave_max_i(int v) {
     return v;
 }
 
+#include "sa_fast.inc"
+
+// ---------------------------------------------------------------------------------------------------
+// The memory-resident kernels come in two flavours.  EXACT (SA_FLAG_EXACT, the expectation pass, HDP with several
+// paths per cell): the reference's arithmetic in the reference's order, rows read back from global memory.
+// RELAX (default for everything the register kernels cannot take: several paths per cell, windows wider than 64
+// lanes): the same recurrence with the register kernels' arithmetic -- logAdd from the LDS table, Gaussian emissions
+// from the folded per-position constants, legality by a float-reciprocal division -- and the three live diagonals in
+// an LDS ring (dynamic shared memory: 68 doubles of logAdd table + 3 x ring_cap x 3 doubles; ring_cap == 0 keeps the
+// rows in global memory).  Results agree with EXACT to ~1e-9 on a posterior (bar: 1e-5).
+// ---------------------------------------------------------------------------------------------------
+template <bool RELAX>
+__device__ __forceinline__ double la_any(const double *LT, double x, double y) {
+    return RELAX ? la_fast(LT, x, y) : la_exact(x, y);
+}
+// k-mer ids are < 2^24: exact in float; one correction step makes the truncated quotient exact
+__device__ __forceinline__ int div_small(int a, int d, float inv_d) {
+    int q = (int) ((float) a * inv_d);
+    int r = a - q * d;
+    q += (r >= d) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
+template <bool RELAX>
+__device__ __forceinline__ bool legal_any(const DevModel &m, float inv_pow, float inv_alpha, int from, int to) {
+    if (!RELAX) return legal_step(m, from, to);
+    if (from < 0 || to < 0) return true;
+    int fq = div_small(from, (int) m.pow_km1, inv_pow);
+    return from - fq * (int) m.pow_km1 == div_small(to, m.n_alpha, inv_alpha);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // generic forward: cellCalculate with doTransitionForward (impl/stateMachine.c:1306-1437,
 // impl/pairwiseAligner.c:852-858, :1280-1322).  Row layout: [cell-path][3].
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_fwd_generic(DevPlan P, const int *region_ids, int n) {
+template <bool RELAX>
+__global__ __launch_bounds__(64) void k_fwd_generic(DevPlan P, const int *region_ids, int n, int ring_cap) {
+    extern __shared__ __attribute__((aligned(32))) double dyn_lds[];
+    double *LT = dyn_lds;                          // RELAX only
+    double *lring = dyn_lds + LA_TAB_DOUBLES;      // RELAX && ring_cap > 0: rows d, d-1, d-2 as [cell-path][3]
     int w = blockIdx.x;
     if (w >= n) return;
     const int lane = threadIdx.x;
+    if (RELAX) {
+        la_tab_init(LT, lane);
+        __syncthreads();
+    }
+    const bool use_ring = RELAX && ring_cap > 0;
+    const float inv_pow = 1.0f / (float) P.m.pow_km1, inv_alpha = 1.0f / (float) P.m.n_alpha;
     const sa_region_t *R = &P.regions[region_ids[w]];
+    const double4 *xc4 = reinterpret_cast<const double4 *>(P.xc) + R->pid_off;
     const sa_row_t *rows = P.rows + R->row_off;
     const int *poff = P.poff + R->poff_off;
     const int *pid = P.pid + R->pid_off;
@@ -181,10 +223,12 @@ __global__ __launch_bounds__(64) void k_fwd_generic(DevPlan P, const int *region
             long long x = x0 + i;
             int np = poff[x + 1] - poff[x];
             double *c = F + 3 * (r0.foff + poff[x] - poff[x0]);
+            double *lc = lring + 3 * (poff[x] - poff[x0]);
             for (int p = 0; p < np; p++) {
                 c[3 * p + 0] = R->ragged_l ? NEG_INF : 0.0;
                 c[3 * p + 1] = R->ragged_l ? 0.0 : NEG_INF;
                 c[3 * p + 2] = R->ragged_l ? 0.0 : NEG_INF;
+                if (use_ring) { lc[3 * p + 0] = c[3 * p + 0]; lc[3 * p + 1] = c[3 * p + 1]; lc[3 * p + 2] = c[3 * p + 2]; }
             }
         }
     }
@@ -196,6 +240,10 @@ __global__ __launch_bounds__(64) void k_fwd_generic(DevPlan P, const int *region
         long long x0 = (d + rd.xmyL) >> 1;
         long long x01 = (d - 1 + r1.xmyL) >> 1;
         long long x02 = d >= 2 ? ((d - 2 + r2.xmyL) >> 1) : 0;
+        // previous diagonals: the LDS ring, or the forward storage itself
+        const double *P1 = use_ring ? lring + ((d - 1) % 3) * (long long) ring_cap * 3 : F + 3 * r1.foff;
+        const double *P2 = use_ring ? lring + ((d + 1) % 3) * (long long) ring_cap * 3 : F + 3 * r2.foff;
+        double *L0 = lring + (d % 3) * (long long) ring_cap * 3;
         for (int i = lane; i < rd.width; i += 64) {
             long long xmy = (long long) rd.xmyL + 2 * i;
             long long x = x0 + i, y = d - x;
@@ -203,43 +251,52 @@ __global__ __launch_bounds__(64) void k_fwd_generic(DevPlan P, const int *region
             int np = poff[x + 1] - poff[x];
             const int *idc = pid + poff[x];
             double *cur = F + 3 * (rd.foff + poff[x] - poff[x0]);
+            double *lcur = L0 + 3 * (poff[x] - poff[x0]);
             long long i_lo = xmy - 1 - r1.xmyL, i_up = xmy + 1 - r1.xmyL, i_mid = xmy - r2.xmyL;
             bool has_lo = x >= 1 && i_lo >= 0 && (i_lo >> 1) < r1.width;
             bool has_up = i_up >= 0 && (i_up >> 1) < r1.width;
             bool has_mid = d >= 2 && x >= 1 && i_mid >= 0 && (i_mid >> 1) < r2.width;
-            const double *lo = has_lo ? F + 3 * (r1.foff + poff[x - 1] - poff[x01]) : nullptr;
-            const double *up = has_up ? F + 3 * (r1.foff + poff[x] - poff[x01]) : nullptr;
-            const double *mid = has_mid ? F + 3 * (r2.foff + poff[x - 1] - poff[x02]) : nullptr;
+            const double *lo = has_lo ? P1 + 3 * (poff[x - 1] - poff[x01]) : nullptr;
+            const double *up = has_up ? P1 + 3 * (poff[x] - poff[x01]) : nullptr;
+            const double *mid = has_mid ? P2 + 3 * (poff[x - 1] - poff[x02]) : nullptr;
             int nq = x >= 1 ? poff[x] - poff[x - 1] : 0;
             const int *idq = x >= 1 ? pid + poff[x - 1] : nullptr;
             for (int p = 0; p < np; p++) {
                 int id = idc[p];
                 double sm = NEG_INF, sx = NEG_INF, sy = NEG_INF;
+                double eM, eY;  // match / gapY emission of this cell-path
+                if (RELAX) {
+                    emit_gauss(xc4[poff[x] + p], e, eM, eY);
+                } else {
+                    eM = has_mid ? emit_ref(m, rp, id, e, 1) : NEG_INF;
+                    eY = has_up ? emit_ref(m, rp, id, e, 0) : NEG_INF;
+                }
                 if (has_lo) {
                     double eP = (m.hdp || id >= 0) ? SA_LOG_GAPX : NEG_INF;
                     for (int q = 0; q < nq; q++)
-                        if (legal_step(m, idq[q], id)) {
-                            sx = la_exact(sx, lo[3 * q + 0] + (eP + m.t_mx));
-                            sx = la_exact(sx, lo[3 * q + 1] + (eP + m.t_xx));
+                        if (legal_any<RELAX>(m, inv_pow, inv_alpha, idq[q], id)) {
+                            sx = la_any<RELAX>(LT, sx, lo[3 * q + 0] + (eP + m.t_mx));
+                            sx = la_any<RELAX>(LT, sx, lo[3 * q + 1] + (eP + m.t_xx));
                         }
                 }
                 if (has_mid) {
-                    double eP = emit_ref(m, rp, id, e, 1);
+                    double eP = eM;
                     for (int q = 0; q < nq; q++)
-                        if (legal_step(m, idq[q], id)) {
-                            sm = la_exact(sm, mid[3 * q + 0] + (eP + m.t_mm));
-                            sm = la_exact(sm, mid[3 * q + 1] + (eP + m.t_xm));
-                            sm = la_exact(sm, mid[3 * q + 2] + (eP + m.t_ym));
+                        if (legal_any<RELAX>(m, inv_pow, inv_alpha, idq[q], id)) {
+                            sm = la_any<RELAX>(LT, sm, mid[3 * q + 0] + (eP + m.t_mm));
+                            sm = la_any<RELAX>(LT, sm, mid[3 * q + 1] + (eP + m.t_xm));
+                            sm = la_any<RELAX>(LT, sm, mid[3 * q + 2] + (eP + m.t_ym));
                         }
                 }
                 if (has_up) {
-                    double eP = emit_ref(m, rp, id, e, 0);
-                    sy = la_exact(sy, up[3 * p + 0] + (eP + m.t_my));
-                    sy = la_exact(sy, up[3 * p + 2] + (eP + m.t_yy));
+                    double eP = eY;
+                    sy = la_any<RELAX>(LT, sy, up[3 * p + 0] + (eP + m.t_my));
+                    sy = la_any<RELAX>(LT, sy, up[3 * p + 2] + (eP + m.t_yy));
                 }
                 cur[3 * p + 0] = sm;
                 cur[3 * p + 1] = sx;
                 cur[3 * p + 2] = sy;
+                if (use_ring) { lcur[3 * p + 0] = sm; lcur[3 * p + 1] = sx; lcur[3 * p + 2] = sy; }
             }
         }
         __syncthreads();
@@ -264,11 +321,20 @@ __device__ __forceinline__ void expect_flush(const DevPlan &P, long long ck, dou
 // the same terms in the same order: first from (x+1,y+1) (it was that cell's "middle"), then from (x,y+1)
 // (its "upper"), then from (x+1,y) (its "lower").  Backward rows live in a 3-row ring in memory.
 // ---------------------------------------------------------------------------------------------------
-template <bool EXPECT>
-__global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_ids, int n) {
+template <bool EXPECT, bool RELAX>
+__global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_ids, int n, int ring_cap) {
+    extern __shared__ __attribute__((aligned(32))) double dyn_lds[];
+    double *LT = dyn_lds;                          // RELAX only
+    double *lring = dyn_lds + LA_TAB_DOUBLES;      // RELAX && ring_cap > 0: backward rows e, e+1, e+2
     int w = blockIdx.x;
     if (w >= n) return;
     const int lane = threadIdx.x;
+    if (RELAX) {
+        la_tab_init(LT, lane);
+        __syncthreads();
+    }
+    const bool use_ring = RELAX && ring_cap > 0;
+    const float inv_pow = 1.0f / (float) P.m.pow_km1, inv_alpha = 1.0f / (float) P.m.n_alpha;
     const int seg = seg_ids[w];
     const sa_seg_t *S = &P.segs[seg];
     const sa_region_t *R = &P.regions[S->region];
@@ -279,8 +345,9 @@ __global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_id
     const double *F = P.F + 3 * R->f_base;
     const DevModel &m = P.m;
     ReadPar rp = {R->scale, R->shift, R->var, R->lvar};
-    const long long rowcap = R->max_rowpaths;
-    double *ring = P.bscratch + S->bscratch_off;  // 3 rows x rowcap x 3
+    const long long rowcap = use_ring ? ring_cap : R->max_rowpaths;
+    double *ring = use_ring ? lring : P.bscratch + S->bscratch_off;  // 3 rows x rowcap x 3
+    const double4 *xc4 = reinterpret_cast<const double4 *>(P.xc) + R->pid_off;
     const long long start = S->start, from = S->from, to = S->to;
     double end_m, end_x, end_y;  // endStateProb / raggedEndStateProb (impl/stateMachine.c:1145-1173)
     if (S->at_end && R->ragged_r) {
@@ -335,26 +402,30 @@ __global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_id
                 double tm = NEG_INF, tx = NEG_INF, ty = NEG_INF;
                 if (has_mid)
                     for (int p = 0; p < nn; p++)
-                        if (legal_step(m, idq, idn[p])) {
-                            double eP = emit_ref(m, rp, idn[p], e_next, 1);
+                        if (legal_any<RELAX>(m, inv_pow, inv_alpha, idq, idn[p])) {
+                            double eP, eU;
+                            if (RELAX) emit_gauss(xc4[poff[x + 1] + p], e_next, eP, eU);
+                            else eP = emit_ref(m, rp, idn[p], e_next, 1);
                             double c = cm[3 * p + 0];
-                            tm = la_exact(tm, c + (eP + m.t_mm));
-                            tx = la_exact(tx, c + (eP + m.t_xm));
-                            ty = la_exact(ty, c + (eP + m.t_ym));
+                            tm = la_any<RELAX>(LT, tm, c + (eP + m.t_mm));
+                            tx = la_any<RELAX>(LT, tx, c + (eP + m.t_xm));
+                            ty = la_any<RELAX>(LT, ty, c + (eP + m.t_ym));
                         }
                 if (has_up) {
-                    double eP = emit_ref(m, rp, idq, e_next, 0);
+                    double eP, eU;
+                    if (RELAX) emit_gauss(xc4[poff[x] + q], e_next, eU, eP);
+                    else eP = emit_ref(m, rp, idq, e_next, 0);
                     double c = cu[3 * q + 2];
-                    tm = la_exact(tm, c + (eP + m.t_my));
-                    ty = la_exact(ty, c + (eP + m.t_yy));
+                    tm = la_any<RELAX>(LT, tm, c + (eP + m.t_my));
+                    ty = la_any<RELAX>(LT, ty, c + (eP + m.t_yy));
                 }
                 if (has_lo)
                     for (int p = 0; p < nn; p++)
-                        if (legal_step(m, idq, idn[p])) {
+                        if (legal_any<RELAX>(m, inv_pow, inv_alpha, idq, idn[p])) {
                             double eP = (m.hdp || idn[p] >= 0) ? SA_LOG_GAPX : NEG_INF;
                             double c = cl[3 * p + 1];
-                            tm = la_exact(tm, c + (eP + m.t_mx));
-                            tx = la_exact(tx, c + (eP + m.t_xx));
+                            tm = la_any<RELAX>(LT, tm, c + (eP + m.t_mx));
+                            tx = la_any<RELAX>(LT, tx, c + (eP + m.t_xx));
                         }
                 cur[3 * q + 0] = tm; cur[3 * q + 1] = tx; cur[3 * q + 2] = ty;
             }
@@ -374,9 +445,9 @@ __global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_id
                 double cell = NEG_INF;
                 for (int q = 0; q < np; q++) {
                     double t = cf[3 * q] + cb[3 * q];
-                    t = la_exact(t, cf[3 * q + 1] + cb[3 * q + 1]);
-                    t = la_exact(t, cf[3 * q + 2] + cb[3 * q + 2]);
-                    cell = la_exact(cell, t);
+                    t = la_any<RELAX>(LT, t, cf[3 * q + 1] + cb[3 * q + 1]);
+                    t = la_any<RELAX>(LT, t, cf[3 * q + 2] + cb[3 * q + 2]);
+                    cell = la_any<RELAX>(LT, cell, t);
                 }
                 P.vbuf[ck.voff + i] = cell;
                 mx = cell > mx ? cell : mx;
@@ -388,7 +459,7 @@ __global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_id
                     const double *cf = F + 3 * (r1.foff + poff[x] - poff[x01]);
                     const double *cb = B1 + 3 * (poff[x] - poff[x01]);
                     double cell = NEG_INF;
-                    for (int q = 0; q < np; q++) cell = la_exact(cell, cf[3 * q] + cb[3 * q]);
+                    for (int q = 0; q < np; q++) cell = la_any<RELAX>(LT, cell, cf[3 * q] + cb[3 * q]);
                     P.vbuf[ck.voff + ck.nA + i] = cell;
                     mx = cell > mx ? cell : mx;
                 }
@@ -699,7 +770,6 @@ __global__ __launch_bounds__(64) void k_gather(DevPlan P, int seg0, int n_segs, 
     }
 }
 
-#include "sa_fast.inc"
 
 // ===================================================================================================
 // host runtime
@@ -738,6 +808,8 @@ struct sa_batch {
     double *d_bscratch;
     double *d_gsum, *d_gmc;  // expectation mode only
     bool expect;
+    bool relax;              // memory-resident kernels in their RELAX flavour
+    int ring_cap;            // cell-paths per diagonal of their LDS ring (0: rows stay in global memory)
     double *d_tab6; int *d_hdp_slot; double *d_hdp_y, *d_hdp_slope, *d_hdp_grid, *d_hdp_tab;
     long long *d_prob; int *d_seg_pass; long long *d_seg_off; sa_pair_t *d_out;
     int *d_ids;  // region / segment id lists per launch
@@ -867,6 +939,14 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr; b->d_hdp_tab = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr;
     b->d_seg_off = nullptr; b->d_out = nullptr; b->d_ids = nullptr; b->d_gsum = nullptr; b->d_gmc = nullptr;
     b->expect = (flags & SA_FLAG_EXPECT_INTERNAL) != 0;
+    b->relax = !(flags & SA_FLAG_EXACT) && !b->expect && m->hdp == nullptr;
+    b->ring_cap = 0;
+    if (b->relax) {
+        long long cap = 0;
+        for (long long r = 0; r < pl->n_regions; r++)
+            if (pl->regions[r].kind == SA_KIND_GENERIC && pl->regions[r].max_rowpaths > cap) cap = pl->regions[r].max_rowpaths;
+        if ((LA_TAB_DOUBLES + 9 * cap) * 8 <= 64 * 1024) b->ring_cap = (int) cap;  // otherwise the rows stay in global memory
+    }
     b->cand_alloc = 0; b->out_alloc = 0;
     b->h_pairs = nullptr; b->h_pairs_cap = 0; b->n_pairs_total = 0;
     memset(&b->stats, 0, sizeof(b->stats));
@@ -1075,10 +1155,14 @@ static int submit_group(sa_batch *b, const DevPlan &P, int g, int which_stream, 
     const sa_launch_group &G = b->groups[g];
     hipStream_t st = b->cstream[which_stream];
     HIPCHK(hipEventRecord(b->gev[4 * g], st));
-    if (G.ngs && !b->expect)
-        hipLaunchKernelGGL(k_bwd_generic<false>, dim3(G.ngs), dim3(64), 0, st, P, b->d_ids + G.ids_gs, G.ngs);
+    const size_t relax_lds = sizeof(double) * (size_t) (LA_TAB_DOUBLES + 9 * b->ring_cap);
     if (G.ngs && b->expect)
-        hipLaunchKernelGGL(k_bwd_generic<true>, dim3(G.ngs), dim3(64), 0, st, P, b->d_ids + G.ids_gs, G.ngs);
+        hipLaunchKernelGGL((k_bwd_generic<true, false>), dim3(G.ngs), dim3(64), 0, st, P, b->d_ids + G.ids_gs, G.ngs, 0);
+    else if (G.ngs && b->relax)
+        hipLaunchKernelGGL((k_bwd_generic<false, true>), dim3(G.ngs), dim3(64), relax_lds, st, P, b->d_ids + G.ids_gs, G.ngs,
+                           b->ring_cap);
+    else if (G.ngs)
+        hipLaunchKernelGGL((k_bwd_generic<false, false>), dim3(G.ngs), dim3(64), 0, st, P, b->d_ids + G.ids_gs, G.ngs, 0);
     if (G.nfs) launch_bwd_fast(P, b->d_ids + G.ids_fs, G.nfs, st);
     HIPCHK(hipEventRecord(b->gev[4 * g + 1], st));
     if (G.ck1 > G.ck0)
@@ -1108,7 +1192,11 @@ static int enqueue_pass(sa_batch *b, bool finalize, AfterGroup after_group) {
     for (size_t c = 0; c < b->chunks.size(); c++) {
         const sa_launch_chunk &C = b->chunks[c];
         HIPCHK(hipEventRecord(b->cev[2 * c], s0));
-        if (C.ngr) hipLaunchKernelGGL(k_fwd_generic, dim3(C.ngr), dim3(64), 0, s0, P, b->d_ids + C.ids_gr, C.ngr);
+        if (C.ngr && b->relax)
+            hipLaunchKernelGGL(k_fwd_generic<true>, dim3(C.ngr), dim3(64), sizeof(double) * (size_t) (LA_TAB_DOUBLES + 9 * b->ring_cap),
+                               s0, P, b->d_ids + C.ids_gr, C.ngr, b->ring_cap);
+        else if (C.ngr)
+            hipLaunchKernelGGL(k_fwd_generic<false>, dim3(C.ngr), dim3(64), 0, s0, P, b->d_ids + C.ids_gr, C.ngr, 0);
         if (C.nfr) launch_fwd_fast(P, b->d_ids + C.ids_fr, C.nfr, s0);
         HIPCHK(hipEventRecord(b->cev[2 * c + 1], s0));
         if (C.g1 - C.g0 > 1) HIPCHK(hipStreamWaitEvent(s1, b->cev[2 * c + 1], 0));

@@ -74,7 +74,7 @@ def test_fast_kernels_within_tolerance_and_same_order(oracle):
 
 
 def test_generic_default_matches_fast(oracle):
-    # the memory-resident generic kernels with device-side finalisation (no EXACT flag)
+    # the memory-resident kernels in their RELAX flavour (register-kernel arithmetic, LDS ring, device-side finalisation)
     pm, om = _models(oracle, cases.MODEL_6MER)
     p = sa.default_params()
     op = cases.oracle_params(oracle, p)
@@ -83,7 +83,7 @@ def test_generic_default_matches_fast(oracle):
     assert st.n_fast_regions == 0
     for j, job in enumerate(jobs):
         exp = cases.oracle_pairs(oracle, om, job, op)
-        w, lonely = cases.compare_pairs(got[j], exp, 1, p.threshold)
+        w, lonely = cases.compare_pairs(got[j], exp, 10, p.threshold)
         assert cases.same_order(got[j], exp)
 
 
