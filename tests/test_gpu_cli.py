@@ -226,3 +226,81 @@ def test_signalmachine_batch_front_door(oracle, tmp_path):
         assert single_out[name][1] in pr.stdout
         assert "signalAlign - SUCCESS: finished alignment of query %s, exiting" % name in pr.stderr
     assert not os.path.exists(str(tmp_path / "broken.tsv"))
+
+
+def _revcomp(s):
+    return s.translate(str.maketrans("ACGT", "TGCA"))[::-1]
+
+
+def test_signalmachine_two_d(oracle, tmp_path):
+    # --twoD: template and complement strands of a 2D R7.3 read, each with its own model; the 2D read is the reference
+    # (one M run), so the complement aligns to the reverse complement (no -b: impl/fasta_handler.c:67-72)
+    t_model = cases.MODEL_R73
+    c_model = os.path.join(cases.GOLDEN, "models", "testModelR73_acegot_complement.model")
+    npread_path = os.path.join(cases.GOLDEN, "npReads", "ZymoC_ch_1_file1.npRead")
+    r = oracle.parse_npread(npread_path)
+    read2d = r["twoD_read"]
+    start2, L = 8, len(read2d) - 20
+    ref_start = 50
+    contig = "ACGT" * 12 + "AC" + read2d[start2:] + "TTGACCA" * 5
+    fasta = str(tmp_path / "ref.fa")
+    _write_fasta(fasta, "chr2D", contig)
+    cigar = str(tmp_path / "guide.cigar")
+    with open(cigar, "w") as f:
+        f.write("cigar: r2d %d %d + chr2D %d %d + 1 M %d\n" % (start2, start2 + L, ref_start, ref_start + L, L))
+    out = str(tmp_path / "out.tsv")
+    pr = subprocess.run([BIN, "--twoD", "-T", t_model, "-C", c_model, "-q", npread_path, "-f", fasta, "-n", "chr2D", "-p", cigar,
+                         "-u", out, "-L", "r2d", "-g", "100"], capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr
+    assert "signalAlign - starting complement alignment" in pr.stderr and "SUCCESS" in pr.stderr
+    rows = [l.rstrip("\n").split("\t") for l in open(out)]
+    got = {"t": [x for x in rows if x[4] == "t"], "c": [x for x in rows if x[4] == "c"]}
+    assert got["t"] and got["c"] and len(got["t"]) + len(got["c"]) == len(rows)
+    assert rows.index(got["c"][0]) == len(got["t"])  # template block first, then complement (two appends)
+
+    params = oracle.default_params()
+    target_fwd = contig[ref_start:ref_start + L]
+    gx, gy = oracle.guide_to_anchors(ref_start, ref_start + L, 1, start2, [(0, L)], 14)
+    summary = []
+    for strand, model_path in (("t", t_model), ("c", c_model)):
+        om = oracle.Model.from_file(model_path)
+        pre = "template" if strand == "t" else "complement"
+        ev = r[pre + "_events"].copy()
+        pr_ = oracle.estimate_params(om, r[pre + "_strand_event_map"], ev, r[pre + "_read"])
+        em = r[pre + "_event_map"]  # 2D maps in the 2D workflow (impl/signalMachine.c:726-733)
+        ax, ay = oracle.remap_anchors(gx, gy, em, start2)
+        lo, hi = int(em[start2]), int(em[start2 + L - 1])
+        target = target_fwd if strand == "t" else _revcomp(target_fwd)
+        om.set_read_params(pr_["scale"], pr_["shift"], pr_["var"])
+        pairs = oracle.align(om, target, ev[lo:hi], ax, ay, params)
+        assert len(pairs) > 200
+        summary.append(len(pairs))
+        k, alpha, tab = om.k, om.alphabet, om.match_table()
+        ref_len, ref_len_kmers = len(target), len(target) - k
+        assert len(got[strand]) == len(pairs), strand
+        bad = 0
+        for g, p in zip(got[strand], pairs):
+            x, y = int(p["x"]), int(p["y"]) + lo
+            # adjustReferenceCoordinate / makeReferenceKmer for a forward-mapped read (impl/signalMachine.c:54-70)
+            if strand == "t":
+                x_adj, ref_kmer = x + ref_start, target[x:x + k]
+            else:
+                x_adj, ref_kmer = ref_len_kmers - (x + (ref_len - (ref_start + L))), _revcomp(target[x:x + k])
+            kid, kmer, t_ = int(p["kmer_id"]), "", int(p["kmer_id"])
+            for _ in range(k):
+                kmer = alpha[t_ % len(alpha)] + kmer
+                t_ //= len(alpha)
+            e_mean = tab[5 * kid]
+            exp = ["chr2D", str(x_adj), ref_kmer, "r2d", strand, str(y), "%f" % ev[y, 0], "%f" % ev[y, 1], "%f" % ev[y, 2],
+                   target[x:x + k], "%f" % (e_mean * pr_["scale"] + pr_["shift"]), None, None,
+                   "%f" % ((ev[y, 0] + pr_["var"] * e_mean - pr_["scale"] * e_mean - pr_["shift"]) / pr_["var"]),
+                   "%f" % e_mean, kmer]
+            for col in range(16):
+                if exp[col] is not None:
+                    assert g[col] == exp[col], (strand, col, g, exp)
+            d = abs(float(g[12]) - int(p["prob_e7"]) / 1e7)
+            assert d <= 1e-5
+            bad += d > 1.5e-6  # the column is printed with six decimals
+        assert bad <= len(pairs) // 100
+    head = pr.stdout.strip("\n").split("\t")
+    assert head[1].startswith("%d(" % summary[0]) and head[2].startswith("%d(" % summary[1])
