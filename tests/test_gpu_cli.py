@@ -304,3 +304,107 @@ def test_signalmachine_two_d(oracle, tmp_path):
         assert bad <= len(pairs) // 100
     head = pr.stdout.strip("\n").split("\t")
     assert head[1].startswith("%d(" % summary[0]) and head[2].startswith("%d(" % summary[1])
+
+
+def test_signalmachine_minus_strand_and_assignments(oracle, tmp_path):
+    # a read mapped to the reverse strand (cigar with '-', rstart > rend: utils/bwaWrapper.py:213-214) with an explicit
+    # backward reference (-b), full TSV (-s 0) and the assignments rendering (-s 2)
+    model = cases.MODEL_5MER
+    npread_path = os.path.join(cases.GOLDEN, "npReads", "c2925_ecoli_ch34_read1023.npRead")
+    r = oracle.parse_npread(npread_path)
+    read = r["template_read"]
+    start2, L = 6, len(read) - 14
+    part = read[start2:start2 + L]
+    pre, post = "GATTACA" * 9, "CCGGTTAA" * 6
+    contig = pre + _revcomp(part) + post          # the read matches the reverse strand of the contig
+    fasta, bfasta = str(tmp_path / "fwd.fa"), str(tmp_path / "bwd.fa")
+    _write_fasta(fasta, "chrM", contig)
+    _write_fasta(bfasta, "chrM", contig.translate(str.maketrans("ACGT", "TGCA")))  # the complement, same coordinates
+    end1, start1 = len(pre), len(pre) + L
+    cigar = str(tmp_path / "guide.cigar")
+    with open(cigar, "w") as f:
+        f.write("cigar: rm %d %d + chrM %d %d - 1 M %d\n" % (start2, start2 + L, start1, end1, L))
+    om = oracle.Model.from_file(model)
+    ev = r["template_events"].copy()
+    pr_ = oracle.estimate_params(om, r["template_strand_event_map"], ev, read)
+    em = r["template_strand_event_map"]
+    gx, gy = oracle.guide_to_anchors(start1, end1, 0, start2, [(0, L)], 14)
+    ax, ay = oracle.remap_anchors(gx, gy, em, start2)
+    lo, hi = int(em[start2]), int(em[start2 + L - 1])
+    target = part                                   # reverse of the complement window == the read's own bases
+    om.set_read_params(pr_["scale"], pr_["shift"], pr_["var"])
+    pairs = oracle.align(om, target, ev[lo:hi], ax, ay, oracle.default_params())
+    assert len(pairs) > 300
+    k, alpha, tab = om.k, om.alphabet, om.match_table()
+
+    full, assign = str(tmp_path / "full.tsv"), str(tmp_path / "assign.tsv")
+    common = [BIN, "-T", model, "-q", npread_path, "-f", fasta, "-b", bfasta, "-n", "chrM", "-p", cigar, "-L", "rm", "-g", "100"]
+    for fmt, out in (("0", full), ("2", assign)):
+        pr = subprocess.run(common + ["-s", fmt, "-u", out], capture_output=True, text=True, timeout=300)
+        assert pr.returncode == 0, pr.stderr
+    rows = [l.rstrip("\n").split("\t") for l in open(full)]
+    arows = [l.rstrip("\n").split("\t") for l in open(assign)]
+    assert len(rows) == len(pairs) == len(arows)
+    ref_len, ref_len_kmers = len(target), len(target) - k
+    for g, a, p in zip(rows, arows, pairs):
+        x, y = int(p["x"]), int(p["y"]) + lo
+        kid, kmer, t_ = int(p["kmer_id"]), "", int(p["kmer_id"])
+        for _ in range(k):
+            kmer = alpha[t_ % len(alpha)] + kmer
+            t_ //= len(alpha)
+        e_mean = tab[5 * kid]
+        desc = (ev[y, 0] + pr_["var"] * e_mean - pr_["scale"] * e_mean - pr_["shift"]) / pr_["var"]
+        # template strand of a reverse-mapped read: mirrored coordinate, reverse-complemented reference k-mer
+        x_adj = ref_len_kmers - (x + (ref_len - start1))
+        assert g[:6] == ["chrM", str(x_adj), _revcomp(target[x:x + k]), "rm", "t", str(y)], (g, x, y)
+        assert g[9] == target[x:x + k] and g[13] == "%f" % desc and g[15] == kmer
+        assert abs(float(g[12]) - int(p["prob_e7"]) / 1e7) <= 1e-5
+        assert a[0] == kmer and a[1] == "t" and a[2] == "%f" % desc
+        assert abs(float(a[3]) - int(p["prob_e7"]) / 1e7) <= 1e-5
+
+
+def test_signalmachine_hdp_model(oracle, tmp_path):
+    # -v <.nhdp> switches to the HMM-HDP state machine (impl/signalMachine.c:667-690): emissions from the HDP, the
+    # model means replaced by the HDP's expected values before alignment (:861-863) -- which the E_mean column shows
+    model, nhdp = cases.MODEL_R73, cases.NHDP
+    npread_path = os.path.join(cases.GOLDEN, "npReads", "ZymoC_ch_1_file1.npRead")
+    r = oracle.parse_npread(npread_path)
+    read = r["template_read"]
+    start2, L = 4, len(read) - 12
+    fasta = str(tmp_path / "ref.fa")
+    _write_fasta(fasta, "chrH", "TTTT" + read[start2:] + "ACACAC")
+    cigar = str(tmp_path / "guide.cigar")
+    with open(cigar, "w") as f:
+        f.write("cigar: rh %d %d + chrH 4 %d + 1 M %d\n" % (start2, start2 + L, 4 + L, L))
+    out = str(tmp_path / "out.tsv")
+    pr = subprocess.run([BIN, "-T", model, "-v", nhdp, "-q", npread_path, "-f", fasta, "-n", "chrH", "-p", cigar, "-u", out,
+                         "-L", "rh", "-g", "100", "-D", "0.05"], capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr
+    assert "Using threeStateHdp stateMachine since you pass in an HDP file" in pr.stderr
+    om = oracle.Model.from_file(model)
+    ev = r["template_events"].copy()
+    pr_ = oracle.estimate_params(om, r["template_strand_event_map"], ev, read)  # before the HDP means are installed
+    om.load_hdp(nhdp)
+    om.set_to_hdp_expected_values()
+    em = r["template_strand_event_map"]
+    gx, gy = oracle.guide_to_anchors(4, 4 + L, 1, start2, [(0, L)], 14)
+    ax, ay = oracle.remap_anchors(gx, gy, em, start2)
+    lo, hi = int(em[start2]), int(em[start2 + L - 1])
+    om.set_read_params(pr_["scale"], pr_["shift"], pr_["var"])
+    pairs = oracle.align(om, read[start2:start2 + L], ev[lo:hi], ax, ay, oracle.default_params(threshold=0.05))
+    rows = [l.rstrip("\n").split("\t") for l in open(out)]
+    assert len(pairs) > 50
+    exp = {(int(p["x"]) + 4, int(p["y"]) + lo): p for p in pairs}
+    got = {(int(g[1]), int(g[5])): g for g in rows}
+    tab = om.match_table()
+    lonely = 0
+    for key in set(exp) | set(got):
+        if key in exp and key in got:
+            p, g = exp[key], got[key]
+            assert abs(float(g[12]) - int(p["prob_e7"]) / 1e7) <= 1e-5 + 5e-7
+            assert g[14] == "%f" % tab[5 * int(p["kmer_id"])]  # HDP expected mean, not the .model file's
+        else:
+            pv = int(exp[key]["prob_e7"]) / 1e7 if key in exp else float(got[key][12])
+            assert abs(pv - 0.05) <= 2e-5, key  # only pairs sitting on the threshold may differ
+            lonely += 1
+    assert lonely <= 2
