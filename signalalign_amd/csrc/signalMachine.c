@@ -18,9 +18,11 @@
 #include <getopt.h>
 #include <inttypes.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "sa_io.h"
 #include "signalalign_hip.h"
@@ -475,6 +477,113 @@ static int64_t load_manifest(const char *path, read_t **out) {
     return n;
 }
 
+/* host work per read (parsing, parameter estimation, TSV rendering) is independent: a small pthread parallel-for */
+typedef struct {
+    void (*fn)(int64_t i, void *ctx);
+    void *ctx;
+    int64_t n;
+    int64_t next;
+    pthread_mutex_t mu;
+} pfor_t;
+
+static void *pfor_worker(void *arg) {
+    pfor_t *pf = arg;
+    for (;;) {
+        pthread_mutex_lock(&pf->mu);
+        int64_t i = pf->next++;
+        pthread_mutex_unlock(&pf->mu);
+        if (i >= pf->n) return NULL;
+        pf->fn(i, pf->ctx);
+    }
+}
+
+static void parallel_for(int64_t n, void (*fn)(int64_t, void *), void *ctx) {
+    const char *e = getenv("SA_HOST_THREADS");
+    long t = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+    if (t > 32) t = 32;
+    if (t > n) t = n;
+    if (t <= 1) {
+        for (int64_t i = 0; i < n; i++) fn(i, ctx);
+        return;
+    }
+    pfor_t pf = {fn, ctx, n, 0, PTHREAD_MUTEX_INITIALIZER};
+    pthread_t th[32];
+    int started[32];
+    for (long k = 0; k < t; k++) started[k] = pthread_create(&th[k], NULL, pfor_worker, &pf) == 0;
+    if (!started[0]) pfor_worker(&pf); /* no threads at all: do the work here */
+    for (long k = 0; k < t; k++)
+        if (started[k]) pthread_join(th[k], NULL);
+}
+
+typedef struct {
+    const run_t *R;
+    read_t *reads;
+    int fatal;
+} prep_ctx_t;
+
+static void prep_one(int64_t i, void *ctx) {
+    prep_ctx_t *c = ctx;
+    if (prepare_read(c->R, &c->reads[i], c->fatal) != 0)
+        fprintf(stderr, "[signalMachine] ERROR: read %s skipped: %s\n", c->reads[i].label, c->reads[i].err);
+}
+
+typedef struct {
+    const run_t *R;
+    read_t *reads;
+    const int64_t *who;
+    sa_pair_t ***pairs;   /* [strand][job] */
+    int64_t **n_pairs;
+    double (*score)[2];
+} out_job_t;
+
+static void output_one(int64_t j, void *ctx) {
+    out_job_t *c = ctx;
+    const run_t *R = c->R;
+    read_t *rd = &c->reads[c->who[j]];
+    const int n_strands = R->two_d ? 2 : 1;
+    if (R->out_fmt == 3 && rd->post_path2 == NULL) {
+        fprintf(stderr, "[signalMachine] ERROR: read %s: 'both' output format needs a second output file\n", rd->label);
+        rd->failed = 1;
+        return;
+    }
+    for (int s = 0; s < n_strands; s++) {
+        double tot = 0.0;
+        for (int64_t i = 0; i < c->n_pairs[s][j]; i++) tot += (double) c->pairs[s][j][i].prob_e7;
+        c->score[j][s] = 100.0 * tot / ((double) c->n_pairs[s][j] * PROB_1); /* scoreByPosteriorProbabilityIgnoringGaps :407-412 */
+    }
+    if (rd->post_path != NULL) {
+        out_ctx_t o;
+        o.label = rd->label; o.contig = rd->pA->contig1; o.sm = &R->smt; o.npp = rd->np->template_params;
+        o.events = rd->np->template_events; o.target = rd->template_target; o.forward = rd->forward; o.is_template = 1;
+        o.rna = R->rna; o.event_offset = rd->t_lo; o.ref_offset = rd->r_shift_t; o.pairs = c->pairs[0][j];
+        o.n_pairs = c->n_pairs[0][j]; o.score = c->score[j][0];
+        output_alignment(R->out_fmt, rd->post_path, rd->post_path2, &o);
+        if (R->two_d) {
+            o.sm = &R->smc; o.npp = rd->np->complement_params; o.events = rd->np->complement_events;
+            o.target = rd->complement_target; o.is_template = 0; o.event_offset = rd->c_lo; o.ref_offset = rd->r_shift_c;
+            o.pairs = c->pairs[1][j]; o.n_pairs = c->n_pairs[1][j]; o.score = c->score[j][1];
+            output_alignment(R->out_fmt, rd->post_path, rd->post_path2, &o);
+        }
+    }
+}
+
+static int cmp_str(const void *a, const void *b) { return strcmp(*(const char *const *) a, *(const char *const *) b); }
+
+/* appending from several threads is only safe when no two reads share an output file */
+static int outputs_distinct(const read_t *reads, const int64_t *who, int64_t n) {
+    const char **v = malloc(sizeof(char *) * (size_t) (2 * n + 1));
+    int64_t m = 0;
+    for (int64_t j = 0; j < n; j++) {
+        if (reads[who[j]].post_path) v[m++] = reads[who[j]].post_path;
+        if (reads[who[j]].post_path2) v[m++] = reads[who[j]].post_path2;
+    }
+    qsort(v, (size_t) m, sizeof(char *), cmp_str);
+    int ok = 1;
+    for (int64_t i = 1; i < m && ok; i++) ok = strcmp(v[i], v[i - 1]) != 0;
+    free(v);
+    return ok;
+}
+
 int main(int argc, char **argv) {
     run_t R;
     memset(&R, 0, sizeof(R));
@@ -614,9 +723,10 @@ int main(int argc, char **argv) {
 
     /* ---- host side of every read ---- */
     int64_t n_ok = 0;
-    for (int64_t i = 0; i < n_reads; i++) {
-        if (prepare_read(&R, &reads[i], !batch_mode) == 0) n_ok++;
-        else fprintf(stderr, "[signalMachine] ERROR: read %s skipped: %s\n", reads[i].label, reads[i].err);
+    {
+        prep_ctx_t pc = {&R, reads, !batch_mode};
+        parallel_for(n_reads, prep_one, &pc);
+        for (int64_t i = 0; i < n_reads; i++) n_ok += reads[i].failed ? 0 : 1;
     }
     if (R.hdp && !R.expect_mode) { /* the alignment branch sets the HDP expected values (impl/signalMachine.c:861-863), the expectation branch does not */
         set_hdp_expected(&R.smt);
@@ -666,8 +776,10 @@ int main(int argc, char **argv) {
         return n_ok == n_reads ? 0 : 1;
     }
 
-    sa_pair_t **pairs[2] = {NULL, NULL};
-    int64_t *n_pairs[2] = {NULL, NULL};
+    sa_pair_t **pairs_s[2] = {NULL, NULL};
+    int64_t *n_pairs_s[2] = {NULL, NULL};
+    sa_pair_t ***pairs = pairs_s;
+    int64_t **n_pairs = n_pairs_s;
     for (int s = 0; s < n_strands; s++) {
         pairs[s] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(sa_pair_t *));
         n_pairs[s] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(int64_t));
@@ -681,36 +793,18 @@ int main(int argc, char **argv) {
         }
     }
 
-    /* ---- outputs, read by read ---- */
+    /* ---- outputs: rendered in parallel (one file per read), summary lines in read order ---- */
+    double (*score)[2] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(*score));
+    {
+        out_job_t oc = {&R, reads, who, pairs, n_pairs, score};
+        if (outputs_distinct(reads, who, n_ok)) parallel_for(n_ok, output_one, &oc);
+        else for (int64_t j = 0; j < n_ok; j++) output_one(j, &oc);
+    }
     for (int64_t j = 0; j < n_ok; j++) {
         read_t *rd = &reads[who[j]];
-        if (R.out_fmt == 3 && rd->post_path2 == NULL) {
-            fprintf(stderr, "[signalMachine] ERROR: read %s: 'both' output format needs a second output file\n", rd->label);
-            rd->failed = 1;
-            continue;
-        }
-        double score[2] = {0, 0};
-        for (int s = 0; s < n_strands; s++) {
-            double tot = 0.0;
-            for (int64_t i = 0; i < n_pairs[s][j]; i++) tot += (double) pairs[s][j][i].prob_e7;
-            score[s] = 100.0 * tot / ((double) n_pairs[s][j] * PROB_1); /* scoreByPosteriorProbabilityIgnoringGaps :407-412 */
-        }
-        if (rd->post_path != NULL) {
-            out_ctx_t o;
-            o.label = rd->label; o.contig = rd->pA->contig1; o.sm = &R.smt; o.npp = rd->np->template_params;
-            o.events = rd->np->template_events; o.target = rd->template_target; o.forward = rd->forward; o.is_template = 1;
-            o.rna = R.rna; o.event_offset = rd->t_lo; o.ref_offset = rd->r_shift_t; o.pairs = pairs[0][j];
-            o.n_pairs = n_pairs[0][j]; o.score = score[0];
-            output_alignment(R.out_fmt, rd->post_path, rd->post_path2, &o);
-            if (R.two_d) {
-                o.sm = &R.smc; o.npp = rd->np->complement_params; o.events = rd->np->complement_events;
-                o.target = rd->complement_target; o.is_template = 0; o.event_offset = rd->c_lo; o.ref_offset = rd->r_shift_c;
-                o.pairs = pairs[1][j]; o.n_pairs = n_pairs[1][j]; o.score = score[1];
-                output_alignment(R.out_fmt, rd->post_path, rd->post_path2, &o);
-            }
-        }
-        fprintf(stdout, "%s %" PRId64 "\t%" PRId64 "(%f)\t", rd->label, rd->n_guide, n_pairs[0][j], score[0]);
-        if (R.two_d) fprintf(stdout, "%" PRId64 "(%f)\n", n_pairs[1][j], score[1]);
+        if (rd->failed) continue;
+        fprintf(stdout, "%s %" PRId64 "\t%" PRId64 "(%f)\t", rd->label, rd->n_guide, n_pairs[0][j], score[j][0]);
+        if (R.two_d) fprintf(stdout, "%" PRId64 "(%f)\n", n_pairs[1][j], score[j][1]);
         else fprintf(stdout, "\n");
         fprintf(stderr, "signalAlign - SUCCESS: finished alignment of query %s, exiting\n", rd->label);
         for (int s = 0; s < n_strands; s++) sa_free(pairs[s][j]);
