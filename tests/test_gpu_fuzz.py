@@ -1,0 +1,68 @@
+"""Randomised parity: many small jobs of random shape against the CPU oracle.
+
+Shapes drawn per job (fixed seed): model (5-mer / 6-mer ACGT / CpG ACEGT with ambiguous positions), read length from a
+handful of events to a few thousand (so that single-traceback, multi-traceback and split matrices all occur), anchors
+dropped at random (from dense to none at all), several parameter sets (band expansion, traceback overlap, threshold).
+SA_FLAG_EXACT must reproduce the oracle bit for bit; the default kernels must stay within the 1e-5 bar and keep the
+row order.  The reference's own tests cover these regimes one read at a time; this walks the product
+of them.
+"""
+import numpy as np
+import pytest
+
+import signalalign_amd as sa
+from signalalign_amd import synth
+
+import sa_cases as cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _jobs_for(model_path, rng, n, ambiguous):
+    alpha, k, t10, tab = synth.parse_model_table(model_path)
+    jobs = []
+    for i in range(n):
+        n_events = int(rng.choice([3, 9, 25, 60, 150, 400, 900, 1700, 2600]))
+        job = synth.make_read(int(rng.integers(0, 10 ** 6)), n_events, alpha, k, tab, cpg_ambiguous=ambiguous)
+        keep = rng.random()
+        if keep < 0.15:
+            m = np.zeros(len(job["ax"]), dtype=bool)            # no anchors at all: the whole matrix is one band
+        elif keep < 0.6:
+            m = rng.random(len(job["ax"])) < rng.uniform(0.02, 0.9)  # thinned at random
+        else:
+            m = np.ones(len(job["ax"]), dtype=bool)
+        if n_events > 1200 and rng.random() < 0.5 and len(job["ax"]) > 40:
+            lo = int(rng.integers(5, len(job["ax"]) // 2))       # a long anchor-free stretch
+            m[lo:lo + int(rng.integers(20, len(job["ax"]) // 3))] = False
+        job["ax"], job["ay"] = job["ax"][m], job["ay"][m]
+        jobs.append(job)
+    return alpha, k, t10, tab, jobs
+
+
+@pytest.mark.parametrize("model_path,ambiguous,seed", [(cases.MODEL_6MER, False, 11), (cases.MODEL_5MER, False, 12),
+                                                        (cases.MODEL_CPG, True, 13)])
+def test_random_shapes(oracle, model_path, ambiguous, seed):
+    rng = np.random.default_rng(seed)
+    alpha, k, t10, tab, jobs = _jobs_for(model_path, rng, 14, ambiguous)
+    pm = sa.Model.load(model_path)
+    om = oracle.Model(alpha, k, t10, tab)
+    amb_p = sa.default_ambig({"X": "CE"}) if ambiguous else None
+    amb_o = oracle.ambig_map({"X": "CE"}) if ambiguous else None
+    for expansion, trace_back, threshold, split in ((50, 100, 0.01, 3000 * 3000), (20, 30, 0.2, 3000 * 3000),
+                                                    (50, 100, 0.01, 250 * 250)):
+        p = sa.default_params(threshold=threshold, expansion=expansion, trace_back=trace_back, split=split)
+        op = cases.oracle_params(oracle, p)
+        exp = [cases.oracle_pairs(oracle, om, job, op, ambig=amb_o) for job in jobs]
+        for flags in (sa.FLAG_EXACT, 0, sa.FLAG_FORCE_GENERIC):
+            b = sa.Batch(pm, p, jobs, ambig=amb_p, flags=flags)
+            b.run()
+            for j in range(len(jobs)):
+                got = b.pairs(j)
+                if flags == sa.FLAG_EXACT:
+                    assert len(got) == len(exp[j]), (j, expansion, len(jobs[j]["events"]))
+                    for f in ("x", "y", "path", "kmer_id", "prob_e7"):
+                        assert np.array_equal(got[f], exp[j][f]), (j, f, expansion)
+                else:
+                    cases.compare_pairs(got, exp[j], 100, p.threshold)
+                    assert cases.same_order(got, exp[j])
+            b.close()
