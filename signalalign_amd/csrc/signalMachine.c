@@ -11,7 +11,8 @@
  * process and ONE GPU batch per strand model -- models are parsed once, HIP is initialised once, and the reads run
  * side by side on the device.  Manifest: one read per line, tab separated, '#' comments,
  *     label  npRead  cigar_file  posteriors_out  [posteriors_out2|-]  [sequence_name|-]  [template_expectations|-]  [complement_expectations|-]
- * Everything else (models, references, thresholds, output format) comes from the usual options.  Per read the same
+ * Everything else (models, references, thresholds, output format) comes from the usual options; --device <n> picks the
+ * GPU (one process per GPU, each with its share of the manifest: reads are independent).  Per read the same
  * files, stdout summary line and stderr SUCCESS line are produced as by one single-read invocation.
  */
 #define _GNU_SOURCE
@@ -589,6 +590,7 @@ int main(int argc, char **argv) {
     memset(&R, 0, sizeof(R));
     int64_t diag_expansion = 50, trace_back = 50;
     double threshold = 0.01;
+    int device = 0; /* --device: which GPU of the node (one process per GPU; reads shard across processes) */
     R.constraint_trim = 14;
     char *t_model = NULL, *c_model = NULL, *label = NULL, *npread_path = NULL, *cigar_path = NULL, *post_path = NULL;
     char *t_expect = NULL, *c_expect = NULL, *t_hdp = NULL, *c_hdp = NULL, *fwd_ref = NULL, *bwd_ref = NULL,
@@ -618,6 +620,7 @@ int main(int argc, char **argv) {
                                            {"posteriorProbsFile2", optional_argument, 0, 'i'},
                                            {"ambig_model", optional_argument, 0, 'a'},
                                            {"batch", required_argument, 0, 1000},
+                                           {"device", required_argument, 0, 1001},
                                            {0, 0, 0, 0}};
     for (;;) {
         int idx = 0;
@@ -649,6 +652,7 @@ int main(int argc, char **argv) {
             case 'g': if (optarg) sscanf(optarg, "%" SCNd64, &trace_back); break;
             case 'i': post_path2 = optarg ? strdup(optarg) : NULL; break;
             case 1000: manifest = strdup(optarg); break;
+            case 1001: device = atoi(optarg); break;
             default: usage(); return 1;
         }
     }
@@ -751,7 +755,7 @@ int main(int argc, char **argv) {
             for (int64_t j = 0; j < 9 * n_ok; j++) trans[j] = 0.001; /* transitionsPseudocount, :785 */
             sa_assignment_t **as = calloc((size_t) n_ok, sizeof(*as));
             int64_t *n_as = calloc((size_t) n_ok, sizeof(int64_t));
-            int rc = sa_expect_batch(sms[s]->model, &R.p, bj, n_ok, R.ambig, 0, 0, trans, lik, as, n_as);
+            int rc = sa_expect_batch(sms[s]->model, &R.p, bj, n_ok, R.ambig, device, 0, trans, lik, as, n_as);
             if (rc != SA_OK) {
                 fprintf(stderr, "signalMachine: expectations failed: %s\n", sa_strerror(rc));
                 return 1;
@@ -786,7 +790,7 @@ int main(int argc, char **argv) {
         if (n_ok == 0) continue;
         fprintf(stderr, s == 0 ? "signalAlign - starting template alignment\n" : "signalAlign - starting complement alignment\n");
         for (int64_t j = 0; j < n_ok; j++) bj[j] = reads[who[j]].jobs[s];
-        int rc = sa_align_batch(sms[s]->model, &R.p, bj, n_ok, R.ambig, 0, 0, pairs[s], n_pairs[s]);
+        int rc = sa_align_batch(sms[s]->model, &R.p, bj, n_ok, R.ambig, device, 0, pairs[s], n_pairs[s]);
         if (rc != SA_OK) {
             fprintf(stderr, "signalMachine: alignment failed: %s\n", sa_strerror(rc));
             return 1;
