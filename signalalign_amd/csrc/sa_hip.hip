@@ -55,6 +55,7 @@ struct DevPlan {
     const int *pk;
     const int *poff;
     const int *pid;
+    const int *px;        // reference position (region-relative x) of every pid entry: cell-path -> cell
     const double *xc;
     const double *ev;
     const sa_seg_t *segs;
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(64) void k_fwd_generic(DevPlan P, const int *region
     const sa_row_t *rows = P.rows + R->row_off;
     const int *poff = P.poff + R->poff_off;
     const int *pid = P.pid + R->pid_off;
+    const int *px = P.px + R->pid_off;
     const double *ev = P.ev + R->ev_off;
     double *F = P.F + 3 * R->f_base;
     const DevModel &m = P.m;
@@ -244,14 +246,18 @@ __global__ __launch_bounds__(64) void k_fwd_generic(DevPlan P, const int *region
         const double *P1 = use_ring ? lring + ((d - 1) % 3) * (long long) ring_cap * 3 : F + 3 * r1.foff;
         const double *P2 = use_ring ? lring + ((d + 1) % 3) * (long long) ring_cap * 3 : F + 3 * r2.foff;
         double *L0 = lring + (d % 3) * (long long) ring_cap * 3;
-        for (int i = lane; i < rd.width; i += 64) {
-            long long xmy = (long long) rd.xmyL + 2 * i;
-            long long x = x0 + i, y = d - x;
+        // one lane per cell-path of the diagonal (cells with many paths would otherwise serialise the whole wave)
+        const int g0 = poff[x0];
+        const int rowpaths = poff[x0 + rd.width] - g0;
+        for (int j = lane; j < rowpaths; j += 64) {
+            const int g = g0 + j;
+            const long long x = px[g];
+            const int p = g - poff[x];
+            const long long xmy = 2 * x - d, y = d - x;
             double e = y >= 1 ? ev[y - 1] : NEG_INF;
-            int np = poff[x + 1] - poff[x];
-            const int *idc = pid + poff[x];
-            double *cur = F + 3 * (rd.foff + poff[x] - poff[x0]);
-            double *lcur = L0 + 3 * (poff[x] - poff[x0]);
+            const int id = pid[g];
+            double *cur = F + 3 * (rd.foff + j);
+            double *lcur = L0 + 3 * j;
             long long i_lo = xmy - 1 - r1.xmyL, i_up = xmy + 1 - r1.xmyL, i_mid = xmy - r2.xmyL;
             bool has_lo = x >= 1 && i_lo >= 0 && (i_lo >> 1) < r1.width;
             bool has_up = i_up >= 0 && (i_up >> 1) < r1.width;
@@ -261,12 +267,11 @@ __global__ __launch_bounds__(64) void k_fwd_generic(DevPlan P, const int *region
             const double *mid = has_mid ? P2 + 3 * (poff[x - 1] - poff[x02]) : nullptr;
             int nq = x >= 1 ? poff[x] - poff[x - 1] : 0;
             const int *idq = x >= 1 ? pid + poff[x - 1] : nullptr;
-            for (int p = 0; p < np; p++) {
-                int id = idc[p];
+            {
                 double sm = NEG_INF, sx = NEG_INF, sy = NEG_INF;
                 double eM, eY;  // match / gapY emission of this cell-path
                 if (RELAX) {
-                    emit_gauss(xc4[poff[x] + p], e, eM, eY);
+                    emit_gauss(xc4[g], e, eM, eY);
                 } else {
                     eM = has_mid ? emit_ref(m, rp, id, e, 1) : NEG_INF;
                     eY = has_up ? emit_ref(m, rp, id, e, 0) : NEG_INF;
@@ -293,10 +298,10 @@ __global__ __launch_bounds__(64) void k_fwd_generic(DevPlan P, const int *region
                     sy = la_any<RELAX>(LT, sy, up[3 * p + 0] + (eP + m.t_my));
                     sy = la_any<RELAX>(LT, sy, up[3 * p + 2] + (eP + m.t_yy));
                 }
-                cur[3 * p + 0] = sm;
-                cur[3 * p + 1] = sx;
-                cur[3 * p + 2] = sy;
-                if (use_ring) { lcur[3 * p + 0] = sm; lcur[3 * p + 1] = sx; lcur[3 * p + 2] = sy; }
+                cur[0] = sm;
+                cur[1] = sx;
+                cur[2] = sy;
+                if (use_ring) { lcur[0] = sm; lcur[1] = sx; lcur[2] = sy; }
             }
         }
         __syncthreads();
@@ -348,6 +353,7 @@ __global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_id
     const long long rowcap = use_ring ? ring_cap : R->max_rowpaths;
     double *ring = use_ring ? lring : P.bscratch + S->bscratch_off;  // 3 rows x rowcap x 3
     const double4 *xc4 = reinterpret_cast<const double4 *>(P.xc) + R->pid_off;
+    const int *px = P.px + R->pid_off;
     const long long start = S->start, from = S->from, to = S->to;
     double end_m, end_x, end_y;  // endStateProb / raggedEndStateProb (impl/stateMachine.c:1145-1173)
     if (S->at_end && R->ragged_r) {
@@ -375,16 +381,17 @@ __global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_id
             x02 = (e + 2 + r2.xmyL) >> 1;
             B2 = ring + ((e + 2) % 3) * rowcap * 3;
         }
-        for (int i = lane; i < re.width; i += 64) {
-            long long xmy = (long long) re.xmyL + 2 * i;
-            long long x = x0 + i, y = e - x;
-            int np = poff[x + 1] - poff[x];
-            const int *idt = pid + poff[x];
-            double *cur = Be + 3 * (poff[x] - poff[x0]);
+        // one lane per cell-path of the diagonal
+        const int g0 = poff[x0];
+        const int rowpaths = poff[x0 + re.width] - g0;
+        for (int j = lane; j < rowpaths; j += 64) {
+            const int g = g0 + j;
+            const long long x = px[g];
+            const int q = g - poff[x];
+            const long long xmy = 2 * x - e, y = e - x;
+            double *cur = Be + 3 * j;
             if (e == start) {
-                for (int q = 0; q < np; q++) {
-                    cur[3 * q + 0] = end_m; cur[3 * q + 1] = end_x; cur[3 * q + 2] = end_y;
-                }
+                cur[0] = end_m; cur[1] = end_x; cur[2] = end_y;
                 continue;
             }
             long long i_mid = xmy - r2.xmyL, i_up = xmy - 1 - r1.xmyL, i_lo = xmy + 1 - r1.xmyL;
@@ -397,8 +404,8 @@ __global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_id
             int nn = (x + 1 <= R->lX) ? poff[x + 2] - poff[x + 1] : 0;
             const int *idn = (x + 1 <= R->lX) ? pid + poff[x + 1] : nullptr;
             double e_next = (y < R->lY) ? ev[y] : NEG_INF;  // event of matrix row y+1
-            for (int q = 0; q < np; q++) {
-                int idq = idt[q];
+            {
+                int idq = pid[g];
                 double tm = NEG_INF, tx = NEG_INF, ty = NEG_INF;
                 if (has_mid)
                     for (int p = 0; p < nn; p++)
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_id
                         }
                 if (has_up) {
                     double eP, eU;
-                    if (RELAX) emit_gauss(xc4[poff[x] + q], e_next, eU, eP);
+                    if (RELAX) emit_gauss(xc4[g], e_next, eU, eP);
                     else eP = emit_ref(m, rp, idq, e_next, 0);
                     double c = cu[3 * q + 2];
                     tm = la_any<RELAX>(LT, tm, c + (eP + m.t_my));
@@ -427,7 +434,7 @@ __global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_id
                             tm = la_any<RELAX>(LT, tm, c + (eP + m.t_mx));
                             tx = la_any<RELAX>(LT, tx, c + (eP + m.t_xx));
                         }
-                cur[3 * q + 0] = tm; cur[3 * q + 1] = tx; cur[3 * q + 2] = ty;
+                cur[0] = tm; cur[1] = tx; cur[2] = ty;
             }
         }
         __syncthreads();
@@ -802,7 +809,7 @@ struct sa_batch {
     hipStream_t stream;            // == cstream[0]
     hipStream_t cstream[2];        // compute streams; groups alternate between them
     // device buffers
-    sa_region_t *d_regions; sa_row_t *d_rows; int *d_pk; int *d_poff; int *d_pid; double *d_xc; double *d_ev;
+    sa_region_t *d_regions; sa_row_t *d_rows; int *d_pk; int *d_poff; int *d_pid; int *d_px; double *d_xc; double *d_ev;
     sa_seg_t *d_segs; sa_ck_t *d_cks;
     double *d_F; double *d_vbuf; sa_cand_t *d_cands; int *d_cand_count; int *d_overflow; double *d_totals;
     double *d_bscratch;
@@ -845,7 +852,7 @@ static DevPlan make_devplan(const sa_batch *b) {
     const sa_model_t *m = pl->model;
     DevPlan P;
     memset(&P, 0, sizeof(P));
-    P.regions = b->d_regions; P.rows = b->d_rows; P.pk = b->d_pk; P.poff = b->d_poff; P.pid = b->d_pid; P.xc = b->d_xc; P.ev = b->d_ev;
+    P.regions = b->d_regions; P.rows = b->d_rows; P.pk = b->d_pk; P.poff = b->d_poff; P.pid = b->d_pid; P.px = b->d_px; P.xc = b->d_xc; P.ev = b->d_ev;
     P.segs = b->d_segs; P.cks = b->d_cks; P.F = b->d_F; P.vbuf = b->d_vbuf; P.cands = b->d_cands;
     P.cand_count = b->d_cand_count; P.overflow = b->h_overflow; P.totals = b->d_totals; P.bscratch = b->d_bscratch;
     P.gsum = b->d_gsum; P.gmc = b->d_gmc;
@@ -878,7 +885,7 @@ static int upload(T **dst, const T *src, long long n) {
 void sa_batch_destroy(sa_batch_t *b) {
     if (!b) return;
     if (b->device >= 0) (void) hipSetDevice(b->device);
-    void *ptrs[] = {b->d_regions, b->d_rows, b->d_pk, b->d_poff, b->d_pid, b->d_xc, b->d_ev, b->d_segs, b->d_cks, b->d_F,
+    void *ptrs[] = {b->d_regions, b->d_rows, b->d_pk, b->d_poff, b->d_pid, b->d_px, b->d_xc, b->d_ev, b->d_segs, b->d_cks, b->d_F,
                     b->d_vbuf, b->d_cands, b->d_cand_count, b->d_overflow, b->d_totals, b->d_bscratch, b->d_tab6,
                     b->d_hdp_slot, b->d_hdp_y, b->d_hdp_slope, b->d_hdp_grid, b->d_hdp_tab, b->d_prob, b->d_seg_pass, b->d_seg_off,
                     b->d_out, b->d_ids, b->d_gsum, b->d_gmc};
@@ -932,7 +939,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     b->h_seg_off = nullptr;
     b->h_overflow = nullptr;
     b->ran = false;
-    b->d_regions = nullptr; b->d_rows = nullptr; b->d_pk = nullptr; b->d_poff = nullptr; b->d_pid = nullptr; b->d_xc = nullptr;
+    b->d_regions = nullptr; b->d_rows = nullptr; b->d_pk = nullptr; b->d_poff = nullptr; b->d_pid = nullptr; b->d_px = nullptr; b->d_xc = nullptr;
     b->d_ev = nullptr; b->d_segs = nullptr; b->d_cks = nullptr; b->d_F = nullptr; b->d_vbuf = nullptr;
     b->d_cands = nullptr; b->d_cand_count = nullptr; b->d_overflow = nullptr; b->d_totals = nullptr;
     b->d_bscratch = nullptr; b->d_tab6 = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr;
@@ -973,6 +980,17 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     TRY(upload(&b->d_pk, pl->pk, pl->n_pk));
     TRY(upload(&b->d_poff, pl->poff, pl->n_poff));
     TRY(upload(&b->d_pid, pl->pid, pl->n_pid));
+    {   // cell-path -> reference position, for the memory-resident kernels (one lane per cell-path)
+        std::vector<int> px((size_t) (pl->n_pid > 0 ? pl->n_pid : 1), 0);
+        for (long long r = 0; r < pl->n_regions; r++) {
+            const sa_region_t *R = &pl->regions[r];
+            if (R->kind != SA_KIND_GENERIC) continue;
+            const int32_t *po = pl->poff + R->poff_off;
+            for (long long x = 0; x <= R->lX; x++)
+                for (int g = po[x]; g < po[x + 1]; g++) px[(size_t) (R->pid_off + g)] = (int) x;
+        }
+        TRY(upload(&b->d_px, px.data(), pl->n_pid));
+    }
     TRY(upload(&b->d_xc, pl->xc, 4 * pl->n_pid));
     {   // one readable element of padding: the kernels clamp event indices to 0 even for reads without events
         std::vector<double> evp((size_t) pl->n_ev + 8, 0.0);
