@@ -69,11 +69,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    device = 0
+    backend = os.environ.get("SA_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N > 1 path on a box with one GPU
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl")  # RCCL; only used for the barrier and the max-over-ranks
+        device = local_rank % max(torch.cuda.device_count(), 1)  # identity on a full node
+        torch.cuda.set_device(device)
+        dist.init_process_group(backend=backend)  # RCCL; only used for the barrier and the max-over-ranks
     import signalalign_amd as sa
     from signalalign_amd import synth
 
@@ -98,7 +101,7 @@ def main():
     jobs = [synth.make_read(int(i), args.events, alpha, k, tab, **read_kw) for i in mine]
     n_events_total = sum(len(j["events"]) for j in jobs)
     t_create = time.perf_counter()
-    batch = sa.Batch(pm, params, jobs, ambig=ambig, device=local_rank if world > 1 else 0)  # planning + upload to HBM
+    batch = sa.Batch(pm, params, jobs, ambig=ambig, device=device)  # planning + upload to HBM
     t_create = time.perf_counter() - t_create
     st0 = batch.stats()
     cells = st0.cells_forward + st0.cells_backward
@@ -126,10 +129,11 @@ def main():
     n_pairs = sum(batch.n_pairs(j) for j in range(len(jobs)))
     if dist is not None:
         import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tdev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tot = torch.tensor([cells, float(n_events_total)], dtype=torch.float64, device="cuda")
+        tot = torch.tensor([cells, float(n_events_total)], dtype=torch.float64, device=tdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         cells_all, events_all = float(tot[0].item()), float(tot[1].item())
     else:
