@@ -226,11 +226,12 @@ __global__ __launch_bounds__(64) void k_fwd_generic(DevPlan P, const int *region
             int np = poff[x + 1] - poff[x];
             double *c = F + 3 * (r0.foff + poff[x] - poff[x0]);
             double *lc = lring + 3 * (poff[x] - poff[x0]);
+            const bool row_in_lds = use_ring && poff[x0 + r0.width] - poff[x0] <= ring_cap;
             for (int p = 0; p < np; p++) {
                 c[3 * p + 0] = R->ragged_l ? NEG_INF : 0.0;
                 c[3 * p + 1] = R->ragged_l ? 0.0 : NEG_INF;
                 c[3 * p + 2] = R->ragged_l ? 0.0 : NEG_INF;
-                if (use_ring) { lc[3 * p + 0] = c[3 * p + 0]; lc[3 * p + 1] = c[3 * p + 1]; lc[3 * p + 2] = c[3 * p + 2]; }
+                if (row_in_lds) { lc[3 * p + 0] = c[3 * p + 0]; lc[3 * p + 1] = c[3 * p + 1]; lc[3 * p + 2] = c[3 * p + 2]; }
             }
         }
     }
@@ -243,12 +244,16 @@ __global__ __launch_bounds__(64) void k_fwd_generic(DevPlan P, const int *region
         long long x01 = (d - 1 + r1.xmyL) >> 1;
         long long x02 = d >= 2 ? ((d - 2 + r2.xmyL) >> 1) : 0;
         // previous diagonals: the LDS ring, or the forward storage itself
-        const double *P1 = use_ring ? lring + ((d - 1) % 3) * (long long) ring_cap * 3 : F + 3 * r1.foff;
-        const double *P2 = use_ring ? lring + ((d + 1) % 3) * (long long) ring_cap * 3 : F + 3 * r2.foff;
+        // a diagonal lives in the ring if it fits (ring_cap cell-paths); the few that do not are read back from F
+        const bool lds1 = use_ring && poff[x01 + r1.width] - poff[x01] <= ring_cap;
+        const bool lds2 = use_ring && d >= 2 && poff[x02 + r2.width] - poff[x02] <= ring_cap;
+        const double *P1 = lds1 ? lring + ((d - 1) % 3) * (long long) ring_cap * 3 : F + 3 * r1.foff;
+        const double *P2 = lds2 ? lring + ((d + 1) % 3) * (long long) ring_cap * 3 : F + 3 * r2.foff;
         double *L0 = lring + (d % 3) * (long long) ring_cap * 3;
         // one lane per cell-path of the diagonal (cells with many paths would otherwise serialise the whole wave)
         const int g0 = poff[x0];
         const int rowpaths = poff[x0 + rd.width] - g0;
+        const bool lds0 = use_ring && rowpaths <= ring_cap;
         for (int j = lane; j < rowpaths; j += 64) {
             const int g = g0 + j;
             const long long x = px[g];
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(64) void k_fwd_generic(DevPlan P, const int *region
                 cur[0] = sm;
                 cur[1] = sx;
                 cur[2] = sy;
-                if (use_ring) { lcur[0] = sm; lcur[1] = sx; lcur[2] = sy; }
+                if (lds0) { lcur[0] = sm; lcur[1] = sx; lcur[2] = sy; }
             }
         }
         __syncthreads();
@@ -350,8 +355,9 @@ __global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_id
     const double *F = P.F + 3 * R->f_base;
     const DevModel &m = P.m;
     ReadPar rp = {R->scale, R->shift, R->var, R->lvar};
-    const long long rowcap = use_ring ? ring_cap : R->max_rowpaths;
-    double *ring = use_ring ? lring : P.bscratch + S->bscratch_off;  // 3 rows x rowcap x 3
+    // backward rows: the LDS ring for diagonals of at most ring_cap cell-paths, the global ring for the others
+    const long long grow = R->max_rowpaths;
+    double *gring = P.bscratch + S->bscratch_off;  // 3 rows x grow x 3
     const double4 *xc4 = reinterpret_cast<const double4 *>(P.xc) + R->pid_off;
     const int *px = P.px + R->pid_off;
     const long long start = S->start, from = S->from, to = S->to;
@@ -367,19 +373,23 @@ __global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_id
     for (long long e = start; e > to; e--) {
         sa_row_t re = rows[e];
         long long x0 = (e + re.xmyL) >> 1;
-        double *Be = ring + (e % 3) * rowcap * 3;
+        auto row_ptr = [&](long long row, long long xfirst, int width) -> double * {
+            const bool in_lds = use_ring && poff[xfirst + width] - poff[xfirst] <= ring_cap;
+            return in_lds ? lring + (row % 3) * (long long) ring_cap * 3 : gring + (row % 3) * grow * 3;
+        };
+        double *Be = row_ptr(e, x0, re.width);
         sa_row_t r1 = {0, 0, 0, 0, 0}, r2 = {0, 0, 0, 0, 0};
         long long x01 = 0, x02 = 0;
         const double *B1 = nullptr, *B2 = nullptr;
         if (e + 1 <= start) {
             r1 = rows[e + 1];
             x01 = (e + 1 + r1.xmyL) >> 1;
-            B1 = ring + ((e + 1) % 3) * rowcap * 3;
+            B1 = row_ptr(e + 1, x01, r1.width);
         }
         if (e + 2 <= start) {
             r2 = rows[e + 2];
             x02 = (e + 2 + r2.xmyL) >> 1;
-            B2 = ring + ((e + 2) % 3) * rowcap * 3;
+            B2 = row_ptr(e + 2, x02, r2.width);
         }
         // one lane per cell-path of the diagonal
         const int g0 = poff[x0];
@@ -952,7 +962,12 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
         long long cap = 0;
         for (long long r = 0; r < pl->n_regions; r++)
             if (pl->regions[r].kind == SA_KIND_GENERIC && pl->regions[r].max_rowpaths > cap) cap = pl->regions[r].max_rowpaths;
-        if ((LA_TAB_DOUBLES + 9 * cap) * 8 <= 64 * 1024) b->ring_cap = (int) cap;  // otherwise the rows stay in global memory
+        // diagonals wider than the ring go through global memory one by one; a small ring keeps many waves per CU
+        long long lim = 128;
+        const char *envr = getenv("SA_RING_CAP");  // tuning hook
+        if (envr && atoll(envr) > 0) lim = atoll(envr);
+        if (lim > 900) lim = 900;                   // 64 KB of dynamic LDS
+        b->ring_cap = (int) (cap < lim ? cap : lim);
     }
     b->cand_alloc = 0; b->out_alloc = 0;
     b->h_pairs = nullptr; b->h_pairs_cap = 0; b->n_pairs_total = 0;
