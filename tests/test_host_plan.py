@@ -169,3 +169,36 @@ def test_threaded_planner_is_deterministic():
     g1 = sa.plan_digest(pm, p, jobs, flags=sa.FLAG_FORCE_GENERIC, threads=1)[1]
     g4 = sa.plan_digest(pm, p, jobs, flags=sa.FLAG_FORCE_GENERIC, threads=4)[1]
     assert g1 == g4
+
+
+def test_planner_error_codes_and_empty_batch():
+    # the reference asserts / aborts on these (impl/pairwiseAligner.c:1460-1464, :195-246); the library returns codes
+    pm = sa.Model.load(cases.MODEL_6MER)
+    p = sa.default_params()
+    info, digest = sa.plan_digest(pm, p, [], threads=1)           # nothing to align is not an error
+    assert (info.n_regions, info.n_segments) == (0, 0)
+    job = cases.synthetic_jobs(cases.MODEL_6MER, 1, 300)[0]
+    bad = dict(job)
+    bad["ax"], bad["ay"] = job["ax"][::-1].copy(), job["ay"][::-1].copy()   # anchors must increase in both coordinates
+    with pytest.raises(sa.SaError) as ei:
+        sa.plan_digest(pm, p, [bad], threads=1)
+    assert ei.value.code == -5                                    # SA_EBAND
+    out_of_range = dict(job)
+    out_of_range["ax"] = job["ax"] + 10 ** 6
+    with pytest.raises(sa.SaError) as ei:
+        sa.plan_digest(pm, p, [out_of_range], threads=1)
+    assert ei.value.code == -5
+    for kw in (dict(trace_back=1000), dict(expansion=51), dict(threshold=1.5)):
+        q = sa.default_params(**kw)
+        if "expansion" in kw:
+            q.diagonal_expansion = 51                             # default_params() would round it up, as signalMachine does
+        with pytest.raises(sa.SaError) as ei:
+            sa.plan_digest(pm, q, [job], threads=1)
+        assert ei.value.code == -1, kw                            # SA_EINVAL
+    # the first failing job in job order decides, whatever the thread count
+    jobs = cases.synthetic_jobs(cases.MODEL_6MER, 12, 200)
+    jobs[7] = bad
+    for t in (1, 3):
+        with pytest.raises(sa.SaError) as ei:
+            sa.plan_digest(pm, p, jobs, threads=t)
+        assert ei.value.code == -5
