@@ -250,3 +250,39 @@ def test_round_trip_properties_full_size(oracle):
     got2, _ = _run(pm, p, jobs)
     for a, b in zip(got, got2):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name,npread,model,nhdp", [("r9_5mer", "c2925_ecoli_ch34_read1023.npRead", cases.MODEL_5MER, None),
+                                                     ("r94_6mer", "r9p4_oneD.npRead", cases.MODEL_6MER, None),
+                                                     ("r73_acegot", "ZymoC_ch_1_file1.npRead", cases.MODEL_R73, None),
+                                                     ("r73_acegot_hdp", "ZymoC_ch_1_file1.npRead", cases.MODEL_R73, cases.NHDP)])
+def test_against_committed_expected_outputs(name, npread, model, nhdp):
+    # no oracle in this test: inputs from the reference's fixture files, expected pairs from tests/golden/expected
+    want = np.load(os.path.join(cases.GOLDEN, "expected", name + ".npz"))
+    pm = sa.Model.load(model, nhdp)
+    if nhdp:
+        pm.set_to_hdp_expected_values()
+    # the job as make_expected.py built it, from the stored anchors and parameters
+    lines = open(os.path.join(cases.GOLDEN, "npReads", npread)).read().split("\n")
+    read = lines[2].strip()
+    ev = np.array(lines[7].split(), dtype=np.float64).reshape(-1, 4)
+    emap = np.array(lines[3].split(), dtype=np.int64)
+    L = len(read)
+    lo, hi = int(emap[0]), int(emap[L - 1])
+    # drift correction of the events is part of the parameter estimation: redo it through the library
+    plain = sa.Model.load(model)                      # estimation starts from the table as loaded (no HDP means yet)
+    est = sa.estimate_params(plain, np.array(plain.table5(), dtype=np.float64, copy=True), emap, ev, read)
+    assert abs(est["scale"] - float(want["scale"])) < 1e-12 and abs(est["var"] - float(want["var"])) < 1e-12
+    job = dict(ref=read, events=np.ascontiguousarray(ev[lo:hi]), ax=want["ax"], ay=want["ay"], scale=float(want["scale"]),
+               shift=float(want["shift"]), var=float(want["var"]))
+    p = sa.default_params(threshold=float(want["threshold"]))
+    exp = np.zeros(len(want["x"]), dtype=sa.PAIR_DTYPE)
+    for f in ("x", "y", "path", "kmer_id", "prob_e7"):
+        exp[f] = want[f]
+    if not nhdp:
+        got, _ = _run(pm, p, [job], flags=sa.FLAG_EXACT)
+        assert np.array_equal(got[0], exp)               # bit-identical rows, values and order
+    got, st = _run(pm, p, [job])
+    assert st.n_fast_regions == st.n_regions
+    cases.compare_pairs(got[0], exp, TOL_E7, p.threshold)
+    assert cases.same_order(got[0], exp)

@@ -185,3 +185,20 @@ def test_nanopore_read_fixtures(oracle, golden):
     # tests/signalPairwiseAlignerTest.c:209-216 test_1dNanoporeRead
     r = oracle.parse_npread(os.path.join(golden, "npReads", "r9p4_oneD.npRead"))
     assert r["twoD"] == 0 and r["n_template_events"] == 10922
+
+
+def test_oracle_reproduces_committed_expected_outputs(oracle, golden):
+    GOLDEN = golden
+    # tests/golden/expected/*.npz were written by tests/golden/make_expected.py; the oracle must keep producing them
+    # bit for bit (guards the checker itself against drift; the GPU suite compares the HIP path with the same files)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_expected", os.path.join(GOLDEN, "make_expected.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    for name, npread, model_path, nhdp in mk.CASES:
+        want = np.load(os.path.join(GOLDEN, "expected", name + ".npz"))
+        got = mk.compute(name, npread, model_path, nhdp)
+        for key in ("scale", "shift", "var"):
+            assert float(got[key]) == float(want[key]), (name, key)
+        for key in ("ax", "ay", "x", "y", "path", "kmer_id", "prob_e7"):
+            assert np.array_equal(got[key], want[key]), (name, key)
