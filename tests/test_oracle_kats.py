@@ -202,3 +202,26 @@ def test_oracle_reproduces_committed_expected_outputs(oracle, golden):
             assert float(got[key]) == float(want[key]), (name, key)
         for key in ("ax", "ay", "x", "y", "path", "kmer_id", "prob_e7"):
             assert np.array_equal(got[key], want[key]), (name, key)
+
+
+def test_scale_params_from_strand_read_and_drift(oracle, golden):
+    # tests/stateMachineTests.c:408-421 test_nanoporeScaleParamsFromStrandRead: the parameters estimated from the
+    # strand read's own event map land within 5 % (scale, shift) and 50 % (var) of the ones in the .npRead header;
+    # :423-440 test_adjustForDrift: afterwards every event mean is the original minus drift * start time, exactly.
+    def pct(a, b):
+        return 100.0 * abs(a - b) / abs(b)
+    r = oracle.parse_npread(os.path.join(golden, "npReads", "ZymoC_ch_1_file1.npRead"))
+    om = oracle.Model.from_file(os.path.join(golden, "models", "testModelR73_acegot_template.model"))
+    ev = r["template_events"].copy()
+    est = oracle.estimate_params(om, r["template_strand_event_map"], ev, r["template_read"])
+    hdr = r["template_params"]
+    assert pct(est["scale"], hdr["scale"]) < 5.0
+    assert pct(est["shift"], hdr["shift"]) < 5.0
+    assert pct(est["var"], hdr["var"]) < 50.0
+    r9 = oracle.parse_npread(os.path.join(golden, "npReads", "c2925_ecoli_ch34_read1023.npRead"))
+    om9 = oracle.Model.from_file(os.path.join(golden, "models", "testModelR9_5mer_acgt_template.model"))
+    ev9 = r9["template_events"].copy()
+    est9 = oracle.estimate_params(om9, r9["template_strand_event_map"], ev9, r9["template_read"])
+    orig = r9["template_events"]
+    assert np.array_equal(ev9[:, 0], orig[:, 0] - est9["drift"] * orig[:, 3])
+    assert np.array_equal(ev9[:, 1:], orig[:, 1:])
