@@ -225,3 +225,38 @@ def test_scale_params_from_strand_read_and_drift(oracle, golden):
     orig = r9["template_events"]
     assert np.array_equal(ev9[:, 0], orig[:, 0] - est9["drift"] * orig[:, 3])
     assert np.array_equal(ev9[:, 1:], orig[:, 1:])
+
+
+def test_path_legal_transitions_and_substituted_kmers(oracle, golden):
+    # tests/variableOrderPairwiseAlignerTests.c:107-123 test_pathLegalTransitions: AAETTT -> AETTTC is legal,
+    # AAETTT -> ACTTTC is not (k-1 suffix must equal k-1 prefix; the NULL k-mer is legal with everything);
+    # :170-180 test_substitutedKmers: ATGXAX with the pattern "CE" is ATGCAE.
+    m = oracle.Model.from_file(os.path.join(golden, "models", "testModelR73_acegot_template.model"))
+    A, k = m.n_alpha, m.k
+
+    def legal(a, b):  # the arithmetic the kernels use (sa_hip.hip:legal_step)
+        if a is None or b is None:
+            return True
+        return m.kmer_id(a) % A ** (k - 1) == m.kmer_id(b) // A
+    assert legal(None, "AAETTT") and legal("AAETTT", None)
+    assert legal("AAETTT", "AETTTC")
+    assert not legal("AAETTT", "ACTTTC")
+    n, ids = m.expand_paths("ATGXAX", oracle.ambig_map({"X": "CE"}))
+    assert n == 4 and ids[1] == m.kmer_id("ATGCAE")
+    # and the DP itself obeys it: an ambiguous reference only yields pairs whose path k-mers chain legally
+    r = oracle.parse_npread(os.path.join(golden, "npReads", "ZymoC_ch_1_file1.npRead"))
+    ref = r["template_read"][:120].replace("C", "X", 3)
+    ev = r["template_events"][:int(r["template_strand_event_map"][119])]
+    pairs = oracle.align(m, ref, ev, [], [], oracle.default_params(threshold=0.005), ambig=oracle.ambig_map({"X": "CE"}))
+    by_x = {}
+    for p in pairs:
+        by_x.setdefault(int(p["x"]), set()).add(int(p["kmer_id"]))
+    checked = 0
+    for x, ids_x in by_x.items():
+        if x + 1 in by_x:
+            # every reported k-mer at x+1 has at least one legal predecessor among the k-mers of position x
+            pre = set(i % A ** (k - 1) for i in m.expand_paths(ref[x:x + k], oracle.ambig_map({"X": "CE"}))[1])
+            for j in by_x[x + 1]:
+                assert j // A in pre
+                checked += 1
+    assert checked >= 3
