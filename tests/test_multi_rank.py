@@ -36,3 +36,22 @@ def test_two_rank_gloo_run():
     pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert pr.returncode == 0, pr.stdout + pr.stderr
     assert "GLOO_OK" in pr.stdout
+
+
+def test_manifest_split_for_the_batch_runner(tmp_path):
+    # the CLI front door shards a manifest the same way the library shards reads: every read exactly once, balanced
+    from signalalign_amd import batch_runner
+    lines = []
+    for i in range(37):
+        p = tmp_path / ("r%d.npRead" % i)
+        p.write_bytes(b"x" * (1000 + 137 * ((i * 7) % 11)))
+        lines.append("\t".join(["read%d" % i, str(p), "g.cigar", "out%d.tsv" % i]))
+    lines.append("\t".join(["gone", str(tmp_path / "missing.npRead"), "g.cigar", "x.tsv"]))
+    mf = tmp_path / "m.tsv"
+    mf.write_text("# header comment\n" + "\n".join(lines) + "\n\n")
+    got = batch_runner.read_manifest(str(mf))
+    assert got == lines
+    parts = batch_runner.split_manifest(got, 8)
+    assert sorted(sum(parts, [])) == sorted(lines) and len(parts) == 8
+    sizes = [sum(os.path.getsize(ln.split("\t")[1]) for ln in part if os.path.exists(ln.split("\t")[1])) for part in parts]
+    assert max(sizes) - min(sizes) <= 2500
