@@ -51,6 +51,59 @@ def cpu_baseline(alpha, k, t10, tab, n_events, reads_per_thread, first_index):
                 events_per_s=float(sum(len(j["events"]) for j in jobs) / dt))
 
 
+def bench_event_align(args):
+    """the event <-> k-mer pre-alignment (adaptive banded Viterbi), same reads as the headline
+    workload.  One step = one sa_event_align_batch call (upload, kernel, traceback, download)."""
+    import signalalign_amd as sa
+    from signalalign_amd import synth
+    from oracle import sa_oracle_py as oracle
+    from concurrent.futures import ThreadPoolExecutor
+    alpha, k, t10, tab = synth.parse_model_table(MODEL)
+    pm = sa.Model.load(MODEL)
+    jobs = []
+    for i in range(args.reads):
+        r = synth.make_read(i, args.events, alpha, k, tab)
+        ev = np.ascontiguousarray(np.asarray(r["events4"])[:, 0])
+        sh, sc = sa.scalings_mom(pm, r["ref"], ev)
+        jobs.append(dict(sequence=r["ref"], event_mean=ev, scale=sc, shift=sh, var=1.0))
+    stats = {}
+    for _ in range(args.warmup):
+        sa.event_align_batch(pm, jobs, stats=stats)
+    t0 = time.perf_counter()
+    kms = 0.0
+    for _ in range(args.steps):
+        out = sa.event_align_batch(pm, jobs, stats=stats)
+        kms += stats["kernel_ms"]
+    dt = time.perf_counter() - t0
+    cells = float(stats["cells"].sum())
+    K = args.steps
+    res = {"metric": "event_align_band_cell_updates_per_s", "value": cells * K / dt, "unit": "cell_updates/s", "n_gpus": 1,
+           "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32 scores / f64 emissions", "data": "synthetic",
+           "config": {"workload": "adaptive banded event alignment (impl/eventAligner.c:899-1235), %d synthetic %d-event reads, "
+                                  "bandwidth 100" % (args.reads, args.events),
+                      "kernel_ms": kms / K, "kernel_cell_updates_per_s": cells / (kms / K * 1e-3),
+                      "reads_aligned": int(sum(1 for o in out if o[2] == 0)), "cells_per_read": cells / max(len(jobs), 1)}}
+    if not args.no_cpu_baseline:
+        om = oracle.Model(alpha, k, t10, tab)
+        cores = min(os.cpu_count() or 1, 16)
+        sample = jobs[:cores * 4]
+
+        def one(j):
+            m = oracle.Model(alpha, k, t10, tab)   # the read parameters live in the model object: one per thread call
+            m.set_read_params(j["scale"], j["shift"], 1.0)
+            return len(oracle.event_align(m, j["event_mean"], oracle.kmer_ids_of(m, j["sequence"]))[0])
+        t1 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(one, sample))
+        dtc = time.perf_counter() - t1
+        res["cpu_baseline"] = {"value": cells / len(jobs) * len(sample) / dtc, "unit": "cell_updates/s", "cores": cores,
+                               "kind": "port", "sample": "%d reads, oracle/sa_oracle.c:sao_event_align, %d threads, %.1f s "
+                                                        "wall (includes the Python k-mer id loop)" % (len(sample), cores, dtc)}
+        del om
+    print(json.dumps(res))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,7 +111,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=2000, help="reads per GPU (BASELINE configs[1]: 2000)")
     ap.add_argument("--events", type=int, default=5000, help="events per read (BASELINE configs[1]: 5000)")
-    ap.add_argument("--workload", choices=["gaussian", "cpg", "hdp"], default="gaussian",
+    ap.add_argument("--workload", choices=["gaussian", "cpg", "hdp", "event_align"], default="gaussian",
                     help="gaussian = BASELINE configs[1] (the headline); cpg = configs[2] (ACEGT model, every CpG cytosine "
                          "ambiguous C/E); hdp = configs[3] (HDP emissions).  The last two run on the memory-resident kernels.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -80,6 +133,8 @@ def main():
     import signalalign_amd as sa
     from signalalign_amd import synth
 
+    if args.workload == "event_align":
+        return bench_event_align(args)
     gold = os.path.join(ROOT, "tests", "golden", "models")
     model_path, nhdp, ambig, read_kw, wl_name = MODEL, None, None, {}, "BASELINE configs[1]: R9.4 6-mer template Gaussian HMM"
     if args.workload == "cpg":

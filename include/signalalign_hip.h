@@ -167,6 +167,33 @@ int sa_plan_describe(const sa_model_t *m, const sa_params_t *p, const sa_job_t *
                      int64_t *rows3_out, int64_t rows_cap,         /* region,xmyL,xmyR per diagonal      */
                      int64_t *segs4_out, int64_t segs_cap);        /* region,start,from,to per traceback */
 
+/* ---- event <-> k-mer pre-alignment (the step upstream of the pair-HMM) ------------
+ * adaptive_banded_simple_event_align (impl/eventAligner.c:899-1235): adaptive banded Viterbi of a raw event table
+ * against the k-mers of the basecalled sequence, with the state machine's MeanOnly match emission
+ * (impl/eventAligner.c:1245-1247).  One wave per read on the GPU.  pairs_out[j] (malloc'd, sa_free) holds the
+ * struct AlignedPair list {ref_pos = k-mer index, read_pos = event index} in ascending order; it is empty and
+ * status_out[j] != 0 when the reference would have rejected the alignment (bit 0: average log emission < -5.2, bit 1:
+ * first/last k-mer not reached, bit 2: more than 50 skipped k-mers in a row, bit 3: more than 5 events per k-mer).
+ * Parity of this entry point is pinned by the CPU restatement only (the reference's tests of it need fast5 files). */
+typedef struct sa_ea_job {
+    const char *sequence;      /* nucleotides; a k-mer at every position (build_kmer_list, impl/eventAligner.c:755-782) */
+    int64_t seq_len;
+    const double *event_mean;  /* event_t.mean of the raw event table                                                  */
+    int64_t n_events;
+    double scale, shift, var;  /* update_SignalMachineWithNanoporeParameters (:845-849); see sa_scalings_mom           */
+} sa_ea_job_t;
+typedef struct sa_ea_pair {
+    int32_t kmer_idx, event_idx;
+} sa_ea_pair_t;
+/* estimate_scalings_using_mom (impl/eventAligner.c:784-843): method of moments; the reference then uses var = 1 */
+int sa_scalings_mom(const sa_model_t *m, const char *sequence, int64_t seq_len, const double *event_mean,
+                    int64_t n_events, double *shift_out, double *scale_out);
+/* cells_out[j] (may be NULL): band cells filled for job j (the reference's `fills`); kernel_ms_out (may be NULL):
+ * HIP-event time of the kernel */
+int sa_event_align_batch(const sa_model_t *m, const sa_ea_job_t *jobs, int64_t n_jobs, int device, unsigned flags,
+                         sa_ea_pair_t **pairs_out, int64_t *n_pairs_out, int32_t *status_out, double *cells_out,
+                         double *kernel_ms_out);
+
 /* Plans a whole batch on the host (no GPU needed) with `threads` planner threads (0 = as sa_batch_create would) and
  * returns aggregate geometry plus a 64-bit FNV-1a digest over every array that would be uploaded.  The digest must
  * not depend on the number of threads: the CPU test-suite checks exactly that. */

@@ -1516,3 +1516,154 @@ int sao_align_batch_mt(const sao_model_t *m, const sao_job_t *jobs, int64_t n_jo
     free(th);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Event <-> k-mer pre-alignment: adaptive_banded_simple_event_align2,
+ * impl/eventAligner.c:899-1235 -- Suzuki-Kasahara adaptive banding as used by nanopolish: bands are
+ * anti-diagonals of the (event+1) x (k-mer+1) matrix, 100 cells wide; each new band steps right or down
+ * from the previous one depending on which end of it scores higher; Viterbi scores with three moves
+ * (step = diagonal, stay = same k-mer next event, skip = next k-mer same event), kept as floats; the
+ * path is traced back from the best (event, last k-mer) cell and rejected by three quality checks.
+ * kmer_ids[i] = kmer_id of position i (emission: the model's match emission, impl/eventAligner.c:1245-1247).
+ * Returns the number of pairs (ascending), 0 when the alignment is rejected, < 0 on error; *status: 0 ok,
+ * bit 0 average emission too low, bit 1 not spanned, bit 2 gap too long, bit 3 more than 5 events per k-mer.
+ * PARITY UNPINNED: the reference's tests of this function read fast5 files (tests/eventAlignerTests.c:223-320,
+ * :404-430), which cannot be opened here; only the restatement itself stands behind these results.
+ * ---------------------------------------------------------------------------------------------- */
+#define EA_BW 100
+int64_t sao_event_align(const sao_model_t *m, const double *event_mean, int64_t n_events, const int32_t *kmer_ids,
+                        int64_t n_kmers, int32_t **kmer_idx_out, int32_t **event_idx_out, int *status) {
+    if (status) *status = 0;
+    *kmer_idx_out = NULL;
+    *event_idx_out = NULL;
+    if (n_events <= 0 || n_kmers <= 0) return -1;
+    const int half = EA_BW / 2;
+    const double events_per_kmer = (double) n_events / (double) n_kmers;
+    const double p_stay = 1 - (1 / (events_per_kmer + 1));
+    const double lp_skip = log(1e-10), lp_stay = log(p_stay);
+    const double lp_step = log(1.0 - exp(lp_skip) - exp(lp_stay));
+    const double lp_trim = log(0.01);
+    const int64_t n_bands = (n_events + 1) + (n_kmers + 1);
+    double *score = malloc(sizeof(double) * (size_t) n_bands * EA_BW);
+    uint8_t *trace = calloc((size_t) n_bands * EA_BW, 1);
+    int32_t *ll_ev = malloc(sizeof(int32_t) * (size_t) n_bands), *ll_km = malloc(sizeof(int32_t) * (size_t) n_bands);
+    if (!score || !trace || !ll_ev || !ll_km) { free(score); free(trace); free(ll_ev); free(ll_km); return -2; }
+    for (int64_t i = 0; i < n_bands * EA_BW; i++) score[i] = LOG_ZERO;
+#define SC(b, o) score[(int64_t) (b) * EA_BW + (o)]
+#define TR(b, o) trace[(int64_t) (b) * EA_BW + (o)]
+#define VALID(o) ((o) >= 0 && (o) < EA_BW)
+    enum { FROM_D = 0, FROM_U = 1, FROM_L = 2 };
+    ll_ev[0] = half - 1; ll_km[0] = -1 - half;
+    ll_ev[1] = ll_ev[0] + 1; ll_km[1] = ll_km[0];                       /* band 1: one step down */
+    SC(0, -1 - ll_km[0]) = 0.0f;                                          /* (event -1, k-mer -1) */
+    SC(1, ll_ev[1] - 0) = lp_trim;                                        /* first event trimmed  */
+    TR(1, ll_ev[1] - 0) = FROM_U;
+    for (int64_t b = 2; b < n_bands; b++) {
+        double lo = SC(b - 1, 0), hi = SC(b - 1, EA_BW - 1);
+        int right;
+        if (lo == LOG_ZERO && hi == LOG_ZERO) right = (b % 2) == 1;       /* both ends outside: alternate */
+        else right = lo < hi;                                            /* Suzuki's rule                */
+        ll_ev[b] = ll_ev[b - 1] + (right ? 0 : 1);
+        ll_km[b] = ll_km[b - 1] + (right ? 1 : 0);
+        int trim_o = -1 - ll_km[b];                                       /* k-mer -1: events trimmed so far */
+        if (VALID(trim_o)) {
+            int64_t ev = (int64_t) ll_ev[b] - trim_o;
+            if (ev >= 0 && ev < n_events) {
+                SC(b, trim_o) = lp_trim * (double) (ev + 1);
+                TR(b, trim_o) = FROM_U;
+            } else {
+                SC(b, trim_o) = LOG_ZERO;
+            }
+        }
+        int64_t o_min = 0 - (int64_t) ll_km[b], o_max = n_kmers - (int64_t) ll_km[b];
+        int64_t e_min = (int64_t) ll_ev[b] - (n_events - 1), e_max = (int64_t) ll_ev[b] + 1;
+        if (e_min > o_min) o_min = e_min;
+        if (o_min < 0) o_min = 0;
+        if (e_max < o_max) o_max = e_max;
+        if (o_max > EA_BW) o_max = EA_BW;
+        for (int64_t o = o_min; o < o_max; o++) {
+            int64_t ev = (int64_t) ll_ev[b] - o, km = (int64_t) ll_km[b] + o;
+            int64_t o_up = (int64_t) ll_ev[b - 1] - (ev - 1), o_left = (km - 1) - ll_km[b - 1], o_diag = (km - 1) - ll_km[b - 2];
+            float up = VALID(o_up) ? (float) SC(b - 1, o_up) : -INFINITY;
+            float left = VALID(o_left) ? (float) SC(b - 1, o_left) : -INFINITY;
+            float diag = VALID(o_diag) ? (float) SC(b - 2, o_diag) : -INFINITY;
+            double y[2] = {event_mean[ev], 0.0};
+            double lp_em = emit(m, kmer_ids[km], y, 1);
+            float s_d = (float) (diag + lp_step + lp_em);
+            float s_u = (float) (up + lp_stay + lp_em);
+            float s_l = (float) (left + lp_skip);
+            float best = s_d;
+            uint8_t from = FROM_D;
+            best = s_u > best ? s_u : best;
+            from = best == s_u ? FROM_U : from;
+            best = s_l > best ? s_l : best;
+            from = best == s_l ? FROM_L : from;
+            SC(b, o) = best;
+            TR(b, o) = from;
+        }
+    }
+    /* best (event, last k-mer) cell, the events behind it trimmed */
+    float best = -INFINITY;
+    int64_t cur_ev = 0, cur_km = n_kmers - 1;
+    for (int64_t ev = 0; ev < n_events; ev++) {
+        int64_t b = (ev + 1) + (cur_km + 1);
+        int64_t o = (int64_t) ll_ev[b] - ev;
+        if (VALID(o)) {
+            float s = (float) (SC(b, o) + (double) (n_events - ev) * lp_trim);
+            if (s > best) { best = s; cur_ev = ev; }
+        }
+    }
+    int64_t cap = n_events + n_kmers + 2, n = 0;
+    int32_t *ok = malloc(sizeof(int32_t) * (size_t) cap), *oe = malloc(sizeof(int32_t) * (size_t) cap);
+    double sum_em = 0;
+    int64_t cur_gap = 0, max_gap = 0;
+    while (cur_km >= 0 && cur_ev >= 0) {
+        ok[n] = (int32_t) cur_km; oe[n] = (int32_t) cur_ev; n++;
+        double y[2] = {event_mean[cur_ev], 0.0};
+        sum_em += emit(m, kmer_ids[cur_km], y, 1);
+        int64_t b = (cur_ev + 1) + (cur_km + 1);
+        int64_t o = (int64_t) ll_ev[b] - cur_ev;
+        uint8_t from = TR(b, o);
+        if (from == FROM_D) { cur_km--; cur_ev--; cur_gap = 0; }
+        else if (from == FROM_U) { cur_ev--; cur_gap = 0; }
+        else { cur_km--; cur_gap++; if (cur_gap > max_gap) max_gap = cur_gap; }
+    }
+    free(score); free(trace); free(ll_ev); free(ll_km);
+#undef SC
+#undef TR
+#undef VALID
+    for (int64_t i = 0; i < n / 2; i++) { /* stList_reverse */
+        int32_t t = ok[i]; ok[i] = ok[n - 1 - i]; ok[n - 1 - i] = t;
+        t = oe[i]; oe[i] = oe[n - 1 - i]; oe[n - 1 - i] = t;
+    }
+    int st = 0;
+    double avg = sum_em / (double) n;
+    if (avg < -5.2) st |= 1;
+    if (!(n > 0 && ok[0] == 0 && ok[n - 1] == n_kmers - 1)) st |= 2;
+    if (max_gap > 50) st |= 4;
+    if (events_per_kmer > 5.0) st |= 8;
+    if (status) *status = st;
+    if (st) { free(ok); free(oe); return 0; }
+    *kmer_idx_out = ok;
+    *event_idx_out = oe;
+    return n;
+}
+
+/* estimate_scalings_using_mom, impl/eventAligner.c:784-843: method of moments over the read's events and the levels
+ * of its k-mers; returns shift and scale (var stays 1, drift 0: set4_NanoporeReadAdjustmentParameters). */
+void sao_scalings_mom(const sao_model_t *m, const double *event_mean, int64_t n_events, const int32_t *kmer_ids,
+                      int64_t n_kmers, double *shift_out, double *scale_out) {
+    double ev_sum = 0.0f;
+    for (int64_t i = 0; i < n_events; i++) ev_sum += event_mean[i];
+    double km_sum = 0.0f, km_sq = 0.0f;
+    for (int64_t i = 0; i < n_kmers; i++) {
+        double level = m->match5[(int64_t) kmer_ids[i] * MODEL_PARAMS];
+        km_sum += level;
+        km_sq += pow(level, 2.0f);
+    }
+    double shift = ev_sum / (double) n_events - km_sum / (double) n_kmers;
+    double ev_sq = 0.0f;
+    for (int64_t i = 0; i < n_events; i++) ev_sq += pow(event_mean[i] - shift, 2.0);
+    *shift_out = shift;
+    *scale_out = (ev_sq / (double) n_events) / (km_sq / (double) n_kmers);
+}

@@ -159,6 +159,11 @@ int64_t sao_remap_anchors(const int64_t *ax, const int64_t *ay, int64_t n, const
 int sao_estimate_params(sao_model_t *m, const int64_t *strand_event_map, double *events, int64_t n_events,
                         const char *strand_read, int64_t read_len, double *out7);
 
+/* event <-> k-mer pre-alignment, impl/eventAligner.c:899-1235 (PARITY UNPINNED, see sa_oracle.c) */
+int64_t sao_event_align(const sao_model_t *m, const double *event_mean, int64_t n_events, const int32_t *kmer_ids,
+                        int64_t n_kmers, int32_t **kmer_idx_out, int32_t **event_idx_out, int *status);
+void sao_scalings_mom(const sao_model_t *m, const double *event_mean, int64_t n_events, const int32_t *kmer_ids,
+                      int64_t n_kmers, double *shift_out, double *scale_out); /* impl/eventAligner.c:784-843 */
 void sao_free(void *p);
 
 /* multi-threaded batch driver used by bench.py's cpu_baseline leg (one read per thread). */

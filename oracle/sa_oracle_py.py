@@ -123,6 +123,46 @@ def _ip(a):
     return a.ctypes.data_as(C.POINTER(C.c_int64))
 
 
+def kmer_ids_of(model, seq):
+    """k-mer id of every position of a nucleotide string (build_kmer_list, impl/eventAligner.c:755-782, DNA)."""
+    k = model.k
+    return np.array([model.kmer_id(seq[i:i + k]) for i in range(len(seq) - k + 1)], dtype=np.int32)
+
+
+def scalings_mom(model, event_means, kmer_ids):
+    """estimate_scalings_using_mom (impl/eventAligner.c:784-843): returns (shift, scale)."""
+    ev = np.ascontiguousarray(event_means, dtype=np.float64)
+    ids = np.ascontiguousarray(kmer_ids, dtype=np.int32)
+    sh, sc = C.c_double(), C.c_double()
+    f = lib().sao_scalings_mom
+    f.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_double),
+                  C.POINTER(C.c_double)]
+    f.restype = None
+    f(model._h, _dp(ev), len(ev), ids.ctypes.data_as(C.POINTER(C.c_int32)), len(ids), C.byref(sh), C.byref(sc))
+    return sh.value, sc.value
+
+
+def event_align(model, event_means, kmer_ids):
+    """adaptive_banded_simple_event_align (impl/eventAligner.c:899-1235).  Returns (kmer_idx, event_idx, status)."""
+    ev = np.ascontiguousarray(event_means, dtype=np.float64)
+    ids = np.ascontiguousarray(kmer_ids, dtype=np.int32)
+    ko, eo, st = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.c_int()
+    f = lib().sao_event_align
+    f.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int32), C.c_int64,
+                  C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int)]
+    f.restype = C.c_int64
+    n = f(model._h, _dp(ev), len(ev), ids.ctypes.data_as(C.POINTER(C.c_int32)), len(ids), C.byref(ko), C.byref(eo),
+          C.byref(st))
+    if n < 0:
+        raise RuntimeError("sao_event_align failed: %d" % n)
+    k = np.array([ko[i] for i in range(n)], dtype=np.int32)
+    e = np.array([eo[i] for i in range(n)], dtype=np.int32)
+    if n:
+        lib().sao_free(ko)
+        lib().sao_free(eo)
+    return k, e, st.value
+
+
 def default_params(threshold=0.01, expansion=50, trace_back=100, min_diags=1000, split=3000 * 3000, trim=14):
     """signalMachine defaults (impl/signalMachine.c:487-490, :672-676) with Python's -g 100."""
     e = expansion if expansion % 2 == 0 else expansion + 1

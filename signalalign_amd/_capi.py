@@ -50,6 +50,11 @@ class BatchStats(C.Structure):
                 ("n_groups", C.c_int64)]
 
 
+class EaJob(C.Structure):
+    _fields_ = [("sequence", C.c_char_p), ("seq_len", C.c_int64), ("event_mean", C.POINTER(C.c_double)),
+                ("n_events", C.c_int64), ("scale", C.c_double), ("shift", C.c_double), ("var", C.c_double)]
+
+
 class PlanInfo(C.Structure):
     _fields_ = [("n_regions", C.c_int64), ("n_segments", C.c_int64), ("n_checkpoints", C.c_int64),
                 ("cells_forward", C.c_double), ("cells_backward", C.c_double), ("f_cellpaths", C.c_int64),
@@ -62,7 +67,7 @@ EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alp
            "sa_model_set_to_hdp_expected_values", "sa_kmer_id", "sa_default_ambig", "sa_load_ambig",
            "sa_batch_create", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_stats",
            "sa_batch_job_cells", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_plan_describe", "sa_plan_digest",
-           "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_device_count", "sa_strerror",
+           "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_device_count", "sa_strerror",
            "sa_version", "sa_free"]
 
 
@@ -125,6 +130,9 @@ def lib():
     L.sa_estimate_params.argtypes = [C.c_void_p, dp, ip, dp, C.c_int64, C.c_char_p, C.c_int64, dp]
     L.sa_expect_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Job), C.c_int64, C.POINTER(C.c_char_p),
                                   C.c_int, C.c_uint, dp, dp, C.POINTER(C.c_void_p), ip]
+    L.sa_scalings_mom.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, dp, C.c_int64, dp, dp]
+    L.sa_event_align_batch.argtypes = [C.c_void_p, C.POINTER(EaJob), C.c_int64, C.c_int, C.c_uint, C.POINTER(C.c_void_p), ip,
+                                       C.POINTER(C.c_int32), dp, dp]
     L.sa_free.argtypes = [C.c_void_p]
     _LIB = L
     return L
@@ -315,6 +323,47 @@ def plan_describe(model, params, job, ambig=None, flags=0):
     for r in reg:
         nrow += (r[2] - r[0]) + (r[3] - r[1]) + 1
     return info, reg, rows[:3 * nrow].reshape(-1, 3), segs[:4 * info.n_segments].reshape(-1, 4)
+
+
+def scalings_mom(model, sequence, event_means):
+    """sa_scalings_mom: (shift, scale) by the method of moments (impl/eventAligner.c:784-843)."""
+    ev = np.ascontiguousarray(event_means, dtype=np.float64)
+    sb = sequence.encode()
+    sh, sc = C.c_double(), C.c_double()
+    _chk(lib().sa_scalings_mom(model._h, sb, len(sb), _dp(ev), len(ev), C.byref(sh), C.byref(sc)), "sa_scalings_mom")
+    return sh.value, sc.value
+
+
+def event_align_batch(model, jobs, device=0, flags=0, stats=None):
+    """sa_event_align_batch.  jobs: dicts(sequence, event_mean, scale, shift, var=1).  Returns per job
+    (kmer_idx array, event_idx array, status); stats (a dict, optional) receives cells per job and the kernel time."""
+    n = len(jobs)
+    arr = (EaJob * max(n, 1))()
+    keep = []
+    for i, j in enumerate(jobs):
+        ev = np.ascontiguousarray(j["event_mean"], dtype=np.float64)
+        sb = j["sequence"].encode()
+        keep.append((ev, sb))
+        arr[i] = EaJob(sb, len(sb), _dp(ev), len(ev), j["scale"], j["shift"], j.get("var", 1.0))
+    ptrs = (C.c_void_p * max(n, 1))()
+    cnt = np.zeros(max(n, 1), dtype=np.int64)
+    st = np.zeros(max(n, 1), dtype=np.int32)
+    cells = np.zeros(max(n, 1), dtype=np.float64)
+    kms = C.c_double()
+    _chk(lib().sa_event_align_batch(model._h, arr, n, device, flags, ptrs, _ip(cnt), st.ctypes.data_as(C.POINTER(C.c_int32)),
+                                    _dp(cells), C.byref(kms)), "sa_event_align_batch")
+    if stats is not None:
+        stats["cells"] = cells[:n].copy()
+        stats["kernel_ms"] = kms.value
+    out = []
+    for i in range(n):
+        a = np.zeros((int(cnt[i]), 2), dtype=np.int32)
+        if cnt[i]:
+            C.memmove(a.ctypes.data, ptrs[i], 8 * int(cnt[i]))
+        lib().sa_free(ptrs[i])
+        out.append((a[:, 0].copy(), a[:, 1].copy(), int(st[i])))
+    del keep
+    return out
 
 
 def plan_digest(model, params, jobs, ambig=None, flags=0, threads=0):

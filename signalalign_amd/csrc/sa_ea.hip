@@ -1,0 +1,333 @@
+// sa_ea.hip -- event <-> k-mer pre-alignment on the GPU.
+//
+// What it replaces: adaptive_banded_simple_event_align2 (impl/eventAligner.c:899-1235), the step immediately upstream
+// of the pair-HMM: Suzuki-Kasahara adaptive banding as used by nanopolish.  Bands are anti-diagonals of the
+// (event+1) x (k-mer+1) matrix, 100 cells wide; every new band steps right or down from the previous one depending on
+// which end of it scores higher; Viterbi scores over three moves (step, stay, skip) kept as floats; traceback from the
+// best (event, last k-mer) cell; three quality checks.
+//
+// Mapping: one wave per read.  The recurrence is serial in the band index (~ events + k-mers steps), the 100 cells of a
+// band are independent: lane l computes offsets l and l+64.  The three live bands sit in LDS (the neighbours of a
+// cell are at the same or an adjacent offset of the two previous bands, which one depends on the moves taken); the
+// trace (one byte per cell) and the band origins go to global memory for the traceback, which lane 0 walks at the end.
+// Arithmetic follows the reference's order of operations and float casts (the file is compiled with
+// -ffp-contract=off), with the emission of the memory-resident EXACT kernels: results are bit-identical to the CPU
+// restatement in oracle/sa_oracle.c.  PARITY UNPINNED against the reference itself: its tests of this function need
+// fast5 files (tests/eventAlignerTests.c:223-320, :404-430).
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "sa_internal.h"
+
+#define EA_BW 100
+#define EA_HALF 50
+#define EA_NEG_INF (-__builtin_inf())
+
+struct EaJob {
+    long long ev_off, kc_off, trace_off, ll_off, col_off, out_off;  // offsets into the shared arrays
+    int n_events, n_kmers;
+    double lp_skip, lp_stay, lp_step, lp_trim, events_per_kmer;
+    double scale, shift, var, lvar;
+};
+
+struct EaPlan {
+    const EaJob *jobs;
+    const double *ev;        // event means
+    const double *kc;        // per k-mer position: mu, sd, c = -log(sqrt(2 pi)) - log(sd)   (3 doubles)
+    unsigned char *trace;    // [n_bands][100] per read
+    int *ll;                 // [n_bands][2] per read: event / k-mer index of the band's offset 0
+    double *col;             // [n_events] per read: score of (event, last k-mer)
+    int *out;                // [cap][2] per read: (k-mer, event) pairs, traceback order
+    int *n_out;              // per read
+    int *status;             // per read
+    int *fills;              // per read: cells filled (the reference's `fills` counter)
+};
+
+// emissions_signal_strawManGetKmerEventMatchProbWithDescaling_MeanOnly (impl/stateMachine.c:557-605), the operation
+// order of oracle/sa_oracle.c:emit
+__device__ __forceinline__ double ea_emit(const double *kc, double e, const EaJob &J) {
+    const double mu = kc[0], sd = kc[1], c = kc[2];
+    const double en = (e + J.var * mu - J.scale * mu - J.shift) / J.var;
+    const double a = (en - mu) / sd;
+    return J.lvar + (c + (-0.5 * a * a));
+}
+
+__global__ __launch_bounds__(64) void k_event_align(EaPlan P, int n_jobs) {
+    __shared__ double ring[3][EA_BW];
+    const int job = blockIdx.x;
+    if (job >= n_jobs) return;
+    const int lane = threadIdx.x;
+    const EaJob J = P.jobs[job];
+    const double *ev = P.ev + J.ev_off;
+    const double *kc = P.kc + 3 * J.kc_off;
+    unsigned char *trace = P.trace + J.trace_off;
+    int *ll = P.ll + 2 * J.ll_off;
+    double *col = P.col + J.col_off;
+    const int n_events = J.n_events, n_kmers = J.n_kmers;
+    const long long n_bands = (long long) (n_events + 1) + (n_kmers + 1);
+
+    int my_fills = 0;
+    for (int i = lane; i < n_events; i += 64) col[i] = EA_NEG_INF;
+    for (int o = lane; o < EA_BW; o += 64) {
+        ring[0][o] = (o == EA_HALF) ? 0.0 : EA_NEG_INF;        // band 0: (event -1, k-mer -1) at offset 50
+        ring[1][o] = (o == EA_HALF) ? J.lp_trim : EA_NEG_INF;  // band 1: first event trimmed
+    }
+    int ll_ev1 = EA_HALF, ll_km1 = -1 - EA_HALF;   // band b-1
+    int ll_ev2 = EA_HALF - 1, ll_km2 = -1 - EA_HALF;  // band b-2
+    if (lane == 0) {
+        ll[0] = ll_ev2; ll[1] = ll_km2;
+        ll[2] = ll_ev1; ll[3] = ll_km1;
+    }
+    __syncthreads();
+    for (long long b = 2; b < n_bands; b++) {
+        const double *prev1 = ring[(b - 1) % 3], *prev2 = ring[(b - 2) % 3];
+        double *cur = ring[b % 3];
+        const double lo = prev1[0], hi = prev1[EA_BW - 1];
+        bool right;
+        if (lo == EA_NEG_INF && hi == EA_NEG_INF) right = (b % 2) == 1;  // both ends outside the matrix: alternate
+        else right = lo < hi;                                           // Suzuki's rule
+        const int ll_ev = ll_ev1 + (right ? 0 : 1), ll_km = ll_km1 + (right ? 1 : 0);
+        if (lane == 0) { ll[2 * b] = ll_ev; ll[2 * b + 1] = ll_km; }
+        int o_min = 0 - ll_km, o_max = n_kmers - ll_km;
+        const int e_min = ll_ev - (n_events - 1), e_max = ll_ev + 1;
+        o_min = e_min > o_min ? e_min : o_min;
+        o_min = o_min < 0 ? 0 : o_min;
+        o_max = e_max < o_max ? e_max : o_max;
+        o_max = o_max > EA_BW ? EA_BW : o_max;
+        const int trim_o = -1 - ll_km;
+#pragma unroll
+        for (int rep = 0; rep < 2; rep++) {
+            const int o = lane + 64 * rep;
+            if (o >= EA_BW) break;
+            double val = EA_NEG_INF;
+            if (o == trim_o) {  // k-mer -1: every event so far trimmed
+                const int e = ll_ev - o;
+                if (e >= 0 && e < n_events) val = J.lp_trim * (double) (e + 1);
+            }
+            if (o >= o_min && o < o_max) {
+                const int e = ll_ev - o, km = ll_km + o;
+                const int o_up = ll_ev1 - (e - 1), o_left = (km - 1) - ll_km1, o_diag = (km - 1) - ll_km2;
+                const float up = (o_up >= 0 && o_up < EA_BW) ? (float) prev1[o_up] : -__builtin_inff();
+                const float left = (o_left >= 0 && o_left < EA_BW) ? (float) prev1[o_left] : -__builtin_inff();
+                const float diag = (o_diag >= 0 && o_diag < EA_BW) ? (float) prev2[o_diag] : -__builtin_inff();
+                const double lp_em = ea_emit(kc + 3ll * km, ev[e], J);
+                const float s_d = (float) ((double) diag + J.lp_step + lp_em);
+                const float s_u = (float) ((double) up + J.lp_stay + lp_em);
+                const float s_l = (float) ((double) left + J.lp_skip);
+                float best = s_d;
+                unsigned char from = 0;               // FROM_D
+                best = s_u > best ? s_u : best;
+                from = best == s_u ? 1 : from;        // FROM_U
+                best = s_l > best ? s_l : best;
+                from = best == s_l ? 2 : from;        // FROM_L
+                val = (double) best;
+                trace[b * EA_BW + o] = from;
+                if (km == n_kmers - 1) col[e] = val;
+                my_fills++;
+            }
+            cur[o] = val;
+        }
+        ll_ev2 = ll_ev1; ll_km2 = ll_km1;
+        ll_ev1 = ll_ev; ll_km1 = ll_km;
+        __syncthreads();
+    }
+    // best (event, last k-mer) cell with the events behind it trimmed: first maximum, as the reference's scan
+    float best = -__builtin_inff();
+    int best_ev = 0x7fffffff;
+    for (int e = lane; e < n_events; e += 64) {
+        const float s = (float) (col[e] + (double) (n_events - e) * J.lp_trim);
+        if (s > best) { best = s; best_ev = e; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oe = __shfl_xor(best_ev, off, 64);
+        if (ob > best || (ob == best && oe < best_ev)) { best = ob; best_ev = oe; }
+    }
+    for (int off = 32; off > 0; off >>= 1) my_fills += __shfl_xor(my_fills, off, 64);
+    if (lane != 0) return;
+    P.fills[job] = my_fills;
+    // traceback (lane 0): the scan starts from event 0 when nothing scored (best == -inf), like the reference
+    int cur_ev = (best > -__builtin_inff()) ? best_ev : 0, cur_km = n_kmers - 1;
+    int *out = P.out + 2 * J.out_off;
+    int n = 0, cur_gap = 0, max_gap = 0;
+    double sum_em = 0;
+    while (cur_km >= 0 && cur_ev >= 0) {
+        out[2 * n] = cur_km; out[2 * n + 1] = cur_ev; n++;
+        sum_em += ea_emit(kc + 3ll * cur_km, ev[cur_ev], J);
+        const long long b = (long long) (cur_ev + 1) + (cur_km + 1);
+        const int o = ll[2 * b] - cur_ev;
+        const unsigned char from = trace[b * EA_BW + o];
+        if (from == 0) { cur_km--; cur_ev--; cur_gap = 0; }
+        else if (from == 1) { cur_ev--; cur_gap = 0; }
+        else { cur_km--; cur_gap++; max_gap = cur_gap > max_gap ? cur_gap : max_gap; }
+    }
+    int st = 0;
+    const double avg = sum_em / (double) n;
+    if (avg < -5.2) st |= 1;
+    // pairs are in traceback order: the last one is the front of the reversed list
+    if (!(n > 0 && out[2 * (n - 1)] == 0 && out[0] == n_kmers - 1)) st |= 2;
+    if (max_gap > 50) st |= 4;
+    if (J.events_per_kmer > 5.0) st |= 8;
+    P.status[job] = st;
+    P.n_out[job] = st ? 0 : n;
+}
+
+#define EACHK(call)                                                                                         \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess) {                                                                             \
+            fprintf(stderr, "[signalalign_hip] %s failed: %s (%s:%d)\n", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            rc = e_ == hipErrorOutOfMemory ? SA_ENOMEM : SA_ENODEVICE;                                      \
+            goto done;                                                                                      \
+        }                                                                                                   \
+    } while (0)
+
+extern "C" int sa_scalings_mom(const sa_model_t *m, const char *sequence, int64_t seq_len, const double *event_mean,
+                               int64_t n_events, double *shift_out, double *scale_out) {
+    if (!m || !sequence || !event_mean || !shift_out || !scale_out) return SA_EINVAL;
+    const int64_t n_kmers = seq_len - (m->k - 1);
+    if (n_kmers <= 0 || n_events <= 0) return SA_EINVAL;
+    double ev_sum = 0.0f;
+    for (int64_t i = 0; i < n_events; i++) ev_sum += event_mean[i];
+    double km_sum = 0.0f, km_sq = 0.0f;
+    for (int64_t i = 0; i < n_kmers; i++) {
+        int64_t id = sa_model_kmer_id(m, sequence + i);
+        if (id < 0) return SA_EALPHABET;
+        double level = m->table5[5 * id];
+        km_sum += level;
+        km_sq += pow(level, 2.0f);
+    }
+    double shift = ev_sum / (double) n_events - km_sum / (double) n_kmers;
+    double ev_sq = 0.0f;
+    for (int64_t i = 0; i < n_events; i++) ev_sq += pow(event_mean[i] - shift, 2.0);
+    *shift_out = shift;
+    *scale_out = (ev_sq / (double) n_events) / (km_sq / (double) n_kmers);
+    return SA_OK;
+}
+
+extern "C" int sa_event_align_batch(const sa_model_t *m, const sa_ea_job_t *jobs, int64_t n_jobs, int device, unsigned flags,
+                                    sa_ea_pair_t **pairs_out, int64_t *n_pairs_out, int32_t *status_out, double *cells_out,
+                                    double *kernel_ms_out) {
+    if (!m || (!jobs && n_jobs > 0) || n_jobs < 0 || !pairs_out || !n_pairs_out) return SA_EINVAL;
+    if (m->hdp) return SA_EUNSUPPORTED;  // the reference builds this aligner's state machine without an HDP
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fprintf(stderr, "[signalalign_hip] no HIP device available; this library has no CPU fallback\n");
+        return SA_ENODEVICE;
+    }
+    if (device < 0 || device >= ndev) return SA_EINVAL;
+    for (int64_t j = 0; j < n_jobs; j++) { pairs_out[j] = nullptr; n_pairs_out[j] = 0; if (status_out) status_out[j] = 0; }
+    if (n_jobs == 0) return SA_OK;
+    // host side: k-mer constants and offsets
+    std::vector<EaJob> hj((size_t) n_jobs);
+    std::vector<double> ev, kc;
+    long long trace_tot = 0, ll_tot = 0, col_tot = 0, out_tot = 0;
+    for (int64_t j = 0; j < n_jobs; j++) {
+        const sa_ea_job_t *jb = &jobs[j];
+        const int64_t n_kmers = jb->seq_len - (m->k - 1);
+        if (!jb->sequence || !jb->event_mean || n_kmers <= 0 || jb->n_events <= 0 || !(jb->var > 0.0) ||
+            jb->n_events > (1 << 24) || n_kmers > (1 << 24))
+            return SA_EINVAL;
+        EaJob &J = hj[(size_t) j];
+        J.ev_off = (long long) ev.size();
+        J.kc_off = (long long) (kc.size() / 3);
+        J.n_events = (int) jb->n_events;
+        J.n_kmers = (int) n_kmers;
+        ev.insert(ev.end(), jb->event_mean, jb->event_mean + jb->n_events);
+        for (int64_t i = 0; i < n_kmers; i++) {
+            int64_t id = sa_model_kmer_id(m, jb->sequence + i);
+            if (id < 0) return SA_EALPHABET;
+            const double mu = m->table5[5 * id], sd = m->table5[5 * id + 1];
+            kc.push_back(mu);
+            kc.push_back(sd == 0.0 ? 1.0 : sd);
+            kc.push_back(sd == 0.0 ? -INFINITY : (-0.91893853320467267 - log(sd)));
+        }
+        const long long n_bands = (long long) (jb->n_events + 1) + (n_kmers + 1);
+        J.trace_off = trace_tot; trace_tot += n_bands * EA_BW;
+        J.ll_off = ll_tot; ll_tot += n_bands;
+        J.col_off = col_tot; col_tot += jb->n_events;
+        J.out_off = out_tot; out_tot += jb->n_events + n_kmers + 2;
+        // transition penalties (impl/eventAligner.c:928-940)
+        J.events_per_kmer = (double) jb->n_events / (double) n_kmers;
+        const double p_stay = 1 - (1 / (J.events_per_kmer + 1));
+        J.lp_skip = log(1e-10);
+        J.lp_stay = log(p_stay);
+        J.lp_step = log(1.0 - exp(J.lp_skip) - exp(J.lp_stay));
+        J.lp_trim = log(0.01);
+        J.scale = jb->scale; J.shift = jb->shift; J.var = jb->var;
+        J.lvar = log((1 / jb->var));
+    }
+    int rc = SA_OK;
+    EaPlan P;
+    memset(&P, 0, sizeof(P));
+    EaJob *d_jobs = nullptr;
+    double *d_ev = nullptr, *d_kc = nullptr, *d_col = nullptr;
+    unsigned char *d_trace = nullptr;
+    int *d_ll = nullptr, *d_out = nullptr, *d_n = nullptr, *d_st = nullptr, *d_fills = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float kms = 0;
+    std::vector<int> h_n((size_t) n_jobs), h_st((size_t) n_jobs), h_fills((size_t) n_jobs), h_out;
+    EACHK(hipSetDevice(device));
+    EACHK(hipMalloc((void **) &d_jobs, sizeof(EaJob) * (size_t) n_jobs));
+    EACHK(hipMalloc((void **) &d_ev, sizeof(double) * ev.size()));
+    EACHK(hipMalloc((void **) &d_kc, sizeof(double) * kc.size()));
+    EACHK(hipMalloc((void **) &d_trace, (size_t) trace_tot));
+    EACHK(hipMalloc((void **) &d_ll, sizeof(int) * 2 * (size_t) ll_tot));
+    EACHK(hipMalloc((void **) &d_col, sizeof(double) * (size_t) col_tot));
+    EACHK(hipMalloc((void **) &d_out, sizeof(int) * 2 * (size_t) out_tot));
+    EACHK(hipMalloc((void **) &d_n, sizeof(int) * (size_t) n_jobs));
+    EACHK(hipMalloc((void **) &d_st, sizeof(int) * (size_t) n_jobs));
+    EACHK(hipMalloc((void **) &d_fills, sizeof(int) * (size_t) n_jobs));
+    EACHK(hipEventCreate(&e0));
+    EACHK(hipEventCreate(&e1));
+    EACHK(hipMemcpy(d_jobs, hj.data(), sizeof(EaJob) * (size_t) n_jobs, hipMemcpyHostToDevice));
+    EACHK(hipMemcpy(d_ev, ev.data(), sizeof(double) * ev.size(), hipMemcpyHostToDevice));
+    EACHK(hipMemcpy(d_kc, kc.data(), sizeof(double) * kc.size(), hipMemcpyHostToDevice));
+    P.jobs = d_jobs; P.ev = d_ev; P.kc = d_kc; P.trace = d_trace; P.ll = d_ll; P.col = d_col; P.out = d_out;
+    P.n_out = d_n; P.status = d_st; P.fills = d_fills;
+    EACHK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_event_align, dim3((unsigned) n_jobs), dim3(64), 0, 0, P, (int) n_jobs);
+    EACHK(hipEventRecord(e1, 0));
+    EACHK(hipGetLastError());
+    EACHK(hipEventSynchronize(e1));
+    EACHK(hipEventElapsedTime(&kms, e0, e1));
+    if (kernel_ms_out) *kernel_ms_out = (double) kms;
+    EACHK(hipMemcpy(h_fills.data(), d_fills, sizeof(int) * (size_t) n_jobs, hipMemcpyDeviceToHost));
+    if (cells_out)
+        for (int64_t j = 0; j < n_jobs; j++) cells_out[j] = (double) h_fills[(size_t) j];
+    EACHK(hipMemcpy(h_n.data(), d_n, sizeof(int) * (size_t) n_jobs, hipMemcpyDeviceToHost));
+    EACHK(hipMemcpy(h_st.data(), d_st, sizeof(int) * (size_t) n_jobs, hipMemcpyDeviceToHost));
+    h_out.resize(2 * (size_t) out_tot);
+    EACHK(hipMemcpy(h_out.data(), d_out, sizeof(int) * 2 * (size_t) out_tot, hipMemcpyDeviceToHost));
+    for (int64_t j = 0; j < n_jobs; j++) {
+        const int n = h_n[(size_t) j];
+        if (status_out) status_out[j] = h_st[(size_t) j];
+        n_pairs_out[j] = n;
+        pairs_out[j] = (sa_ea_pair_t *) malloc(sizeof(sa_ea_pair_t) * (size_t) (n > 0 ? n : 1));
+        if (!pairs_out[j]) { rc = SA_ENOMEM; goto done; }
+        const int *src = h_out.data() + 2 * hj[(size_t) j].out_off;
+        for (int i = 0; i < n; i++) {  // stList_reverse: ascending order
+            pairs_out[j][i].kmer_idx = src[2 * (n - 1 - i)];
+            pairs_out[j][i].event_idx = src[2 * (n - 1 - i) + 1];
+        }
+    }
+done:
+    {
+        if (e0) (void) hipEventDestroy(e0);
+        if (e1) (void) hipEventDestroy(e1);
+        void *ptrs[] = {d_jobs, d_ev, d_kc, d_trace, d_ll, d_col, d_out, d_n, d_st, d_fills};
+        for (void *p : ptrs)
+            if (p) (void) hipFree(p);
+    }
+    if (rc != SA_OK)
+        for (int64_t j = 0; j < n_jobs; j++) { free(pairs_out[j]); pairs_out[j] = nullptr; n_pairs_out[j] = 0; }
+    (void) flags;
+    return rc;
+}

@@ -202,3 +202,19 @@ def test_planner_error_codes_and_empty_batch():
         with pytest.raises(sa.SaError) as ei:
             sa.plan_digest(pm, p, jobs, threads=t)
         assert ei.value.code == -5
+
+
+def test_scalings_by_method_of_moments(oracle):
+    # estimate_scalings_using_mom (impl/eventAligner.c:784-843): host-only entry point, bit-identical to the restatement
+    alpha, k, t10, tab = synth.parse_model_table(cases.MODEL_6MER)
+    om = oracle.Model(alpha, k, t10, tab)
+    pm = sa.Model.load(cases.MODEL_6MER)
+    r = synth.make_read(31, 1200, alpha, k, tab)
+    ev = np.ascontiguousarray(np.asarray(r["events4"])[:, 0])
+    sh, sc = sa.scalings_mom(pm, r["ref"], ev)
+    osh, osc = oracle.scalings_mom(om, ev, oracle.kmer_ids_of(om, r["ref"]))
+    assert (sh, sc) == (osh, osc)
+    assert abs(sc - 1.0) < 0.15 and abs(sh) < 15.0
+    with pytest.raises(sa.SaError) as ei:
+        sa.scalings_mom(pm, "ACGTNACGTACGT", ev)        # a letter outside the model's alphabet
+    assert ei.value.code == -4
