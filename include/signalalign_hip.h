@@ -38,6 +38,7 @@ extern "C" {
 #define SA_FLAG_EXACT 1u          /* reference-ordered, un-contracted fp64 arithmetic on the device
                                      (slow kernels; bit-identical posteriors for Gaussian emissions) */
 #define SA_FLAG_FORCE_GENERIC 2u  /* never pick the register-resident fast kernels */
+#define SA_FLAG_RNA 4u            /* event alignment only: k-mers as build_kmer_list(..., rna=true) makes them (U -> T, reversed) */
 
 typedef struct sa_model sa_model_t; /* replaces StateMachine3 / StateMachine3_HDP (inc/stateMachine.h:150-190) */
 typedef struct sa_batch sa_batch_t;
@@ -187,7 +188,7 @@ typedef struct sa_ea_pair {
 } sa_ea_pair_t;
 /* estimate_scalings_using_mom (impl/eventAligner.c:784-843): method of moments; the reference then uses var = 1 */
 int sa_scalings_mom(const sa_model_t *m, const char *sequence, int64_t seq_len, const double *event_mean,
-                    int64_t n_events, double *shift_out, double *scale_out);
+                    int64_t n_events, unsigned flags, double *shift_out, double *scale_out);
 /* cells_out[j] (may be NULL): band cells filled for job j (the reference's `fills`); kernel_ms_out (may be NULL):
  * HIP-event time of the kernel */
 int sa_event_align_batch(const sa_model_t *m, const sa_ea_job_t *jobs, int64_t n_jobs, int device, unsigned flags,

@@ -123,9 +123,13 @@ def _ip(a):
     return a.ctypes.data_as(C.POINTER(C.c_int64))
 
 
-def kmer_ids_of(model, seq):
-    """k-mer id of every position of a nucleotide string (build_kmer_list, impl/eventAligner.c:755-782, DNA)."""
+def kmer_ids_of(model, seq, rna=False):
+    """k-mer id of every position of a nucleotide string as build_kmer_list lists them (impl/eventAligner.c:772-790):
+    for RNA, U reads as T and every k-mer is reversed."""
     k = model.k
+    if rna:
+        seq = seq.replace("U", "T")
+        return np.array([model.kmer_id(seq[i:i + k][::-1]) for i in range(len(seq) - k + 1)], dtype=np.int32)
     return np.array([model.kmer_id(seq[i:i + k]) for i in range(len(seq) - k + 1)], dtype=np.int32)
 
 

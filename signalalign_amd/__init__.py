@@ -7,8 +7,8 @@ for the compute calls, everything here raises.
 """
 from ._capi import (Batch, Model, Params, SaError, build, default_ambig, default_params, device_count, lib,
                     library_path, plan_describe, plan_digest, expect_batch, scalings_mom, event_align_batch, guide_to_anchors, remap_anchors, estimate_params, PAIR_DTYPE,
-                    FLAG_EXACT, FLAG_FORCE_GENERIC)
+                    FLAG_EXACT, FLAG_FORCE_GENERIC, FLAG_RNA)
 
 __all__ = ["Batch", "Model", "Params", "SaError", "build", "default_ambig", "default_params", "device_count", "lib",
            "library_path", "plan_describe", "plan_digest", "expect_batch", "scalings_mom", "event_align_batch", "guide_to_anchors", "remap_anchors", "estimate_params", "PAIR_DTYPE",
-           "FLAG_EXACT", "FLAG_FORCE_GENERIC"]
+           "FLAG_EXACT", "FLAG_FORCE_GENERIC", "FLAG_RNA"]

@@ -130,7 +130,7 @@ def lib():
     L.sa_estimate_params.argtypes = [C.c_void_p, dp, ip, dp, C.c_int64, C.c_char_p, C.c_int64, dp]
     L.sa_expect_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Job), C.c_int64, C.POINTER(C.c_char_p),
                                   C.c_int, C.c_uint, dp, dp, C.POINTER(C.c_void_p), ip]
-    L.sa_scalings_mom.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, dp, C.c_int64, dp, dp]
+    L.sa_scalings_mom.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, dp, C.c_int64, C.c_uint, dp, dp]
     L.sa_event_align_batch.argtypes = [C.c_void_p, C.POINTER(EaJob), C.c_int64, C.c_int, C.c_uint, C.POINTER(C.c_void_p), ip,
                                        C.POINTER(C.c_int32), dp, dp]
     L.sa_free.argtypes = [C.c_void_p]
@@ -325,12 +325,15 @@ def plan_describe(model, params, job, ambig=None, flags=0):
     return info, reg, rows[:3 * nrow].reshape(-1, 3), segs[:4 * info.n_segments].reshape(-1, 4)
 
 
-def scalings_mom(model, sequence, event_means):
+FLAG_RNA = 4
+
+
+def scalings_mom(model, sequence, event_means, flags=0):
     """sa_scalings_mom: (shift, scale) by the method of moments (impl/eventAligner.c:784-843)."""
     ev = np.ascontiguousarray(event_means, dtype=np.float64)
     sb = sequence.encode()
     sh, sc = C.c_double(), C.c_double()
-    _chk(lib().sa_scalings_mom(model._h, sb, len(sb), _dp(ev), len(ev), C.byref(sh), C.byref(sc)), "sa_scalings_mom")
+    _chk(lib().sa_scalings_mom(model._h, sb, len(sb), _dp(ev), len(ev), flags, C.byref(sh), C.byref(sc)), "sa_scalings_mom")
     return sh.value, sc.value
 
 

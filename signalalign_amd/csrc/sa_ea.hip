@@ -179,6 +179,19 @@ __global__ __launch_bounds__(64) void k_event_align(EaPlan P, int n_jobs) {
     P.n_out[job] = st ? 0 : n;
 }
 
+// k-mer id of position i as build_kmer_list (impl/eventAligner.c:772-790) lists it: for RNA, U reads as T and the k-mer
+// is reversed
+static int64_t ea_kmer_id(const sa_model_t *m, const char *p, bool rna) {
+    if (!rna) return sa_model_kmer_id(m, p);
+    char tmp[64];
+    for (int i = 0; i < m->k; i++) {
+        char c = p[m->k - 1 - i];
+        tmp[i] = c == 'U' ? 'T' : c;
+    }
+    tmp[m->k] = 0;
+    return sa_model_kmer_id(m, tmp);
+}
+
 #define EACHK(call)                                                                                         \
     do {                                                                                                    \
         hipError_t e_ = (call);                                                                             \
@@ -190,7 +203,7 @@ __global__ __launch_bounds__(64) void k_event_align(EaPlan P, int n_jobs) {
     } while (0)
 
 extern "C" int sa_scalings_mom(const sa_model_t *m, const char *sequence, int64_t seq_len, const double *event_mean,
-                               int64_t n_events, double *shift_out, double *scale_out) {
+                               int64_t n_events, unsigned flags, double *shift_out, double *scale_out) {
     if (!m || !sequence || !event_mean || !shift_out || !scale_out) return SA_EINVAL;
     const int64_t n_kmers = seq_len - (m->k - 1);
     if (n_kmers <= 0 || n_events <= 0) return SA_EINVAL;
@@ -198,7 +211,7 @@ extern "C" int sa_scalings_mom(const sa_model_t *m, const char *sequence, int64_
     for (int64_t i = 0; i < n_events; i++) ev_sum += event_mean[i];
     double km_sum = 0.0f, km_sq = 0.0f;
     for (int64_t i = 0; i < n_kmers; i++) {
-        int64_t id = sa_model_kmer_id(m, sequence + i);
+        int64_t id = ea_kmer_id(m, sequence + i, (flags & SA_FLAG_RNA) != 0);
         if (id < 0) return SA_EALPHABET;
         double level = m->table5[5 * id];
         km_sum += level;
@@ -242,7 +255,7 @@ extern "C" int sa_event_align_batch(const sa_model_t *m, const sa_ea_job_t *jobs
         J.n_kmers = (int) n_kmers;
         ev.insert(ev.end(), jb->event_mean, jb->event_mean + jb->n_events);
         for (int64_t i = 0; i < n_kmers; i++) {
-            int64_t id = sa_model_kmer_id(m, jb->sequence + i);
+            int64_t id = ea_kmer_id(m, jb->sequence + i, (flags & SA_FLAG_RNA) != 0);
             if (id < 0) return SA_EALPHABET;
             const double mu = m->table5[5 * id], sd = m->table5[5 * id + 1];
             kc.push_back(mu);
@@ -328,6 +341,5 @@ done:
     }
     if (rc != SA_OK)
         for (int64_t j = 0; j < n_jobs; j++) { free(pairs_out[j]); pairs_out[j] = nullptr; n_pairs_out[j] = 0; }
-    (void) flags;
     return rc;
 }

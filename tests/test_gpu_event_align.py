@@ -73,3 +73,25 @@ def test_rejected_alignment_reports_why(oracle):
     ek, ee, est = oracle.event_align(om, jobs[0]["event_mean"], oracle.kmer_ids_of(om, jobs[0]["sequence"]))
     assert got[0][2] == est and est != 0 and len(got[0][0]) == 0 and len(ek) == 0
     assert got[1][2] == 0 and len(got[1][0]) > 0
+
+
+def test_rna_kmer_list(oracle):
+    # build_kmer_list(..., rna=true): U -> T, every k-mer reversed (impl/eventAligner.c:772-780)
+    alpha, k, t10, tab = synth.parse_model_table(cases.MODEL_5MER)
+    om = oracle.Model(alpha, k, t10, tab)
+    pm = sa.Model.load(cases.MODEL_5MER)
+    r = synth.make_read(4242, 700, alpha, k, tab)
+    seq = r["ref"].replace("T", "U")
+    ids = oracle.kmer_ids_of(om, seq, rna=True)
+    assert not np.array_equal(ids, oracle.kmer_ids_of(om, r["ref"]))
+    # events drawn for the reversed k-mers, so that the alignment is accepted
+    rng = np.random.default_rng(3)
+    counts = rng.integers(1, 3, size=len(ids))
+    owner = np.repeat(np.arange(len(ids)), counts)
+    ev = rng.normal(tab[5 * ids[owner]], tab[5 * ids[owner] + 1])
+    sh, sc = sa.scalings_mom(pm, seq, ev, flags=sa.FLAG_RNA)
+    assert (sh, sc) == oracle.scalings_mom(om, ev, ids)
+    got = sa.event_align_batch(pm, [dict(sequence=seq, event_mean=ev, scale=sc, shift=sh, var=1.0)], flags=sa.FLAG_RNA)[0]
+    om.set_read_params(sc, sh, 1.0)
+    ek, ee, est = oracle.event_align(om, ev, ids)
+    assert got[2] == est == 0 and np.array_equal(got[0], ek) and np.array_equal(got[1], ee)
