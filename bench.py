@@ -70,10 +70,11 @@ def bench_event_align(args):
     for _ in range(args.warmup):
         sa.event_align_batch(pm, jobs, stats=stats)
     t0 = time.perf_counter()
-    kms = 0.0
+    kms = cms = 0.0
     for _ in range(args.steps):
         out = sa.event_align_batch(pm, jobs, stats=stats)
         kms += stats["kernel_ms"]
+        cms += stats["call_ms"]
     dt = time.perf_counter() - t0
     cells = float(stats["cells"].sum())
     K = args.steps
@@ -82,7 +83,7 @@ def bench_event_align(args):
            "vs_baseline": None, "dtype": "f32 scores / f64 emissions", "data": "synthetic",
            "config": {"workload": "adaptive banded event alignment (impl/eventAligner.c:899-1235), %d synthetic %d-event reads, "
                                   "bandwidth 100" % (args.reads, args.events),
-                      "kernel_ms": kms / K, "kernel_cell_updates_per_s": cells / (kms / K * 1e-3),
+                      "kernel_ms": kms / K, "c_call_ms": cms / K, "kernel_cell_updates_per_s": cells / (kms / K * 1e-3),
                       "reads_aligned": int(sum(1 for o in out if o[2] == 0)), "cells_per_read": cells / max(len(jobs), 1)}}
     if not args.no_cpu_baseline:
         om = oracle.Model(alpha, k, t10, tab)

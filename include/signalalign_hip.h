@@ -194,6 +194,9 @@ int sa_scalings_mom(const sa_model_t *m, const char *sequence, int64_t seq_len, 
 int sa_event_align_batch(const sa_model_t *m, const sa_ea_job_t *jobs, int64_t n_jobs, int device, unsigned flags,
                          sa_ea_pair_t **pairs_out, int64_t *n_pairs_out, int32_t *status_out, double *cells_out,
                          double *kernel_ms_out);
+/* sa_event_align_batch keeps its device and pinned-host scratch between calls (grow only, one workspace per process,
+ * calls serialise on it); this returns the memory.  Safe to call at any time, also when nothing is held. */
+void sa_event_align_release(void);
 
 /* Plans a whole batch on the host (no GPU needed) with `threads` planner threads (0 = as sa_batch_create would) and
  * returns aggregate geometry plus a 64-bit FNV-1a digest over every array that would be uploaded.  The digest must

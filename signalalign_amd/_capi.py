@@ -1,5 +1,6 @@
 """ctypes mirror of include/signalalign_hip.h.  No arithmetic happens here."""
 import ctypes as C
+import time
 import os
 import subprocess
 
@@ -67,7 +68,7 @@ EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alp
            "sa_model_set_to_hdp_expected_values", "sa_kmer_id", "sa_default_ambig", "sa_load_ambig",
            "sa_batch_create", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_stats",
            "sa_batch_job_cells", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_plan_describe", "sa_plan_digest",
-           "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_device_count", "sa_strerror",
+           "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_device_count", "sa_strerror",
            "sa_version", "sa_free"]
 
 
@@ -353,11 +354,13 @@ def event_align_batch(model, jobs, device=0, flags=0, stats=None):
     st = np.zeros(max(n, 1), dtype=np.int32)
     cells = np.zeros(max(n, 1), dtype=np.float64)
     kms = C.c_double()
+    t0 = time.perf_counter()
     _chk(lib().sa_event_align_batch(model._h, arr, n, device, flags, ptrs, _ip(cnt), st.ctypes.data_as(C.POINTER(C.c_int32)),
                                     _dp(cells), C.byref(kms)), "sa_event_align_batch")
     if stats is not None:
         stats["cells"] = cells[:n].copy()
         stats["kernel_ms"] = kms.value
+        stats["call_ms"] = (time.perf_counter() - t0) * 1e3  # the C call alone, without this wrapper's marshalling
     out = []
     for i in range(n):
         a = np.zeros((int(cnt[i]), 2), dtype=np.int32)

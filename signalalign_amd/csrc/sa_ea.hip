@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "sa_internal.h"
@@ -179,17 +180,33 @@ __global__ __launch_bounds__(64) void k_event_align(EaPlan P, int n_jobs) {
     P.n_out[job] = st ? 0 : n;
 }
 
-// k-mer id of position i as build_kmer_list (impl/eventAligner.c:772-790) lists it: for RNA, U reads as T and the k-mer
-// is reversed
-static int64_t ea_kmer_id(const sa_model_t *m, const char *p, bool rna) {
-    if (!rna) return sa_model_kmer_id(m, p);
-    char tmp[64];
-    for (int i = 0; i < m->k; i++) {
-        char c = p[m->k - 1 - i];
-        tmp[i] = c == 'U' ? 'T' : c;
+// k-mer ids of every position as build_kmer_list (impl/eventAligner.c:772-790) lists them (for RNA, U reads as T and
+// every k-mer is reversed), computed by rolling the id along the sequence.  Returns SA_EALPHABET for a foreign letter.
+static int ea_kmer_ids(const sa_model_t *m, const char *seq, int64_t n_kmers, bool rna, int32_t *out) {
+    int8_t digit[256];
+    memset(digit, -1, sizeof(digit));
+    for (int i = 0; i < m->n_alpha; i++) digit[(unsigned char) m->alphabet[i]] = (int8_t) i;
+    if (rna && digit[(unsigned char) 'T'] >= 0) digit[(unsigned char) 'U'] = digit[(unsigned char) 'T'];
+    const int k = m->k;
+    const int64_t A = m->n_alpha, top = m->pow_km1, full = top * A;  // A^(k-1), A^k
+    const int64_t n = n_kmers + k - 1;
+    for (int64_t i = 0; i < n; i++)
+        if (digit[(unsigned char) seq[i]] < 0) return SA_EALPHABET;
+    int64_t id = 0;
+    if (!rna) {  // forward k-mers, left to right: shift in the new letter, take out the one that left the window
+        for (int64_t i = 0; i < n; i++) {
+            id = id * A + digit[(unsigned char) seq[i]];
+            if (i >= k) id -= digit[(unsigned char) seq[i - k]] * full;
+            if (i >= k - 1) out[i - (k - 1)] = (int32_t) id;
+        }
+    } else {     // reversed k-mers (letter j of the window weighs A^j), right to left for the same division-free roll
+        for (int64_t i = n - 1; i >= 0; i--) {
+            id = id * A + digit[(unsigned char) seq[i]];
+            if (i + k < n) id -= digit[(unsigned char) seq[i + k]] * full;
+            if (i < n_kmers) out[i] = (int32_t) id;
+        }
     }
-    tmp[m->k] = 0;
-    return sa_model_kmer_id(m, tmp);
+    return SA_OK;
 }
 
 #define EACHK(call)                                                                                         \
@@ -210,9 +227,12 @@ extern "C" int sa_scalings_mom(const sa_model_t *m, const char *sequence, int64_
     double ev_sum = 0.0f;
     for (int64_t i = 0; i < n_events; i++) ev_sum += event_mean[i];
     double km_sum = 0.0f, km_sq = 0.0f;
+    std::vector<int32_t> ids;
+    ids.resize((size_t) n_kmers);
+    int rck = ea_kmer_ids(m, sequence, n_kmers, (flags & SA_FLAG_RNA) != 0, ids.data());
+    if (rck) return rck;
     for (int64_t i = 0; i < n_kmers; i++) {
-        int64_t id = ea_kmer_id(m, sequence + i, (flags & SA_FLAG_RNA) != 0);
-        if (id < 0) return SA_EALPHABET;
+        int64_t id = ids[(size_t) i];
         double level = m->table5[5 * id];
         km_sum += level;
         km_sq += pow(level, 2.0f);
@@ -223,6 +243,73 @@ extern "C" int sa_scalings_mom(const sa_model_t *m, const char *sequence, int64_
     *shift_out = shift;
     *scale_out = (ev_sq / (double) n_events) / (km_sq / (double) n_kmers);
     return SA_OK;
+}
+
+// kc[i] = constants of the k-mer at position i (24 bytes per position written on the device instead of uploaded)
+__global__ void k_ea_expand(const double *__restrict__ kt, const int32_t *__restrict__ ids, double *__restrict__ kc, long long n) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *src = kt + 3ll * ids[i];
+    kc[3 * i] = src[0];
+    kc[3 * i + 1] = src[1];
+    kc[3 * i + 2] = src[2];
+}
+
+// Device and pinned-host scratch of sa_event_align_batch, kept between calls (grow only) so that a caller feeding
+// batches in a loop pays allocation once; sa_event_align_release() returns it.  One workspace per process, calls
+// serialise on it.
+struct EaWorkspace {
+    std::mutex mu;
+    int device = -1;
+    void *d_ws = nullptr, *d_trace = nullptr, *h_in = nullptr, *h_res = nullptr;
+    size_t d_ws_cap = 0, d_trace_cap = 0, h_in_cap = 0, h_res_cap = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    void release() {
+        if (device >= 0) (void) hipSetDevice(device);
+        if (d_ws) (void) hipFree(d_ws);
+        if (d_trace) (void) hipFree(d_trace);
+        if (h_in) (void) hipHostFree(h_in);
+        if (h_res) (void) hipHostFree(h_res);
+        if (e0) (void) hipEventDestroy(e0);
+        if (e1) (void) hipEventDestroy(e1);
+        d_ws = d_trace = h_in = h_res = nullptr;
+        d_ws_cap = d_trace_cap = h_in_cap = h_res_cap = 0;
+        e0 = e1 = nullptr;
+        device = -1;
+    }
+    int rebind(int dev) {
+        if (device != dev) { release(); device = dev; }
+        return hipSetDevice(dev) == hipSuccess ? SA_OK : SA_ENODEVICE;
+    }
+    int dev(void **p, size_t *cap, size_t bytes, int devno) {
+        int rc = rebind(devno);
+        if (rc) return rc;
+        if (bytes <= *cap) return SA_OK;
+        if (*p) (void) hipFree(*p);
+        *p = nullptr; *cap = 0;
+        bytes += bytes / 8;
+        if (hipMalloc(p, bytes) != hipSuccess) { *p = nullptr; return SA_ENOMEM; }
+        *cap = bytes;
+        return SA_OK;
+    }
+    int pin(void **p, size_t *cap, size_t bytes, int devno) {
+        int rc = rebind(devno);
+        if (rc) return rc;
+        if (bytes <= *cap) return SA_OK;
+        if (*p) (void) hipHostFree(*p);
+        *p = nullptr; *cap = 0;
+        bytes += bytes / 8;
+        if (hipHostMalloc(p, bytes, hipHostMallocDefault) != hipSuccess) { *p = nullptr; return SA_ENOMEM; }
+        *cap = bytes;
+        return SA_OK;
+    }
+};
+static EaWorkspace g_ea_ws;
+static inline size_t ea_up(size_t x) { return (x + 255) & ~(size_t) 255; }
+
+extern "C" void sa_event_align_release(void) {
+    std::lock_guard<std::mutex> guard(g_ea_ws.mu);
+    g_ea_ws.release();
 }
 
 extern "C" int sa_event_align_batch(const sa_model_t *m, const sa_ea_job_t *jobs, int64_t n_jobs, int device, unsigned flags,
@@ -240,28 +327,47 @@ extern "C" int sa_event_align_batch(const sa_model_t *m, const sa_ea_job_t *jobs
     if (n_jobs == 0) return SA_OK;
     // host side: k-mer constants and offsets
     std::vector<EaJob> hj((size_t) n_jobs);
-    std::vector<double> ev, kc;
-    long long trace_tot = 0, ll_tot = 0, col_tot = 0, out_tot = 0;
+    size_t ev_tot = 0, kc_tot = 0;
     for (int64_t j = 0; j < n_jobs; j++) {
         const sa_ea_job_t *jb = &jobs[j];
         const int64_t n_kmers = jb->seq_len - (m->k - 1);
         if (!jb->sequence || !jb->event_mean || n_kmers <= 0 || jb->n_events <= 0 || !(jb->var > 0.0) ||
             jb->n_events > (1 << 24) || n_kmers > (1 << 24))
             return SA_EINVAL;
+        ev_tot += (size_t) jb->n_events;
+        kc_tot += 3 * (size_t) n_kmers;
+    }
+    EaWorkspace &W = g_ea_ws;
+    std::lock_guard<std::mutex> guard(W.mu);
+    int rc = SA_OK;
+    if (hipSetDevice(device) != hipSuccess) return SA_ENODEVICE;
+    // pinned upload image: event means | per-model k-mer constants {level mean, level sd, -log(sqrt(2 pi)) - log(sd)} |
+    // k-mer id of every position (the device expands ids to per-position constants, k_ea_expand)
+    const size_t kt_n = 3 * (size_t) m->n_kmers, in_bytes = sizeof(double) * (ev_tot + kt_n) + sizeof(int32_t) * (kc_tot / 3);
+    if ((rc = W.pin(&W.h_in, &W.h_in_cap, in_bytes, device)) != SA_OK) return rc;
+    double *ev = (double *) W.h_in, *kt = ev + ev_tot;
+    int32_t *ids = (int32_t *) (kt + kt_n);
+    for (int64_t id = 0; id < m->n_kmers; id++) {
+        const double mu = m->table5[5 * id], sd = m->table5[5 * id + 1];
+        kt[3 * (size_t) id] = mu;
+        kt[3 * (size_t) id + 1] = sd == 0.0 ? 1.0 : sd;
+        kt[3 * (size_t) id + 2] = sd == 0.0 ? -INFINITY : (-0.91893853320467267 - log(sd));
+    }
+    size_t ev_n = 0, kc_n = 0;
+    long long trace_tot = 0, ll_tot = 0, col_tot = 0, out_tot = 0;
+    for (int64_t j = 0; j < n_jobs; j++) {
+        const sa_ea_job_t *jb = &jobs[j];
+        const int64_t n_kmers = jb->seq_len - (m->k - 1);
         EaJob &J = hj[(size_t) j];
-        J.ev_off = (long long) ev.size();
-        J.kc_off = (long long) (kc.size() / 3);
+        J.ev_off = (long long) ev_n;
+        J.kc_off = (long long) (kc_n / 3);
         J.n_events = (int) jb->n_events;
         J.n_kmers = (int) n_kmers;
-        ev.insert(ev.end(), jb->event_mean, jb->event_mean + jb->n_events);
-        for (int64_t i = 0; i < n_kmers; i++) {
-            int64_t id = ea_kmer_id(m, jb->sequence + i, (flags & SA_FLAG_RNA) != 0);
-            if (id < 0) return SA_EALPHABET;
-            const double mu = m->table5[5 * id], sd = m->table5[5 * id + 1];
-            kc.push_back(mu);
-            kc.push_back(sd == 0.0 ? 1.0 : sd);
-            kc.push_back(sd == 0.0 ? -INFINITY : (-0.91893853320467267 - log(sd)));
-        }
+        memcpy(ev + ev_n, jb->event_mean, sizeof(double) * (size_t) jb->n_events);
+        ev_n += (size_t) jb->n_events;
+        int rck = ea_kmer_ids(m, jb->sequence, n_kmers, (flags & SA_FLAG_RNA) != 0, ids + kc_n / 3);
+        if (rck) return rck;
+        kc_n += 3 * (size_t) n_kmers;
         const long long n_bands = (long long) (jb->n_events + 1) + (n_kmers + 1);
         J.trace_off = trace_tot; trace_tot += n_bands * EA_BW;
         J.ll_off = ll_tot; ll_tot += n_bands;
@@ -277,68 +383,61 @@ extern "C" int sa_event_align_batch(const sa_model_t *m, const sa_ea_job_t *jobs
         J.scale = jb->scale; J.shift = jb->shift; J.var = jb->var;
         J.lvar = log((1 / jb->var));
     }
-    int rc = SA_OK;
     EaPlan P;
     memset(&P, 0, sizeof(P));
-    EaJob *d_jobs = nullptr;
-    double *d_ev = nullptr, *d_kc = nullptr, *d_col = nullptr;
-    unsigned char *d_trace = nullptr;
-    int *d_ll = nullptr, *d_out = nullptr, *d_n = nullptr, *d_st = nullptr, *d_fills = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
     float kms = 0;
-    std::vector<int> h_n((size_t) n_jobs), h_st((size_t) n_jobs), h_fills((size_t) n_jobs), h_out;
-    EACHK(hipSetDevice(device));
-    EACHK(hipMalloc((void **) &d_jobs, sizeof(EaJob) * (size_t) n_jobs));
-    EACHK(hipMalloc((void **) &d_ev, sizeof(double) * ev.size()));
-    EACHK(hipMalloc((void **) &d_kc, sizeof(double) * kc.size()));
-    EACHK(hipMalloc((void **) &d_trace, (size_t) trace_tot));
-    EACHK(hipMalloc((void **) &d_ll, sizeof(int) * 2 * (size_t) ll_tot));
-    EACHK(hipMalloc((void **) &d_col, sizeof(double) * (size_t) col_tot));
-    EACHK(hipMalloc((void **) &d_out, sizeof(int) * 2 * (size_t) out_tot));
-    EACHK(hipMalloc((void **) &d_n, sizeof(int) * (size_t) n_jobs));
-    EACHK(hipMalloc((void **) &d_st, sizeof(int) * (size_t) n_jobs));
-    EACHK(hipMalloc((void **) &d_fills, sizeof(int) * (size_t) n_jobs));
-    EACHK(hipEventCreate(&e0));
-    EACHK(hipEventCreate(&e1));
-    EACHK(hipMemcpy(d_jobs, hj.data(), sizeof(EaJob) * (size_t) n_jobs, hipMemcpyHostToDevice));
-    EACHK(hipMemcpy(d_ev, ev.data(), sizeof(double) * ev.size(), hipMemcpyHostToDevice));
-    EACHK(hipMemcpy(d_kc, kc.data(), sizeof(double) * kc.size(), hipMemcpyHostToDevice));
-    P.jobs = d_jobs; P.ev = d_ev; P.kc = d_kc; P.trace = d_trace; P.ll = d_ll; P.col = d_col; P.out = d_out;
-    P.n_out = d_n; P.status = d_st; P.fills = d_fills;
-    EACHK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(k_event_align, dim3((unsigned) n_jobs), dim3(64), 0, 0, P, (int) n_jobs);
-    EACHK(hipEventRecord(e1, 0));
-    EACHK(hipGetLastError());
-    EACHK(hipEventSynchronize(e1));
-    EACHK(hipEventElapsedTime(&kms, e0, e1));
+    const size_t nj = (size_t) n_jobs;
+    // device workspace, kept between calls (grow only): [jobs | upload image | kc | ll | col | out | n,status,fills] and the trace plane
+    const size_t o_jobs = 0, o_in = ea_up(o_jobs + sizeof(EaJob) * nj), o_kc = ea_up(o_in + in_bytes),
+                 o_ll = ea_up(o_kc + sizeof(double) * kc_tot),
+                 o_col = ea_up(o_ll + sizeof(int) * 2 * (size_t) ll_tot), o_out = ea_up(o_col + sizeof(double) * (size_t) col_tot),
+                 o_res = ea_up(o_out + sizeof(int) * 2 * (size_t) out_tot), dev_bytes = o_res + sizeof(int) * 3 * nj;
+    const size_t res_bytes = dev_bytes - o_out;  // pair lists and the three per-read result words come back in one copy
+    const int *h_out, *h_n, *h_st, *h_fills;
+    if ((rc = W.dev(&W.d_ws, &W.d_ws_cap, dev_bytes, device)) != SA_OK) goto done;
+    if ((rc = W.dev(&W.d_trace, &W.d_trace_cap, (size_t) trace_tot, device)) != SA_OK) goto done;
+    if ((rc = W.pin(&W.h_res, &W.h_res_cap, res_bytes, device)) != SA_OK) goto done;
+    if (!W.e0) { EACHK(hipEventCreate(&W.e0)); EACHK(hipEventCreate(&W.e1)); }
+    {
+        char *d = (char *) W.d_ws;
+        EACHK(hipMemcpyAsync(d + o_jobs, hj.data(), sizeof(EaJob) * nj, hipMemcpyHostToDevice, 0));
+        EACHK(hipMemcpyAsync(d + o_in, W.h_in, in_bytes, hipMemcpyHostToDevice, 0));
+        P.jobs = (EaJob *) (d + o_jobs); P.ev = (double *) (d + o_in); P.kc = (double *) (d + o_kc);
+        P.trace = (unsigned char *) W.d_trace; P.ll = (int *) (d + o_ll); P.col = (double *) (d + o_col);
+        P.out = (int *) (d + o_out); P.n_out = (int *) (d + o_res); P.status = P.n_out + nj; P.fills = P.status + nj;
+        EACHK(hipEventRecord(W.e0, 0));
+        {
+            const long long n_pos = (long long) (kc_tot / 3);
+            const double *d_kt = P.ev + ev_tot;
+            hipLaunchKernelGGL(k_ea_expand, dim3((unsigned) ((n_pos + 255) / 256)), dim3(256), 0, 0, d_kt,
+                               (const int32_t *) (d_kt + kt_n), (double *) (d + o_kc), n_pos);
+        }
+        hipLaunchKernelGGL(k_event_align, dim3((unsigned) n_jobs), dim3(64), 0, 0, P, (int) n_jobs);
+        EACHK(hipEventRecord(W.e1, 0));
+        EACHK(hipGetLastError());
+        EACHK(hipMemcpyAsync(W.h_res, d + o_out, res_bytes, hipMemcpyDeviceToHost, 0));
+        EACHK(hipStreamSynchronize(0));
+        EACHK(hipEventElapsedTime(&kms, W.e0, W.e1));
+    }
     if (kernel_ms_out) *kernel_ms_out = (double) kms;
-    EACHK(hipMemcpy(h_fills.data(), d_fills, sizeof(int) * (size_t) n_jobs, hipMemcpyDeviceToHost));
+    h_out = (const int *) W.h_res;
+    h_n = (const int *) ((const char *) W.h_res + (o_res - o_out));
+    h_st = h_n + nj; h_fills = h_st + nj;
     if (cells_out)
         for (int64_t j = 0; j < n_jobs; j++) cells_out[j] = (double) h_fills[(size_t) j];
-    EACHK(hipMemcpy(h_n.data(), d_n, sizeof(int) * (size_t) n_jobs, hipMemcpyDeviceToHost));
-    EACHK(hipMemcpy(h_st.data(), d_st, sizeof(int) * (size_t) n_jobs, hipMemcpyDeviceToHost));
-    h_out.resize(2 * (size_t) out_tot);
-    EACHK(hipMemcpy(h_out.data(), d_out, sizeof(int) * 2 * (size_t) out_tot, hipMemcpyDeviceToHost));
     for (int64_t j = 0; j < n_jobs; j++) {
         const int n = h_n[(size_t) j];
         if (status_out) status_out[j] = h_st[(size_t) j];
         n_pairs_out[j] = n;
         pairs_out[j] = (sa_ea_pair_t *) malloc(sizeof(sa_ea_pair_t) * (size_t) (n > 0 ? n : 1));
         if (!pairs_out[j]) { rc = SA_ENOMEM; goto done; }
-        const int *src = h_out.data() + 2 * hj[(size_t) j].out_off;
+        const int *src = h_out + 2 * hj[(size_t) j].out_off;
         for (int i = 0; i < n; i++) {  // stList_reverse: ascending order
             pairs_out[j][i].kmer_idx = src[2 * (n - 1 - i)];
             pairs_out[j][i].event_idx = src[2 * (n - 1 - i) + 1];
         }
     }
 done:
-    {
-        if (e0) (void) hipEventDestroy(e0);
-        if (e1) (void) hipEventDestroy(e1);
-        void *ptrs[] = {d_jobs, d_ev, d_kc, d_trace, d_ll, d_col, d_out, d_n, d_st, d_fills};
-        for (void *p : ptrs)
-            if (p) (void) hipFree(p);
-    }
     if (rc != SA_OK)
         for (int64_t j = 0; j < n_jobs; j++) { free(pairs_out[j]); pairs_out[j] = nullptr; n_pairs_out[j] = 0; }
     return rc;
