@@ -166,6 +166,20 @@ void sao_scalings_mom(const sao_model_t *m, const double *event_mean, int64_t n_
                       int64_t n_kmers, double *shift_out, double *scale_out); /* impl/eventAligner.c:784-843 */
 void sao_free(void *p);
 
+/* maximum-expected-accuracy path over a read's posteriors, src/signalalign/mea_algorithm.py (sa_mea_oracle.c) */
+#define SAO_MEA_OK 0
+#define SAO_MEA_EMPTY 1        /* no entries: min() of an empty sequence raises ValueError (:42)             */
+#define SAO_MEA_SINGLE_EVENT 2 /* every entry belongs to the first event: IndexError at :61                  */
+#define SAO_MEA_NO_FRONT 3     /* an event starts with no forward edge left: IndexError at :106              */
+#define SAO_MEA_NO_PATH 4      /* no final edge with a sum above 0: the reference returns the int 0 (:188)   */
+#define SAO_MEA_BAD_EVENT 5    /* event index outside shortest_ref_per_event: IndexError at :106             */
+int sao_mea(const int32_t *rows, const int32_t *cols, const double *data, int64_t n, const int32_t *shortest,
+            int64_t n_shortest, int32_t **path_ref, int32_t **path_event, int64_t *n_path, double *best_sum,
+            double **edge_sums, int64_t *n_edges);
+int64_t sao_mea_params(const int64_t *reference_index, const int64_t *event_index, const double *posterior, int64_t n,
+                       int32_t *rows_out, int32_t *cols_out, double *data_out, int32_t *shortest_out,
+                       int64_t *n_events_out);
+
 /* multi-threaded batch driver used by bench.py's cpu_baseline leg (one read per thread). */
 typedef struct sao_job {
     const char *ref; int64_t lX;

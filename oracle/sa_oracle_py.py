@@ -48,8 +48,8 @@ PAIR_DTYPE = np.dtype([("prob_e7", "<i8"), ("x", "<i8"), ("y", "<i8"), ("path", 
 
 def build(force=False):
     so = os.path.join(_HERE, "libsa_oracle.so")
-    src = os.path.join(_HERE, "sa_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("sa_oracle.c", "sa_mea_oracle.c", "sa_oracle.h")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
 
@@ -165,6 +165,102 @@ def event_align(model, event_means, kmer_ids):
         lib().sao_free(ko)
         lib().sao_free(eo)
     return k, e, st.value
+
+
+MEA_INF = 2 ** 31 - 1   # shortest_ref_per_event entry of an event without rows (the reference's np.inf)
+MEA_STATUS = {0: "ok", 1: "empty", 2: "single event", 3: "no forward edge", 4: "no path", 5: "bad event index"}
+
+
+def mea(rows, cols, data, shortest, return_all=False):
+    """maximum_expected_accuracy_alignment + get_indexes_from_best_path (src/signalalign/mea_algorithm.py:25-264) on a
+    COO matrix.  Returns (status, path [n, 2] of (ref, event), best sum) or, with return_all, the sums of all final
+    forward edges as a fourth element."""
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    cols = np.ascontiguousarray(cols, dtype=np.int32)
+    data = np.ascontiguousarray(data, dtype=np.float64)
+    sh = np.asarray(shortest, dtype=np.float64)
+    sh = np.ascontiguousarray(np.where(np.isfinite(sh), sh, MEA_INF).astype(np.int32))
+    i32p = C.POINTER(C.c_int32)
+    f = lib().sao_mea
+    f.restype = C.c_int
+    f.argtypes = [i32p, i32p, C.POINTER(C.c_double), C.c_int64, i32p, C.c_int64, C.POINTER(i32p), C.POINTER(i32p),
+                  C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int64)]
+    pr, pe, ne, best = i32p(), i32p(), C.c_int64(), C.c_double()
+    es, n_es = C.POINTER(C.c_double)(), C.c_int64()
+    st = f(rows.ctypes.data_as(i32p), cols.ctypes.data_as(i32p), _dp(data), len(rows), sh.ctypes.data_as(i32p), len(sh),
+           C.byref(pr), C.byref(pe), C.byref(ne), C.byref(best), C.byref(es), C.byref(n_es))
+    path = np.zeros((ne.value, 2), dtype=np.int32)
+    if ne.value:
+        path[:, 0] = np.ctypeslib.as_array(pr, (ne.value,))
+        path[:, 1] = np.ctypeslib.as_array(pe, (ne.value,))
+    sums = np.ctypeslib.as_array(es, (n_es.value,)).copy() if n_es.value else np.zeros(0)
+    for q in (pr, pe, es):
+        if q:
+            lib().sao_free(q)
+    return (st, path, best.value, sums) if return_all else (st, path, best.value)
+
+
+def mea_params(reference_index, event_index, posterior):
+    """get_mea_params_from_events (mea_algorithm.py:267-320) in sparse form: (rows, cols, data, shortest_ref_per_event)."""
+    ri = np.ascontiguousarray(reference_index, dtype=np.int64)
+    ei = np.ascontiguousarray(event_index, dtype=np.int64)
+    po = np.ascontiguousarray(posterior, dtype=np.float64)
+    n = len(ri)
+    rows = np.zeros(max(n, 1), dtype=np.int32)
+    cols = np.zeros(max(n, 1), dtype=np.int32)
+    data = np.zeros(max(n, 1), dtype=np.float64)
+    n_ev = int(ei.max() - ei.min() + 1) if n else 1
+    sh = np.zeros(n_ev, dtype=np.int32)
+    i32p = C.POINTER(C.c_int32)
+    f = lib().sao_mea_params
+    f.restype = C.c_int64
+    f.argtypes = [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int64, i32p, i32p,
+                  C.POINTER(C.c_double), i32p, C.POINTER(C.c_int64)]
+    ne = C.c_int64()
+    m = f(_ip(ri), _ip(ei), _dp(po), n, rows.ctypes.data_as(i32p), cols.ctypes.data_as(i32p), _dp(data),
+          sh.ctypes.data_as(i32p), C.byref(ne))
+    if m < 0:
+        raise RuntimeError("sao_mea_params failed: %d" % m)
+    return rows[:m].copy(), cols[:m].copy(), data[:m].copy(), sh
+
+
+def mea_exhaustive(matrix, shortest):
+    """Independent formulation used to cross-check sao_mea on small dense matrices, after the reference's `mea_slow`
+    (mea_algorithm.py:726-816): every cell of an event looks at EVERY forward edge of the previous event.  Pure Python,
+    small cases only.  Returns the best sum (0 when there is none)."""
+    m = np.asarray(matrix, dtype=np.float64)
+    n_ev, n_ref = m.shape
+    front = []   # (ref, sum)
+    started = False
+    for ev in range(n_ev):
+        top = 0.0
+        new = []
+        if not started:
+            for r in range(n_ref):
+                if 0 < m[ev, r] >= top:
+                    new.append((r, m[ev, r]))
+                    top = m[ev, r]
+            if new:
+                front, started = new, True
+            continue
+        opener = None
+        for r in range(n_ref):   # a fresh start above every later reference position (:761-770)
+            if m[ev, r] >= top and r < shortest[ev]:
+                opener = (r, m[ev, r])
+                top = m[ev, r]
+        if opener is not None:
+            new.append(opener)
+        for r in range(n_ref):
+            cand = [s + m[ev, r] for (fr, s) in front if fr < r] + [s for (fr, s) in front if fr == r]
+            if cand:
+                if max(cand) > top:
+                    new.append((r, max(cand)))
+                    top = max(cand)
+            elif front[0][0] > r and m[ev, r] > top:
+                new.append((r, m[ev, r]))
+                top = m[ev, r]
+        front = new
+    return max([s for (_, s) in front], default=0.0)
 
 
 def default_params(threshold=0.01, expansion=50, trace_back=100, min_diags=1000, split=3000 * 3000, trim=14):
