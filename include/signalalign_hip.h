@@ -198,6 +198,46 @@ int sa_event_align_batch(const sa_model_t *m, const sa_ea_job_t *jobs, int64_t n
  * calls serialise on it); this returns the memory.  Safe to call at any time, also when nothing is held. */
 void sa_event_align_release(void);
 
+/* ---- maximum-expected-accuracy path over a read's posteriors ----------------------------------
+ * Replaces maximum_expected_accuracy_alignment + get_indexes_from_best_path (src/signalalign/mea_algorithm.py:25-197,
+ * :248-264; called by mea_alignment_from_signal_align :323-341): the best monotone path through the sparse posterior
+ * matrix, one (reference position, event) pair per event, bit-identical to the reference's choice among ties.
+ * A job is what that function receives: the COO form of posterior_matrix (row = event, column = reference position,
+ * row-major as scipy.sparse.coo_matrix(dense) yields it) and shortest_ref_per_event (INT32_MAX where the reference
+ * holds inf).  sa_mea_params builds both from the columns of a signalAlign event table.  Pinned by the reference's
+ * known-answer matrix (tests/golden/mea/kat_5x5.json). */
+#define SA_MEA_OK 0
+#define SA_MEA_EMPTY 1        /* no entries: the reference raises ValueError (min of an empty sequence, :42)   */
+#define SA_MEA_SINGLE_EVENT 2 /* every entry belongs to the first event: IndexError at :61                      */
+#define SA_MEA_NO_FRONT 3     /* an event starts with no forward edge left: IndexError at :106                  */
+#define SA_MEA_NO_PATH 4      /* no final edge with a sum above 0: the reference returns the int 0 (:188-196)   */
+#define SA_MEA_BAD_EVENT 5    /* event index outside shortest_ref_per_event: IndexError at :106                 */
+#define SA_MEA_INF 2147483647 /* shortest_ref_per_event of an event without rows                                */
+typedef struct sa_mea_job {
+    const int32_t *event_idx;               /* COO row    */
+    const int32_t *ref_idx;                 /* COO column */
+    const double *posterior;                /* COO data   */
+    int64_t n;
+    const int32_t *shortest_ref_per_event;  /* indexed by event_idx */
+    int64_t n_events;
+} sa_mea_job_t;
+typedef struct sa_mea_pair {
+    int32_t ref_idx, event_idx;             /* get_indexes_from_best_path: [ref_pos, event_pos] */
+} sa_mea_pair_t;
+/* One wave per read.  path_out[j] (malloc'd, sa_free) holds n_path_out[j] pairs in path order; status_out[j] one of
+ * SA_MEA_* (a failed read has no path and does not fail the call); sum_out[j] the best edge's sum; n_edges_out[j] the
+ * number of final forward edges (return_all=True); any of the last four pointers may be NULL. */
+int sa_mea_batch(const sa_mea_job_t *jobs, int64_t n_jobs, int device, unsigned flags, sa_mea_pair_t **path_out,
+                 int64_t *n_path_out, double *sum_out, int32_t *status_out, int32_t *n_edges_out, double *kernel_ms_out);
+void sa_mea_release(void); /* returns the scratch sa_mea_batch keeps between calls */
+/* get_mea_params_from_events (mea_algorithm.py:267-320), host side, sparse: from the reference_index, event_index and
+ * posterior_probability columns of an event table (any row order) to the COO entries and shortest_ref_per_event.
+ * The outputs need room for n entries / (max event - min event + 1) events; returns the number of COO entries and the
+ * number of events in *n_events_out, or a negative SA_E* code. */
+int64_t sa_mea_params(const int64_t *reference_index, const int64_t *event_index, const double *posterior, int64_t n,
+                      int32_t *event_idx_out, int32_t *ref_idx_out, double *posterior_out, int32_t *shortest_out,
+                      int64_t *n_events_out);
+
 /* Plans a whole batch on the host (no GPU needed) with `threads` planner threads (0 = as sa_batch_create would) and
  * returns aggregate geometry plus a 64-bit FNV-1a digest over every array that would be uploaded.  The digest must
  * not depend on the number of threads: the CPU test-suite checks exactly that. */

@@ -56,6 +56,15 @@ class EaJob(C.Structure):
                 ("n_events", C.c_int64), ("scale", C.c_double), ("shift", C.c_double), ("var", C.c_double)]
 
 
+class MeaJob(C.Structure):
+    _fields_ = [("event_idx", C.POINTER(C.c_int32)), ("ref_idx", C.POINTER(C.c_int32)), ("posterior", C.POINTER(C.c_double)),
+                ("n", C.c_int64), ("shortest_ref_per_event", C.POINTER(C.c_int32)), ("n_events", C.c_int64)]
+
+
+MEA_INF = 2 ** 31 - 1
+MEA_STATUS = {0: "ok", 1: "empty", 2: "single event", 3: "no forward edge", 4: "no path", 5: "bad event index"}
+
+
 class PlanInfo(C.Structure):
     _fields_ = [("n_regions", C.c_int64), ("n_segments", C.c_int64), ("n_checkpoints", C.c_int64),
                 ("cells_forward", C.c_double), ("cells_backward", C.c_double), ("f_cellpaths", C.c_int64),
@@ -68,7 +77,7 @@ EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alp
            "sa_model_set_to_hdp_expected_values", "sa_kmer_id", "sa_default_ambig", "sa_load_ambig",
            "sa_batch_create", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_stats",
            "sa_batch_job_cells", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_plan_describe", "sa_plan_digest",
-           "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_device_count", "sa_strerror",
+           "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_device_count", "sa_strerror",
            "sa_version", "sa_free"]
 
 
@@ -134,6 +143,10 @@ def lib():
     L.sa_scalings_mom.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, dp, C.c_int64, C.c_uint, dp, dp]
     L.sa_event_align_batch.argtypes = [C.c_void_p, C.POINTER(EaJob), C.c_int64, C.c_int, C.c_uint, C.POINTER(C.c_void_p), ip,
                                        C.POINTER(C.c_int32), dp, dp]
+    i32p = C.POINTER(C.c_int32)
+    L.sa_mea_batch.argtypes = [C.POINTER(MeaJob), C.c_int64, C.c_int, C.c_uint, C.POINTER(C.c_void_p), ip, dp, i32p, i32p, dp]
+    L.sa_mea_params.restype = C.c_int64
+    L.sa_mea_params.argtypes = [ip, ip, dp, C.c_int64, i32p, i32p, dp, i32p, ip]
     L.sa_free.argtypes = [C.c_void_p]
     _LIB = L
     return L
@@ -370,6 +383,64 @@ def event_align_batch(model, jobs, device=0, flags=0, stats=None):
         out.append((a[:, 0].copy(), a[:, 1].copy(), int(st[i])))
     del keep
     return out
+
+
+def _i32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def mea_batch(jobs, device=0, flags=0, stats=None):
+    """sa_mea_batch.  jobs: dicts(event_idx, ref_idx, posterior, shortest) -- the COO posterior matrix and
+    shortest_ref_per_event (np.inf or MEA_INF for events without rows).  Returns per job (path [n, 2] of (ref, event),
+    best sum, status, number of final forward edges)."""
+    n = len(jobs)
+    arr = (MeaJob * max(n, 1))()
+    keep = []
+    for i, j in enumerate(jobs):
+        ev = np.ascontiguousarray(j["event_idx"], dtype=np.int32)
+        rf = np.ascontiguousarray(j["ref_idx"], dtype=np.int32)
+        po = np.ascontiguousarray(j["posterior"], dtype=np.float64)
+        sh = np.asarray(j["shortest"], dtype=np.float64)
+        sh = np.ascontiguousarray(np.where(np.isfinite(sh), sh, MEA_INF).astype(np.int32))
+        keep.append((ev, rf, po, sh))
+        arr[i] = MeaJob(_i32p(ev), _i32p(rf), _dp(po), len(ev), _i32p(sh), len(sh))
+    ptrs = (C.c_void_p * max(n, 1))()
+    cnt = np.zeros(max(n, 1), dtype=np.int64)
+    sums = np.zeros(max(n, 1), dtype=np.float64)
+    st = np.zeros(max(n, 1), dtype=np.int32)
+    ne = np.zeros(max(n, 1), dtype=np.int32)
+    kms = C.c_double()
+    t0 = time.perf_counter()
+    _chk(lib().sa_mea_batch(arr, n, device, flags, ptrs, _ip(cnt), _dp(sums), _i32p(st), _i32p(ne), C.byref(kms)), "sa_mea_batch")
+    if stats is not None:
+        stats["kernel_ms"] = kms.value
+        stats["call_ms"] = (time.perf_counter() - t0) * 1e3
+    out = []
+    for i in range(n):
+        a = np.zeros((int(cnt[i]), 2), dtype=np.int32)
+        if cnt[i]:
+            C.memmove(a.ctypes.data, ptrs[i], 8 * int(cnt[i]))
+        lib().sa_free(ptrs[i])
+        out.append((a, float(sums[i]), int(st[i]), int(ne[i])))
+    del keep
+    return out
+
+
+def mea_params(reference_index, event_index, posterior):
+    """sa_mea_params: event-table columns -> (event_idx, ref_idx, posterior, shortest_ref_per_event)."""
+    ri = np.ascontiguousarray(reference_index, dtype=np.int64)
+    ei = np.ascontiguousarray(event_index, dtype=np.int64)
+    po = np.ascontiguousarray(posterior, dtype=np.float64)
+    n = len(ri)
+    rows = np.zeros(max(n, 1), dtype=np.int32)
+    cols = np.zeros(max(n, 1), dtype=np.int32)
+    data = np.zeros(max(n, 1), dtype=np.float64)
+    sh = np.zeros(int(ei.max() - ei.min() + 1) if n else 1, dtype=np.int32)
+    ne = C.c_int64()
+    m = lib().sa_mea_params(_ip(ri), _ip(ei), _dp(po), n, _i32p(rows), _i32p(cols), _dp(data), _i32p(sh), C.byref(ne))
+    if m < 0:
+        _chk(int(m), "sa_mea_params")
+    return rows[:m].copy(), cols[:m].copy(), data[:m].copy(), sh
 
 
 def plan_digest(model, params, jobs, ambig=None, flags=0, threads=0):

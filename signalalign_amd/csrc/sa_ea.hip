@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "sa_internal.h"
+#include "sa_scratch.h"
 
 #define EA_BW 100
 #define EA_HALF 50
@@ -255,57 +256,13 @@ __global__ void k_ea_expand(const double *__restrict__ kt, const int32_t *__rest
     kc[3 * i + 2] = src[2];
 }
 
-// Device and pinned-host scratch of sa_event_align_batch, kept between calls (grow only) so that a caller feeding
-// batches in a loop pays allocation once; sa_event_align_release() returns it.  One workspace per process, calls
-// serialise on it.
-struct EaWorkspace {
-    std::mutex mu;
-    int device = -1;
+// Device and pinned-host scratch of sa_event_align_batch, kept between calls (sa_scratch.h).
+struct EaWorkspace : SaScratch {
     void *d_ws = nullptr, *d_trace = nullptr, *h_in = nullptr, *h_res = nullptr;
     size_t d_ws_cap = 0, d_trace_cap = 0, h_in_cap = 0, h_res_cap = 0;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    void release() {
-        if (device >= 0) (void) hipSetDevice(device);
-        if (d_ws) (void) hipFree(d_ws);
-        if (d_trace) (void) hipFree(d_trace);
-        if (h_in) (void) hipHostFree(h_in);
-        if (h_res) (void) hipHostFree(h_res);
-        if (e0) (void) hipEventDestroy(e0);
-        if (e1) (void) hipEventDestroy(e1);
-        d_ws = d_trace = h_in = h_res = nullptr;
-        d_ws_cap = d_trace_cap = h_in_cap = h_res_cap = 0;
-        e0 = e1 = nullptr;
-        device = -1;
-    }
-    int rebind(int dev) {
-        if (device != dev) { release(); device = dev; }
-        return hipSetDevice(dev) == hipSuccess ? SA_OK : SA_ENODEVICE;
-    }
-    int dev(void **p, size_t *cap, size_t bytes, int devno) {
-        int rc = rebind(devno);
-        if (rc) return rc;
-        if (bytes <= *cap) return SA_OK;
-        if (*p) (void) hipFree(*p);
-        *p = nullptr; *cap = 0;
-        bytes += bytes / 8;
-        if (hipMalloc(p, bytes) != hipSuccess) { *p = nullptr; return SA_ENOMEM; }
-        *cap = bytes;
-        return SA_OK;
-    }
-    int pin(void **p, size_t *cap, size_t bytes, int devno) {
-        int rc = rebind(devno);
-        if (rc) return rc;
-        if (bytes <= *cap) return SA_OK;
-        if (*p) (void) hipHostFree(*p);
-        *p = nullptr; *cap = 0;
-        bytes += bytes / 8;
-        if (hipHostMalloc(p, bytes, hipHostMallocDefault) != hipSuccess) { *p = nullptr; return SA_ENOMEM; }
-        *cap = bytes;
-        return SA_OK;
-    }
 };
 static EaWorkspace g_ea_ws;
-static inline size_t ea_up(size_t x) { return (x + 255) & ~(size_t) 255; }
+static inline size_t ea_up(size_t x) { return sa_up256(x); }
 
 extern "C" void sa_event_align_release(void) {
     std::lock_guard<std::mutex> guard(g_ea_ws.mu);
@@ -397,7 +354,7 @@ extern "C" int sa_event_align_batch(const sa_model_t *m, const sa_ea_job_t *jobs
     if ((rc = W.dev(&W.d_ws, &W.d_ws_cap, dev_bytes, device)) != SA_OK) goto done;
     if ((rc = W.dev(&W.d_trace, &W.d_trace_cap, (size_t) trace_tot, device)) != SA_OK) goto done;
     if ((rc = W.pin(&W.h_res, &W.h_res_cap, res_bytes, device)) != SA_OK) goto done;
-    if (!W.e0) { EACHK(hipEventCreate(&W.e0)); EACHK(hipEventCreate(&W.e1)); }
+    if ((rc = W.events()) != SA_OK) goto done;
     {
         char *d = (char *) W.d_ws;
         EACHK(hipMemcpyAsync(d + o_jobs, hj.data(), sizeof(EaJob) * nj, hipMemcpyHostToDevice, 0));

@@ -1,0 +1,534 @@
+// Maximum-expected-accuracy path over a read's posteriors on gfx950 -- SURVEY.md §8(f) row 3, the step immediately
+// downstream of the pair-HMM: maximum_expected_accuracy_alignment + get_indexes_from_best_path
+// (src/signalalign/mea_algorithm.py:25-197, :248-264).
+//
+// The reference walks the sparse posterior matrix (COO, row = event, column = reference position) in row-major order
+// and keeps a short front of "forward edges" (reference position, best sum so far, back pointer) whose sums rise with
+// the reference position; every entry extends the best edge to its left ("move", the sum grows by the posterior) or
+// the edge in its own column ("stay", the sum is kept).  The recurrence is a chain: entry j needs the front entry j-1
+// left behind, and the result must equal the reference's choice among ties, so the work inside one read is serial.
+// The parallelism is across reads: ONE WAVE PER READ, run wave-uniformly -- 64 entries are fetched with one coalesced
+// load and handed to the serial loop by v_readlane, the two fronts live in LDS (ping-pong), the edge arena (reference
+// position, event, back pointer) streams out to HBM and is read back in 64-record blocks for the traceback, so the
+// chain of dependent HBM loads a pointer walk would be becomes one load per 64 arena records.  A read whose front
+// outgrows its LDS share is re-run by the same kernel body with its fronts in global memory (k_mea<true>).
+//
+// Branch order, comparison strictness and the order of the double additions follow the reference line by line
+// (there are no multiplications to contract): paths and sums are bit-identical to oracle/sa_mea_oracle.c.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "sa_internal.h"
+#include "sa_scratch.h"
+
+#define MEA_FRONT_CAP 256     // entries per LDS front (2 fronts x 16 bytes x 256 = 8 KB per wave)
+#define MEA_ST_OVERFLOW 100   // internal: front outgrew LDS, the read is re-run with global fronts
+
+struct MeaJob {
+    long long off;      // first COO entry (and first arena record) of the read
+    long long sh_off;   // first shortest_ref_per_event entry
+    long long out_off;  // first output pair
+    long long gf_off;   // first global-front entry (second pass only)
+    int n, n_sh, out_cap, pad;
+};
+
+struct MeaPlan {
+    const MeaJob *jobs;
+    const int *rows, *cols;
+    const double *data;
+    const int *shortest;
+    int *a_ref, *a_ev, *a_prev;  // edge arena, one record per COO entry at most
+    int2 *out;                   // path, written backwards from out_off + out_cap
+    int *n_out, *n_edges, *status;
+    double *sum;
+    int *gf_ref, *gf_id;         // global fronts (k_mea<true>)
+    double *gf_sum;
+};
+
+__device__ __forceinline__ int rl(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
+__device__ __forceinline__ double rld(double v, int k) {
+    return __hiloint2double(rl(__double2hiint(v), k), rl(__double2loint(v), k));
+}
+__device__ __forceinline__ int wave_min(int v) {
+    for (int o = 32; o; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+    for (int o = 32; o; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+
+template <bool GLOBAL_FRONT>
+__global__ __launch_bounds__(64) void k_mea(MeaPlan P, const int *__restrict__ ids, int n_ids) {
+    const int jb = ids ? ids[blockIdx.x] : (int) blockIdx.x;
+    const int lane = threadIdx.x;
+    const MeaJob J = P.jobs[jb];
+    const int *__restrict__ rows = P.rows + J.off;
+    const int *__restrict__ cols = P.cols + J.off;
+    const double *__restrict__ data = P.data + J.off;
+    const int *__restrict__ shortest = P.shortest + J.sh_off;
+    int *a_ref = P.a_ref + J.off, *a_ev = P.a_ev + J.off, *a_prev = P.a_prev + J.off;
+    const int n = J.n;
+
+    __shared__ int s_ref[2 * MEA_FRONT_CAP], s_id[2 * MEA_FRONT_CAP];
+    __shared__ double s_sum[2 * MEA_FRONT_CAP];
+    const int cap = GLOBAL_FRONT ? n + 2 : MEA_FRONT_CAP;
+    int *f_ref, *f_id, *n_ref, *n_id;      // F = forward edges of the previous events, N = new edges
+    double *f_sum, *n_sum;
+    if (GLOBAL_FRONT) {
+        f_ref = P.gf_ref + J.gf_off; f_id = P.gf_id + J.gf_off; f_sum = P.gf_sum + J.gf_off;
+        n_ref = f_ref + cap; n_id = f_id + cap; n_sum = f_sum + cap;
+    } else {
+        f_ref = s_ref; f_id = s_id; f_sum = s_sum;
+        n_ref = s_ref + MEA_FRONT_CAP; n_id = s_id + MEA_FRONT_CAP; n_sum = s_sum + MEA_FRONT_CAP;
+    }
+    int nF = 0, nN = 0, na = 0, status = SA_MEA_OK, n_edges = 0, n_path = 0;
+    double best_sum = 0.0;
+
+// every lane holds the same values and writes them: a lane reads back what it wrote itself (LDS or global)
+#define N_PUSH(ref_, id_, sum_)                                   \
+    do {                                                          \
+        if (nN >= cap) { status = MEA_ST_OVERFLOW; goto done; }   \
+        n_ref[nN] = (ref_); n_id[nN] = (id_); n_sum[nN] = (sum_); \
+        nN++;                                                     \
+    } while (0)
+#define ARENA_PUSH(ref_, ev_, prev_)                                                 \
+    do {                                                                             \
+        if (lane == 0) { a_ref[na] = (ref_); a_ev[na] = (ev_); a_prev[na] = (prev_); } \
+        na++;                                                                        \
+    } while (0)
+#define SWAP_FRONTS()                                                        \
+    do {                                                                     \
+        int *t_; double *u_;                                                 \
+        t_ = f_ref; f_ref = n_ref; n_ref = t_; t_ = f_id; f_id = n_id; n_id = t_; \
+        u_ = f_sum; f_sum = n_sum; n_sum = u_;                               \
+        nF = nN;                                                             \
+    } while (0)
+
+    if (n <= 0) { status = SA_MEA_EMPTY; goto done; }
+    {
+        // :41-58 the first event: its entries up to the largest posterior, kept while they do not fall
+        int smallest = 0x7fffffff;
+        for (int j = lane; j < n; j += 64) smallest = min(smallest, rows[j]);
+        smallest = wave_min(smallest);
+        double mx = -INFINITY;
+        for (int j = lane; j < n; j += 64)
+            if (rows[j] == smallest) mx = fmax(mx, data[j]);
+        mx = wave_max(mx);
+        int jstar = 0x7fffffff;   // np.argmax: the first maximum of the masked data
+        for (int j = lane; j < n; j += 64)
+            if (rows[j] == smallest && data[j] == mx) jstar = min(jstar, j);
+        jstar = wave_min(jstar);
+        int num_first = 0, arg = 0;
+        for (int j = lane; j < n; j += 64)
+            if (rows[j] == smallest) { num_first++; arg += j < jstar; }
+        num_first = wave_sum(num_first);
+        arg = min(wave_sum(arg), n - 1);
+        double max_prob = 0;
+        for (int x = 0; x <= arg; x++) {   // x indexes the unmasked arrays, as the reference does
+            const double d = data[x];
+            if (d >= max_prob) {
+                N_PUSH(cols[x], na, d);
+                ARENA_PUSH(cols[x], rows[x], -1);
+                max_prob = d;
+            }
+        }
+        SWAP_FRONTS();
+        nN = 0;
+        if (num_first >= n) { status = SA_MEA_SINGLE_EVENT; goto done; }
+
+        int prev_event = rows[num_first];
+        bool first_pass = true;
+        int i = 0, max_i = -1;
+        max_prob = 0;
+        for (int base = num_first; base < n; base += 64) {
+            const int cnt = min(64, n - base);
+            int rv = 0, cv = 0;
+            double dv = 0;
+            if (lane < cnt) { rv = rows[base + lane]; cv = cols[base + lane]; dv = data[base + lane]; }
+            for (int k = 0; k < cnt; k++) {
+                const int e = rl(rv, k), r = rl(cv, k);
+                const double p = rld(dv, k);
+                if (prev_event != e) {   // :76-93 what is left of the old front survives where it raises the maximum
+                    prev_event = e;
+                    for (; i < nF; i++) {
+                        const double s = f_sum[i];
+                        if (s > max_prob) { N_PUSH(f_ref[i], f_id[i], s); max_prob = s; }
+                    }
+                    first_pass = true;
+                    SWAP_FRONTS();
+                }
+                if (first_pass) {        // :95-118
+                    first_pass = false;
+                    max_i = -1;
+                    nN = 0;
+                    i = 0;
+                    max_prob = 0;
+                    bool found = false;
+                    if (nF == 0) { status = SA_MEA_NO_FRONT; goto done; }
+                    if (e < 0 || e >= J.n_sh) { status = SA_MEA_BAD_EVENT; goto done; }
+                    const int sh = shortest[e];
+                    while (f_ref[i] < sh) {
+                        i++;
+                        found = true;
+                        if (i == nF) break;
+                    }
+                    if (found) {         // the last edge below every future reference position stays reachable
+                        N_PUSH(f_ref[i - 1], f_id[i - 1], f_sum[i - 1]);
+                        max_prob = f_sum[i - 1];
+                    }
+                    i = 0;
+                }
+                for (;;) {               // :120-171
+                    if (i < nF) {
+                        const int fr = f_ref[i];
+                        if (fr < r) {
+                            const double s = f_sum[i];
+                            if (i > max_i && max_prob < s) {
+                                N_PUSH(fr, f_id[i], s);
+                                max_prob = s;
+                                max_i = i;
+                            }
+                            i++;
+                        } else if (fr == r) {
+                            const double stay = f_sum[i];
+                            if (i == 0) {
+                                if (stay > max_prob) {   // stay: the sum does not grow
+                                    N_PUSH(r, na, stay);
+                                    ARENA_PUSH(r, e, f_id[i]);
+                                    max_prob = stay;
+                                }
+                            } else {
+                                const double via = f_sum[i - 1] + p;
+                                if (stay > via) {
+                                    if (stay > max_prob) {
+                                        N_PUSH(r, na, stay);
+                                        ARENA_PUSH(r, e, f_id[i]);
+                                        max_prob = stay;
+                                    }
+                                } else if (via > max_prob) {
+                                    N_PUSH(r, na, via);
+                                    ARENA_PUSH(r, e, f_id[i - 1]);
+                                    max_prob = via;
+                                }
+                            }
+                            max_i = i;
+                            break;
+                        } else {
+                            if (i == 0) {
+                                if (p > max_prob) {
+                                    N_PUSH(r, na, p);
+                                    ARENA_PUSH(r, e, -1);
+                                    max_prob = p;
+                                }
+                            } else {
+                                const double via = f_sum[i - 1] + p;
+                                if (via > max_prob) {
+                                    N_PUSH(r, na, via);
+                                    ARENA_PUSH(r, e, f_id[i - 1]);
+                                    max_prob = via;
+                                }
+                            }
+                            break;
+                        }
+                    } else {             // the reference position lies past every edge
+                        const double via = f_sum[i - 1] + p;
+                        if (via > max_prob) {
+                            N_PUSH(r, na, via);
+                            ARENA_PUSH(r, e, f_id[i - 1]);
+                            max_prob = via;
+                        }
+                        break;
+                    }
+                }
+            }
+        }
+        // :174-180 trailing edges; max_prob is NOT raised here
+        for (; i < nF; i++) {
+            const double s = f_sum[i];
+            if (s > max_prob) N_PUSH(f_ref[i], f_id[i], s);
+        }
+        SWAP_FRONTS();
+        n_edges = nF;
+        // :186-196 the first edge with the strictly highest sum above 0
+        double highest = 0;
+        int best_id = -1;
+        for (int q = 0; q < nF; q++) {
+            const double s = f_sum[q];
+            if (s > highest) { highest = s; best_id = f_id[q]; }
+        }
+        if (best_id < 0) { status = SA_MEA_NO_PATH; goto done; }
+        best_sum = highest;
+        // :248-264 traceback: the arena comes back in blocks of 64 consecutive records (one coalesced load each; back
+        // pointers are short, so a block serves many steps), the walk inside a block is v_readlane
+        __threadfence();
+        int q = best_id, w = J.out_cap;
+        int2 *out = P.out + J.out_off;
+        while (q >= 0) {
+            const int lo = max(0, q - 63);
+            const int idx = lo + lane;
+            int rr = 0, ee = 0, pp = -1;
+            if (idx <= q) { rr = a_ref[idx]; ee = a_ev[idx]; pp = a_prev[idx]; }
+            while (q >= lo) {
+                const int l = q - lo;
+                const int r_ = rl(rr, l), e_ = rl(ee, l);
+                const int nq = rl(pp, l);
+                // cannot happen: back pointers fall strictly and a path holds one pair per event at most
+                if (w <= 0 || nq >= q) { status = SA_MEA_NO_PATH; goto done; }
+                q = nq;
+                w--;
+                if (lane == 0) out[w] = make_int2(r_, e_);
+                n_path++;
+            }
+        }
+    }
+done:
+    if (lane == 0) {
+        P.status[jb] = status;
+        P.n_out[jb] = status == SA_MEA_OK ? n_path : 0;
+        P.n_edges[jb] = n_edges;
+        P.sum[jb] = best_sum;
+    }
+#undef N_PUSH
+#undef ARENA_PUSH
+#undef SWAP_FRONTS
+}
+
+struct MeaWorkspace : SaScratch {
+    void *d_ws = nullptr, *d_gf = nullptr, *h_in = nullptr, *h_res = nullptr;
+    size_t d_ws_cap = 0, d_gf_cap = 0, h_in_cap = 0, h_res_cap = 0;
+};
+static MeaWorkspace g_mea_ws;
+
+extern "C" void sa_mea_release(void) {
+    std::lock_guard<std::mutex> guard(g_mea_ws.mu);
+    g_mea_ws.release();
+}
+
+#define MEACHK(call)                                                                                        \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess) {                                                                             \
+            fprintf(stderr, "[signalalign_hip] %s failed: %s (%s:%d)\n", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            rc = e_ == hipErrorOutOfMemory ? SA_ENOMEM : SA_ENODEVICE;                                      \
+            goto done;                                                                                      \
+        }                                                                                                   \
+    } while (0)
+
+extern "C" int sa_mea_batch(const sa_mea_job_t *jobs, int64_t n_jobs, int device, unsigned flags, sa_mea_pair_t **path_out,
+                            int64_t *n_path_out, double *sum_out, int32_t *status_out, int32_t *n_edges_out,
+                            double *kernel_ms_out) {
+    (void) flags;
+    if ((!jobs && n_jobs > 0) || n_jobs < 0 || !path_out || !n_path_out) return SA_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fprintf(stderr, "[signalalign_hip] no HIP device available; this library has no CPU fallback\n");
+        return SA_ENODEVICE;
+    }
+    if (device < 0 || device >= ndev) return SA_EINVAL;
+    for (int64_t j = 0; j < n_jobs; j++) {
+        path_out[j] = nullptr; n_path_out[j] = 0;
+        if (status_out) status_out[j] = 0;
+        if (sum_out) sum_out[j] = 0.0;
+        if (n_edges_out) n_edges_out[j] = 0;
+    }
+    if (kernel_ms_out) *kernel_ms_out = 0.0;
+    if (n_jobs == 0) return SA_OK;
+    const size_t nj = (size_t) n_jobs;
+    std::vector<MeaJob> hj(nj);
+    size_t n_tot = 0, sh_tot = 0, out_tot = 0;
+    for (size_t j = 0; j < nj; j++) {
+        const sa_mea_job_t *jb = &jobs[j];
+        if (jb->n < 0 || jb->n_events < 0 || jb->n > (1ll << 30) || jb->n_events > (1ll << 30) ||
+            (jb->n > 0 && (!jb->event_idx || !jb->ref_idx || !jb->posterior)) || (jb->n_events > 0 && !jb->shortest_ref_per_event))
+            return SA_EINVAL;
+        MeaJob &J = hj[j];
+        memset(&J, 0, sizeof(J));
+        J.off = (long long) n_tot; J.sh_off = (long long) sh_tot; J.out_off = (long long) out_tot;
+        J.n = (int) jb->n; J.n_sh = (int) jb->n_events;
+        J.out_cap = (int) (jb->n < jb->n_events ? jb->n : jb->n_events);   // one pair per event at most
+        n_tot += (size_t) jb->n; sh_tot += (size_t) jb->n_events; out_tot += (size_t) J.out_cap;
+    }
+    MeaWorkspace &W = g_mea_ws;
+    std::lock_guard<std::mutex> guard(W.mu);
+    int rc = SA_OK;
+    // pinned upload image: data (f64) | rows | cols | shortest (i32)
+    const size_t o_h_rows = sizeof(double) * n_tot, o_h_cols = o_h_rows + 4 * n_tot, o_h_sh = o_h_cols + 4 * n_tot,
+                 in_bytes = o_h_sh + 4 * sh_tot;
+    // device: [jobs | upload image | arena ref, ev, prev | out | sum | n_out, n_edges, status | ids]
+    const size_t o_jobs = 0, o_in = sa_up256(sizeof(MeaJob) * nj), o_arena = sa_up256(o_in + in_bytes),
+                 o_out = sa_up256(o_arena + 12 * n_tot), o_sum = sa_up256(o_out + 8 * out_tot), o_res = o_sum + 8 * nj,
+                 o_ids = sa_up256(o_res + 12 * nj), dev_bytes = o_ids + 4 * nj;
+    const size_t res_bytes = o_ids - o_out;
+    MeaPlan P;
+    memset(&P, 0, sizeof(P));
+    float kms = 0, kms2 = 0;
+    std::vector<int> redo;
+    if ((rc = W.pin(&W.h_in, &W.h_in_cap, in_bytes ? in_bytes : 8, device)) != SA_OK) return rc;
+    {
+        char *h = (char *) W.h_in;
+        size_t a = 0, s = 0;
+        for (size_t j = 0; j < nj; j++) {
+            const sa_mea_job_t *jb = &jobs[j];
+            const size_t n = (size_t) jb->n, ns = (size_t) jb->n_events;
+            if (n) {
+                memcpy(h + 8 * a, jb->posterior, 8 * n);
+                memcpy(h + o_h_rows + 4 * a, jb->event_idx, 4 * n);
+                memcpy(h + o_h_cols + 4 * a, jb->ref_idx, 4 * n);
+            }
+            if (ns) memcpy(h + o_h_sh + 4 * s, jb->shortest_ref_per_event, 4 * ns);
+            a += n; s += ns;
+        }
+    }
+    if ((rc = W.dev(&W.d_ws, &W.d_ws_cap, dev_bytes, device)) != SA_OK) goto done;
+    if ((rc = W.pin(&W.h_res, &W.h_res_cap, res_bytes, device)) != SA_OK) goto done;
+    if ((rc = W.events()) != SA_OK) goto done;
+    {
+        char *d = (char *) W.d_ws;
+        MEACHK(hipMemcpyAsync(d + o_jobs, hj.data(), sizeof(MeaJob) * nj, hipMemcpyHostToDevice, 0));
+        if (in_bytes) MEACHK(hipMemcpyAsync(d + o_in, W.h_in, in_bytes, hipMemcpyHostToDevice, 0));
+        P.jobs = (const MeaJob *) (d + o_jobs);
+        P.data = (const double *) (d + o_in);
+        P.rows = (const int *) (d + o_in + o_h_rows);
+        P.cols = (const int *) (d + o_in + o_h_cols);
+        P.shortest = (const int *) (d + o_in + o_h_sh);
+        P.a_ref = (int *) (d + o_arena); P.a_ev = P.a_ref + n_tot; P.a_prev = P.a_ev + n_tot;
+        P.out = (int2 *) (d + o_out);
+        P.sum = (double *) (d + o_sum);
+        P.n_out = (int *) (d + o_res); P.n_edges = P.n_out + nj; P.status = P.n_edges + nj;
+        MEACHK(hipEventRecord(W.e0, 0));
+        hipLaunchKernelGGL(k_mea<false>, dim3((unsigned) nj), dim3(64), 0, 0, P, (const int *) nullptr, (int) nj);
+        MEACHK(hipEventRecord(W.e1, 0));
+        MEACHK(hipGetLastError());
+        MEACHK(hipMemcpyAsync(W.h_res, d + o_out, res_bytes, hipMemcpyDeviceToHost, 0));
+        MEACHK(hipStreamSynchronize(0));
+        MEACHK(hipEventElapsedTime(&kms, W.e0, W.e1));
+        // reads whose front outgrew LDS: same body, fronts in global memory (two lists of n + 2 entries each)
+        const int *h_status = (const int *) ((const char *) W.h_res + (o_res - o_out)) + 2 * nj;
+        size_t gf_tot = 0;
+        for (size_t j = 0; j < nj; j++)
+            if (h_status[j] == MEA_ST_OVERFLOW) {
+                redo.push_back((int) j);
+                hj[j].gf_off = (long long) gf_tot;
+                gf_tot += 2 * ((size_t) hj[j].n + 2);
+            }
+        if (!redo.empty()) {
+            if ((rc = W.dev(&W.d_gf, &W.d_gf_cap, 16 * gf_tot, device)) != SA_OK) goto done;
+            P.gf_sum = (double *) W.d_gf; P.gf_ref = (int *) (P.gf_sum + gf_tot); P.gf_id = P.gf_ref + gf_tot;
+            MEACHK(hipMemcpyAsync(d + o_jobs, hj.data(), sizeof(MeaJob) * nj, hipMemcpyHostToDevice, 0));
+            MEACHK(hipMemcpyAsync(d + o_ids, redo.data(), 4 * redo.size(), hipMemcpyHostToDevice, 0));
+            MEACHK(hipEventRecord(W.e0, 0));
+            hipLaunchKernelGGL(k_mea<true>, dim3((unsigned) redo.size()), dim3(64), 0, 0, P, (const int *) (d + o_ids),
+                               (int) redo.size());
+            MEACHK(hipEventRecord(W.e1, 0));
+            MEACHK(hipGetLastError());
+            MEACHK(hipMemcpyAsync(W.h_res, d + o_out, res_bytes, hipMemcpyDeviceToHost, 0));
+            MEACHK(hipStreamSynchronize(0));
+            MEACHK(hipEventElapsedTime(&kms2, W.e0, W.e1));
+        }
+    }
+    if (kernel_ms_out) *kernel_ms_out = (double) kms + (double) kms2;
+    {
+        const char *hr = (const char *) W.h_res;
+        const int2 *h_out = (const int2 *) hr;
+        const double *h_sum = (const double *) (hr + (o_sum - o_out));
+        const int *h_n = (const int *) (hr + (o_res - o_out)), *h_edges = h_n + nj, *h_status = h_edges + nj;
+        for (size_t j = 0; j < nj; j++) {
+            const int n = h_n[j];
+            if (status_out) status_out[j] = h_status[j];
+            if (sum_out) sum_out[j] = h_sum[j];
+            if (n_edges_out) n_edges_out[j] = h_edges[j];
+            n_path_out[j] = n;
+            path_out[j] = (sa_mea_pair_t *) malloc(sizeof(sa_mea_pair_t) * (size_t) (n > 0 ? n : 1));
+            if (!path_out[j]) { rc = SA_ENOMEM; goto done; }
+            if (n > 0) memcpy(path_out[j], h_out + hj[j].out_off + hj[j].out_cap - n, sizeof(sa_mea_pair_t) * (size_t) n);
+        }
+    }
+done:
+    if (rc != SA_OK)
+        for (int64_t j = 0; j < n_jobs; j++) { free(path_out[j]); path_out[j] = nullptr; n_path_out[j] = 0; }
+    return rc;
+}
+
+// get_mea_params_from_events (mea_algorithm.py:267-320) without its dense matrices.  np.sort(events,
+// order=['event_index']) breaks ties with the table's remaining fields in dtype order, so within an event rows come by
+// reference index and rows of one cell by ascending posterior; the reference fills its matrices walking that order
+// BACKWARDS, so a cell keeps the posterior of its first row, and coo_matrix(dense) then drops exact zeros.
+extern "C" int64_t sa_mea_params(const int64_t *reference_index, const int64_t *event_index, const double *posterior,
+                                 int64_t n, int32_t *event_idx_out, int32_t *ref_idx_out, double *posterior_out,
+                                 int32_t *shortest_out, int64_t *n_events_out) {
+    if (n <= 0 || !reference_index || !event_index || !posterior || !event_idx_out || !ref_idx_out || !posterior_out ||
+        !shortest_out)
+        return SA_EINVAL;
+    int64_t r0 = reference_index[0], r1 = r0, e0 = event_index[0], e1 = e0;
+    for (int64_t i = 1; i < n; i++) {
+        r0 = reference_index[i] < r0 ? reference_index[i] : r0;
+        r1 = reference_index[i] > r1 ? reference_index[i] : r1;
+        e0 = event_index[i] < e0 ? event_index[i] : e0;
+        e1 = event_index[i] > e1 ? event_index[i] : e1;
+    }
+    if (e1 - e0 >= (1ll << 30) || r1 - r0 >= (1ll << 30)) return SA_EINVAL;
+    // :288-292 minus strand: the first sorted row (first event, its lowest reference index) lies above the last one
+    // (last event, its highest reference index)
+    int64_t lo_first = INT64_MAX, hi_last = INT64_MIN;
+    for (int64_t i = 0; i < n; i++) {
+        if (event_index[i] == e0 && reference_index[i] < lo_first) lo_first = reference_index[i];
+        if (event_index[i] == e1 && reference_index[i] > hi_last) hi_last = reference_index[i];
+    }
+    const bool minus = lo_first > hi_last;
+    const int64_t n_ev = e1 - e0 + 1;
+    // bucket the rows by event (counting sort), order each bucket by (reference index, posterior)
+    std::vector<int64_t> start((size_t) n_ev + 1, 0);
+    for (int64_t i = 0; i < n; i++) start[(size_t) (event_index[i] - e0) + 1]++;
+    for (int64_t e = 0; e < n_ev; e++) start[(size_t) e + 1] += start[(size_t) e];
+    struct Cell {
+        int32_t ref;
+        double p;
+    };
+    std::vector<Cell> cells((size_t) n);
+    {
+        std::vector<int64_t> fill(start.begin(), start.end() - 1);
+        for (int64_t i = 0; i < n; i++) {
+            Cell &c = cells[(size_t) fill[(size_t) (event_index[i] - e0)]++];
+            c.ref = (int32_t) (minus ? r1 - reference_index[i] : reference_index[i] - r0);
+            c.p = posterior[i];
+        }
+    }
+    int64_t m = 0;
+    for (int64_t e = 0; e < n_ev; e++) {
+        Cell *b = cells.data() + start[(size_t) e], *end = cells.data() + start[(size_t) e + 1];
+        // on the minus strand the flipped index falls where the table's rises; ties of one cell stay by posterior
+        std::sort(b, end, [](const Cell &x, const Cell &y) { return x.ref != y.ref ? x.ref < y.ref : x.p < y.p; });
+        for (Cell *c = b; c < end; c++) {
+            if (c > b && c->ref == c[-1].ref) continue;   // a later row of the same cell is overwritten
+            if (c->p == 0.0) continue;                    // coo_matrix keeps non-zeros only
+            event_idx_out[m] = (int32_t) e;
+            ref_idx_out[m] = c->ref;
+            posterior_out[m] = c->p;
+            m++;
+        }
+    }
+    // :305-318 shortest_ref_per_event: the lowest reference position of this and every later event (zeros count);
+    // an event without rows keeps inf
+    int64_t lowest = INT64_MAX;
+    for (int64_t e = n_ev - 1; e >= 0; e--) {
+        const int64_t b = start[(size_t) e], end = start[(size_t) e + 1];
+        if (b == end) { shortest_out[e] = SA_MEA_INF; continue; }
+        for (int64_t q = b; q < end; q++) lowest = cells[(size_t) q].ref < lowest ? cells[(size_t) q].ref : lowest;
+        shortest_out[e] = (int32_t) lowest;
+    }
+    if (n_events_out) *n_events_out = n_ev;
+    return m;
+}
