@@ -105,6 +105,65 @@ def bench_event_align(args):
     print(json.dumps(res))
 
 
+def bench_mea(args):
+    """the maximum-expected-accuracy path over the posteriors of the headline workload's reads
+    (src/signalalign/mea_algorithm.py:25-264).  The aligner produces the posteriors first (untimed); one step = one
+    sa_mea_batch call (upload of the sparse matrices, kernel, traceback, download of the paths)."""
+    import signalalign_amd as sa
+    from signalalign_amd import synth
+    from oracle import sa_oracle_py as oracle
+    from concurrent.futures import ThreadPoolExecutor
+    alpha, k, t10, tab = synth.parse_model_table(MODEL)
+    pm = sa.Model.load(MODEL)
+    reads = synth.make_jobs(args.reads, args.events, alpha, k, tab)
+    b = sa.Batch(pm, sa.default_params(), reads)
+    b.run()
+    jobs = []
+    for j in range(len(reads)):
+        pr = b.pairs(j)
+        ev, rf, po, sh = sa.mea_params(pr["x"], pr["y"], np.round(pr["prob_e7"] / 1e7, 6))
+        jobs.append(dict(event_idx=ev, ref_idx=rf, posterior=po, shortest=sh))
+    b.close()
+    entries = float(sum(len(j["posterior"]) for j in jobs))
+    stats = {}
+    for _ in range(args.warmup):
+        sa.mea_batch(jobs, stats=stats)
+    kms = cms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = sa.mea_batch(jobs, stats=stats)
+        kms += stats["kernel_ms"]
+        cms += stats["call_ms"]
+    dt = time.perf_counter() - t0
+    K = args.steps
+    res = {"metric": "mea_matrix_entries_per_s", "value": entries * K / dt, "unit": "entries/s", "n_gpus": 1, "steps": K,
+           "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "maximum expected accuracy path (src/signalalign/mea_algorithm.py:25-264) over the posteriors "
+                                  "of %d synthetic %d-event reads" % (args.reads, args.events),
+                      "kernel_ms": kms / K, "c_call_ms": cms / K, "kernel_entries_per_s": entries / (kms / K * 1e-3),
+                      "entries_per_read": entries / max(len(jobs), 1),
+                      "paths_found": int(sum(1 for o in out if o[2] == 0)),
+                      "mean_path_length": float(np.mean([len(o[0]) for o in out]))}}
+    if not args.no_cpu_baseline:
+        cores = min(os.cpu_count() or 1, 16)
+        reps = max(1, int(2e7 // max(entries / len(jobs) * min(len(jobs), cores * 8), 1)))
+        sample = jobs[:cores * 8]
+
+        def one(j):
+            for _ in range(reps):
+                oracle.mea(j["event_idx"], j["ref_idx"], j["posterior"], j["shortest"])
+        t1 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(one, sample))
+        dtc = time.perf_counter() - t1
+        n_s = float(sum(len(j["posterior"]) for j in sample)) * reps
+        res["cpu_baseline"] = {"value": n_s / dtc, "unit": "entries/s", "cores": cores, "kind": "port",
+                               "sample": "%d reads x %d repetitions, oracle/sa_mea_oracle.c:sao_mea, %d threads, %.1f s wall"
+                                         % (len(sample), reps, cores, dtc)}
+    print(json.dumps(res))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,7 +171,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=2000, help="reads per GPU (BASELINE configs[1]: 2000)")
     ap.add_argument("--events", type=int, default=5000, help="events per read (BASELINE configs[1]: 5000)")
-    ap.add_argument("--workload", choices=["gaussian", "cpg", "hdp", "event_align"], default="gaussian",
+    ap.add_argument("--workload", choices=["gaussian", "cpg", "hdp", "event_align", "mea"], default="gaussian",
                     help="gaussian = BASELINE configs[1] (the headline); cpg = configs[2] (ACEGT model, every CpG cytosine "
                          "ambiguous C/E); hdp = configs[3] (HDP emissions).  The last two run on the memory-resident kernels.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -134,6 +193,8 @@ def main():
     import signalalign_amd as sa
     from signalalign_amd import synth
 
+    if args.workload == "mea":
+        return bench_mea(args)
     if args.workload == "event_align":
         return bench_event_align(args)
     gold = os.path.join(ROOT, "tests", "golden", "models")

@@ -49,8 +49,11 @@ struct MeaPlan {
     int2 *out;                   // path, written backwards from out_off + out_cap
     int *n_out, *n_edges, *status;
     double *sum;
-    int *gf_ref, *gf_id;         // global fronts (k_mea<true>)
-    double *gf_sum;
+    struct MeaEdge *gf;          // global fronts (k_mea<true>)
+};
+struct __attribute__((aligned(16))) MeaEdge {   // one front entry, read and written as a single 16-byte word
+    double sum;
+    int ref, id;
 };
 
 __device__ __forceinline__ int rl(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
@@ -82,18 +85,15 @@ __global__ __launch_bounds__(64) void k_mea(MeaPlan P, const int *__restrict__ i
     int *a_ref = P.a_ref + J.off, *a_ev = P.a_ev + J.off, *a_prev = P.a_prev + J.off;
     const int n = J.n;
 
-    __shared__ int s_ref[2 * MEA_FRONT_CAP], s_id[2 * MEA_FRONT_CAP];
-    __shared__ double s_sum[2 * MEA_FRONT_CAP];
+    __shared__ MeaEdge s_front[2 * MEA_FRONT_CAP];
     const int cap = GLOBAL_FRONT ? n + 2 : MEA_FRONT_CAP;
-    int *f_ref, *f_id, *n_ref, *n_id;      // F = forward edges of the previous events, N = new edges
-    double *f_sum, *n_sum;
-    if (GLOBAL_FRONT) {
-        f_ref = P.gf_ref + J.gf_off; f_id = P.gf_id + J.gf_off; f_sum = P.gf_sum + J.gf_off;
-        n_ref = f_ref + cap; n_id = f_id + cap; n_sum = f_sum + cap;
-    } else {
-        f_ref = s_ref; f_id = s_id; f_sum = s_sum;
-        n_ref = s_ref + MEA_FRONT_CAP; n_id = s_id + MEA_FRONT_CAP; n_sum = s_sum + MEA_FRONT_CAP;
-    }
+    // F = forward edges of the previous events, N = new edges: two halves of one array, told apart by an offset (not
+    // by swapping pointers: the LDS accesses must stay ds_read/ds_write -- a generic pointer turns them into flat
+    // loads, which wait for the outstanding arena stores as well)
+    MeaEdge *const gfront = GLOBAL_FRONT ? P.gf + J.gf_off : nullptr;
+    int fo = 0, no = cap;
+#define FRONT(idx_) (*(GLOBAL_FRONT ? &gfront[idx_] : &s_front[idx_]))
+#define F_AT(i_) FRONT(fo + (i_))
     int nF = 0, nN = 0, na = 0, status = SA_MEA_OK, n_edges = 0, n_path = 0;
     double best_sum = 0.0;
 
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64) void k_mea(MeaPlan P, const int *__restrict__ i
 #define N_PUSH(ref_, id_, sum_)                                   \
     do {                                                          \
         if (nN >= cap) { status = MEA_ST_OVERFLOW; goto done; }   \
-        n_ref[nN] = (ref_); n_id[nN] = (id_); n_sum[nN] = (sum_); \
+        { MeaEdge t_; t_.sum = (sum_); t_.ref = (ref_); t_.id = (id_); FRONT(no + nN) = t_; } \
         nN++;                                                     \
     } while (0)
 #define ARENA_PUSH(ref_, ev_, prev_)                                                 \
@@ -111,9 +111,7 @@ __global__ __launch_bounds__(64) void k_mea(MeaPlan P, const int *__restrict__ i
     } while (0)
 #define SWAP_FRONTS()                                                        \
     do {                                                                     \
-        int *t_; double *u_;                                                 \
-        t_ = f_ref; f_ref = n_ref; n_ref = t_; t_ = f_id; f_id = n_id; n_id = t_; \
-        u_ = f_sum; f_sum = n_sum; n_sum = u_;                               \
+        { const int t_ = fo; fo = no; no = t_; }                             \
         nF = nN;                                                             \
     } while (0)
 
@@ -155,17 +153,20 @@ __global__ __launch_bounds__(64) void k_mea(MeaPlan P, const int *__restrict__ i
         max_prob = 0;
         for (int base = num_first; base < n; base += 64) {
             const int cnt = min(64, n - base);
-            int rv = 0, cv = 0;
+            int rv = 0, cv = 0, sv = 0;
             double dv = 0;
-            if (lane < cnt) { rv = rows[base + lane]; cv = cols[base + lane]; dv = data[base + lane]; }
+            if (lane < cnt) {
+                rv = rows[base + lane]; cv = cols[base + lane]; dv = data[base + lane];
+                if (rv >= 0 && rv < J.n_sh) sv = shortest[rv];   // fetched with the entry: no load on the serial chain
+            }
             for (int k = 0; k < cnt; k++) {
                 const int e = rl(rv, k), r = rl(cv, k);
                 const double p = rld(dv, k);
                 if (prev_event != e) {   // :76-93 what is left of the old front survives where it raises the maximum
                     prev_event = e;
                     for (; i < nF; i++) {
-                        const double s = f_sum[i];
-                        if (s > max_prob) { N_PUSH(f_ref[i], f_id[i], s); max_prob = s; }
+                        const MeaEdge fe = F_AT(i);
+                        if (fe.sum > max_prob) { N_PUSH(fe.ref, fe.id, fe.sum); max_prob = fe.sum; }
                     }
                     first_pass = true;
                     SWAP_FRONTS();
@@ -179,48 +180,51 @@ __global__ __launch_bounds__(64) void k_mea(MeaPlan P, const int *__restrict__ i
                     bool found = false;
                     if (nF == 0) { status = SA_MEA_NO_FRONT; goto done; }
                     if (e < 0 || e >= J.n_sh) { status = SA_MEA_BAD_EVENT; goto done; }
-                    const int sh = shortest[e];
-                    while (f_ref[i] < sh) {
+                    const int sh = rl(sv, k);
+                    MeaEdge last = F_AT(0), fe = last;
+                    while (fe.ref < sh) {
+                        last = fe;
                         i++;
                         found = true;
                         if (i == nF) break;
+                        fe = F_AT(i);
                     }
                     if (found) {         // the last edge below every future reference position stays reachable
-                        N_PUSH(f_ref[i - 1], f_id[i - 1], f_sum[i - 1]);
-                        max_prob = f_sum[i - 1];
+                        N_PUSH(last.ref, last.id, last.sum);
+                        max_prob = last.sum;
                     }
                     i = 0;
                 }
                 for (;;) {               // :120-171
                     if (i < nF) {
-                        const int fr = f_ref[i];
-                        if (fr < r) {
-                            const double s = f_sum[i];
-                            if (i > max_i && max_prob < s) {
-                                N_PUSH(fr, f_id[i], s);
-                                max_prob = s;
+                        const MeaEdge fe = F_AT(i);
+                        if (fe.ref < r) {
+                            if (i > max_i && max_prob < fe.sum) {
+                                N_PUSH(fe.ref, fe.id, fe.sum);
+                                max_prob = fe.sum;
                                 max_i = i;
                             }
                             i++;
-                        } else if (fr == r) {
-                            const double stay = f_sum[i];
+                        } else if (fe.ref == r) {
+                            const double stay = fe.sum;
                             if (i == 0) {
                                 if (stay > max_prob) {   // stay: the sum does not grow
                                     N_PUSH(r, na, stay);
-                                    ARENA_PUSH(r, e, f_id[i]);
+                                    ARENA_PUSH(r, e, fe.id);
                                     max_prob = stay;
                                 }
                             } else {
-                                const double via = f_sum[i - 1] + p;
+                                const MeaEdge left = F_AT(i - 1);
+                                const double via = left.sum + p;
                                 if (stay > via) {
                                     if (stay > max_prob) {
                                         N_PUSH(r, na, stay);
-                                        ARENA_PUSH(r, e, f_id[i]);
+                                        ARENA_PUSH(r, e, fe.id);
                                         max_prob = stay;
                                     }
                                 } else if (via > max_prob) {
                                     N_PUSH(r, na, via);
-                                    ARENA_PUSH(r, e, f_id[i - 1]);
+                                    ARENA_PUSH(r, e, left.id);
                                     max_prob = via;
                                 }
                             }
@@ -234,20 +238,22 @@ __global__ __launch_bounds__(64) void k_mea(MeaPlan P, const int *__restrict__ i
                                     max_prob = p;
                                 }
                             } else {
-                                const double via = f_sum[i - 1] + p;
+                                const MeaEdge left = F_AT(i - 1);
+                                const double via = left.sum + p;
                                 if (via > max_prob) {
                                     N_PUSH(r, na, via);
-                                    ARENA_PUSH(r, e, f_id[i - 1]);
+                                    ARENA_PUSH(r, e, left.id);
                                     max_prob = via;
                                 }
                             }
                             break;
                         }
                     } else {             // the reference position lies past every edge
-                        const double via = f_sum[i - 1] + p;
+                        const MeaEdge left = F_AT(i - 1);
+                        const double via = left.sum + p;
                         if (via > max_prob) {
                             N_PUSH(r, na, via);
-                            ARENA_PUSH(r, e, f_id[i - 1]);
+                            ARENA_PUSH(r, e, left.id);
                             max_prob = via;
                         }
                         break;
@@ -257,8 +263,8 @@ __global__ __launch_bounds__(64) void k_mea(MeaPlan P, const int *__restrict__ i
         }
         // :174-180 trailing edges; max_prob is NOT raised here
         for (; i < nF; i++) {
-            const double s = f_sum[i];
-            if (s > max_prob) N_PUSH(f_ref[i], f_id[i], s);
+            const MeaEdge fe = F_AT(i);
+            if (fe.sum > max_prob) N_PUSH(fe.ref, fe.id, fe.sum);
         }
         SWAP_FRONTS();
         n_edges = nF;
@@ -266,8 +272,8 @@ __global__ __launch_bounds__(64) void k_mea(MeaPlan P, const int *__restrict__ i
         double highest = 0;
         int best_id = -1;
         for (int q = 0; q < nF; q++) {
-            const double s = f_sum[q];
-            if (s > highest) { highest = s; best_id = f_id[q]; }
+            const MeaEdge fe = F_AT(q);
+            if (fe.sum > highest) { highest = fe.sum; best_id = fe.id; }
         }
         if (best_id < 0) { status = SA_MEA_NO_PATH; goto done; }
         best_sum = highest;
@@ -304,6 +310,8 @@ done:
 #undef N_PUSH
 #undef ARENA_PUSH
 #undef SWAP_FRONTS
+#undef F_AT
+#undef FRONT
 }
 
 struct MeaWorkspace : SaScratch {
@@ -425,8 +433,8 @@ extern "C" int sa_mea_batch(const sa_mea_job_t *jobs, int64_t n_jobs, int device
                 gf_tot += 2 * ((size_t) hj[j].n + 2);
             }
         if (!redo.empty()) {
-            if ((rc = W.dev(&W.d_gf, &W.d_gf_cap, 16 * gf_tot, device)) != SA_OK) goto done;
-            P.gf_sum = (double *) W.d_gf; P.gf_ref = (int *) (P.gf_sum + gf_tot); P.gf_id = P.gf_ref + gf_tot;
+            if ((rc = W.dev(&W.d_gf, &W.d_gf_cap, sizeof(MeaEdge) * gf_tot, device)) != SA_OK) goto done;
+            P.gf = (MeaEdge *) W.d_gf;
             MEACHK(hipMemcpyAsync(d + o_jobs, hj.data(), sizeof(MeaJob) * nj, hipMemcpyHostToDevice, 0));
             MEACHK(hipMemcpyAsync(d + o_ids, redo.data(), 4 * redo.size(), hipMemcpyHostToDevice, 0));
             MEACHK(hipEventRecord(W.e0, 0));
