@@ -60,17 +60,299 @@ __device__ __forceinline__ int rl(int v, int k) { return __builtin_amdgcn_readla
 __device__ __forceinline__ double rld(double v, int k) {
     return __hiloint2double(rl(__double2hiint(v), k), rl(__double2loint(v), k));
 }
+// Wave reductions.  The result is the same in every lane, but the compiler cannot know that of a cross-lane shuffle:
+// v_readfirstlane tells it, and everything computed from these values (loop bounds, front lengths) stays in SGPRs with
+// scalar branches instead of exec-masked vector code.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni(double v) {
+    return __hiloint2double(uni(__double2hiint(v)), uni(__double2loint(v)));
+}
 __device__ __forceinline__ int wave_min(int v) {
     for (int o = 32; o; o >>= 1) v = min(v, __shfl_xor(v, o));
-    return v;
+    return uni(v);
 }
 __device__ __forceinline__ int wave_sum(int v) {
     for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    return uni(v);
 }
 __device__ __forceinline__ double wave_max(double v) {
     for (int o = 32; o; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
+    return uni(v);
+}
+
+// :41-58 which entries belong to the first event: their count and the (masked) index of their first largest posterior
+__device__ __forceinline__ void mea_first_event(const int *__restrict__ rows, const double *__restrict__ data, int n, int lane,
+                                                int &num_first, int &arg) {
+    int smallest = 0x7fffffff;
+    for (int j = lane; j < n; j += 64) smallest = min(smallest, rows[j]);
+    smallest = wave_min(smallest);
+    double mx = -INFINITY;
+    for (int j = lane; j < n; j += 64)
+        if (rows[j] == smallest) mx = fmax(mx, data[j]);
+    mx = wave_max(mx);
+    int jstar = 0x7fffffff;   // np.argmax: the first maximum of the masked data
+    for (int j = lane; j < n; j += 64)
+        if (rows[j] == smallest && data[j] == mx) jstar = min(jstar, j);
+    jstar = wave_min(jstar);
+    int nf = 0, a = 0;
+    for (int j = lane; j < n; j += 64)
+        if (rows[j] == smallest) { nf++; a += j < jstar; }
+    num_first = wave_sum(nf);
+    arg = min(wave_sum(a), n - 1);
+}
+
+// :248-264 traceback: the arena comes back in blocks of 64 consecutive records (one coalesced load each; back pointers
+// are short, so a block serves many steps), the walk inside a block is v_readlane.  Returns the path length, or -1 if
+// the arena is inconsistent (cannot happen: back pointers fall strictly, a path holds one pair per event at most).
+__device__ __forceinline__ int mea_traceback(const int *a_ref, const int *a_ev, const int *a_prev, int best_id, int2 *out,
+                                             int out_cap, int lane) {
+    __threadfence();
+    int q = best_id, w = out_cap, n_path = 0;
+    while (q >= 0) {
+        const int lo = max(0, q - 63);
+        const int idx = lo + lane;
+        int rr = 0, ee = 0, pp = -1;
+        if (idx <= q) { rr = a_ref[idx]; ee = a_ev[idx]; pp = a_prev[idx]; }
+        while (q >= lo) {
+            const int l = q - lo;
+            const int r_ = rl(rr, l), e_ = rl(ee, l);
+            const int nq = rl(pp, l);
+            if (w <= 0 || nq >= q) return -1;
+            q = nq;
+            w--;
+            if (lane == 0) out[w] = make_int2(r_, e_);
+            n_path++;
+        }
+    }
+    return n_path;
+}
+
+// ---- fronts in registers: lane l holds forward edge l -------------------------------------------------------------------
+// The serial kernel below walks the front entry by entry; a lone wave issues about one instruction per 2.3 ns, and with a
+// front of 5-10 edges every matrix entry costs 1.4 us.  Here both fronts live in VGPRs, one edge per lane (a front is
+// rarely longer than a handful of edges; 64 is the limit of this kernel), and each of the reference's loops over the
+// front becomes a few wave operations:
+//   * "while forward_edges[i][0] < x: i += 1"  ->  count-trailing-zeros of a ballot (first lane whose edge fails);
+//   * "append every edge that raises max_prob" ->  a ballot, because sums never fall along a front (every edge of a
+//     front was appended because its sum exceeded the running maximum; the first event's edges are kept while they do
+//     not fall): an edge raises the running maximum iff it exceeds the value the loop started with and the edge to its
+//     left, which is one DPP wave rotate away;
+//   * appending = writing the lane whose index equals the length (v_cndmask), copying an old edge = v_readlane.
+// Order of appends, comparisons and additions are the reference's; a front that outgrows 64 edges sends the read to the
+// serial kernel.
+__device__ __forceinline__ unsigned long long lanes_below(int k) { return k >= 64 ? ~0ull : ((1ull << k) - 1ull); }
+__device__ __forceinline__ double ror1(double v) {   // lane l receives lane l-1 (lane 0: lane 63)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x13C, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x13C, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(64) void k_mea_wave(MeaPlan P, int n_jobs) {
+    const int jb = blockIdx.x;
+    const int lane = threadIdx.x;
+    const MeaJob J = P.jobs[jb];
+    const int *__restrict__ rows = P.rows + J.off;
+    const int *__restrict__ cols = P.cols + J.off;
+    const double *__restrict__ data = P.data + J.off;
+    const int *__restrict__ shortest = P.shortest + J.sh_off;
+    int *a_ref = P.a_ref + J.off, *a_ev = P.a_ev + J.off, *a_prev = P.a_prev + J.off;
+    const int n = J.n;
+    int fref = 0, fid = 0, nref = 0, nid = 0;   // F[lane] (lane < nF), N[lane] (lane < nN)
+    double fsum = 0, nsum = 0;
+    int nF = 0, nN = 0, na = 0, status = SA_MEA_OK, n_edges = 0, n_path = 0;
+    double best_sum = 0.0;
+
+#define WN_SET(ref_, id_, sum_)                                         \
+    do {                                                                \
+        if (nN >= 64) { status = MEA_ST_OVERFLOW; goto done; }          \
+        if (lane == nN) { nref = (ref_); nid = (id_); nsum = (sum_); }  \
+        nN++;                                                           \
+    } while (0)
+#define WN_COPY_SET(mask_)                                              \
+    do {                                                                \
+        unsigned long long m_ = (mask_);                                \
+        while (m_) {                                                    \
+            const int l_ = __builtin_ctzll(m_);                         \
+            m_ &= m_ - 1;                                               \
+            WN_SET(rl(fref, l_), rl(fid, l_), rld(fsum, l_));           \
+        }                                                               \
+    } while (0)
+#define WARENA_PUSH(ref_, ev_, prev_)                                                  \
+    do {                                                                               \
+        if (lane == 0) { a_ref[na] = (ref_); a_ev[na] = (ev_); a_prev[na] = (prev_); } \
+        na++;                                                                          \
+    } while (0)
+#define WSWAP()                                      \
+    do {                                             \
+        fref = nref; fid = nid; fsum = nsum; nF = nN; \
+    } while (0)
+
+    if (n <= 0) { status = SA_MEA_EMPTY; goto done; }
+    {
+        int num_first, arg;
+        mea_first_event(rows, data, n, lane, num_first, arg);
+        double max_prob = 0;
+        for (int x = 0; x <= arg; x++) {   // x indexes the unmasked arrays, as the reference does
+            const double d = data[x];
+            if (d >= max_prob) {
+                WN_SET(cols[x], na, d);
+                WARENA_PUSH(cols[x], rows[x], -1);
+                max_prob = d;
+            }
+        }
+        WSWAP();
+        nN = 0;
+        if (num_first >= n) { status = SA_MEA_SINGLE_EVENT; goto done; }
+
+        int prev_event = rows[num_first];
+        bool first_pass = true;
+        int i = 0, max_i = -1;
+        max_prob = 0;
+        for (int base = num_first; base < n; base += 64) {
+            const int cnt = min(64, n - base);
+            int rv = 0, cv = 0, sv = 0;
+            double dv = 0;
+            if (lane < cnt) {
+                rv = rows[base + lane]; cv = cols[base + lane]; dv = data[base + lane];
+                if (rv >= 0 && rv < J.n_sh) sv = shortest[rv];
+            }
+            for (int k = 0; k < cnt; k++) {
+                const int e = rl(rv, k), r = rl(cv, k);
+                const double p = rld(dv, k);
+                if (prev_event != e) {   // :76-93 what is left of the old front survives where it raises the maximum
+                    prev_event = e;
+                    if (i < nF) {
+                        const double left = ror1(fsum);
+                        const unsigned long long cand = lanes_below(nF) & ~lanes_below(i);
+                        const unsigned long long up =
+                            __builtin_amdgcn_ballot_w64(fsum > max_prob && (lane == i || fsum > left)) & cand;
+                        if (up) max_prob = rld(fsum, 63 - __builtin_clzll(up));
+                        WN_COPY_SET(up);
+                    }
+                    first_pass = true;
+                    WSWAP();
+                }
+                if (first_pass) {        // :95-118
+                    first_pass = false;
+                    max_i = -1;
+                    nN = 0;
+                    i = 0;
+                    max_prob = 0;
+                    if (nF == 0) { status = SA_MEA_NO_FRONT; goto done; }
+                    if (e < 0 || e >= J.n_sh) { status = SA_MEA_BAD_EVENT; goto done; }
+                    const int sh = rl(sv, k);
+                    const unsigned long long stop = __builtin_amdgcn_ballot_w64(!(fref < sh)) | ~lanes_below(nF);
+                    const int i_stop = stop ? __builtin_ctzll(stop) : 64;
+                    if (i_stop > 0) {    // the last edge below every future reference position stays reachable
+                        const double ks = rld(fsum, i_stop - 1);
+                        WN_SET(rl(fref, i_stop - 1), rl(fid, i_stop - 1), ks);
+                        max_prob = ks;
+                    }
+                }
+                // :120-171  edges left of r: those that raise the maximum are carried over ...
+                {
+                    const unsigned long long stop =
+                        (__builtin_amdgcn_ballot_w64(!(fref < r)) | ~lanes_below(nF)) & ~lanes_below(i);
+                    const int i_end = stop ? __builtin_ctzll(stop) : 64;
+                    const int c0 = max(i, max_i + 1);
+                    if (c0 < i_end) {
+                        const double left = ror1(fsum);
+                        const unsigned long long cand = lanes_below(i_end) & ~lanes_below(c0);
+                        const unsigned long long up =
+                            __builtin_amdgcn_ballot_w64(fsum > max_prob && (lane == c0 || fsum > left)) & cand;
+                        if (up) {
+                            max_i = 63 - __builtin_clzll(up);
+                            max_prob = rld(fsum, max_i);
+                        }
+                        WN_COPY_SET(up);
+                    }
+                    if (i_end > i) i = i_end;
+                }
+                // ... then the entry itself: stay in its column, or move in from the edge to its left
+                if (i < nF) {
+                    const int fr = rl(fref, i);
+                    if (fr == r) {
+                        const double stay = rld(fsum, i);
+                        if (i == 0) {
+                            if (stay > max_prob) {
+                                WN_SET(r, na, stay);
+                                WARENA_PUSH(r, e, rl(fid, i));
+                                max_prob = stay;
+                            }
+                        } else {
+                            const double via = rld(fsum, i - 1) + p;
+                            if (stay > via) {
+                                if (stay > max_prob) {
+                                    WN_SET(r, na, stay);
+                                    WARENA_PUSH(r, e, rl(fid, i));
+                                    max_prob = stay;
+                                }
+                            } else if (via > max_prob) {
+                                WN_SET(r, na, via);
+                                WARENA_PUSH(r, e, rl(fid, i - 1));
+                                max_prob = via;
+                            }
+                        }
+                        max_i = i;
+                    } else if (i == 0) {
+                        if (p > max_prob) {
+                            WN_SET(r, na, p);
+                            WARENA_PUSH(r, e, -1);
+                            max_prob = p;
+                        }
+                    } else {
+                        const double via = rld(fsum, i - 1) + p;
+                        if (via > max_prob) {
+                            WN_SET(r, na, via);
+                            WARENA_PUSH(r, e, rl(fid, i - 1));
+                            max_prob = via;
+                        }
+                    }
+                } else {                 // the reference position lies past every edge
+                    const double via = rld(fsum, i - 1) + p;
+                    if (via > max_prob) {
+                        WN_SET(r, na, via);
+                        WARENA_PUSH(r, e, rl(fid, i - 1));
+                        max_prob = via;
+                    }
+                }
+            }
+        }
+        // :174-180 trailing edges; max_prob is NOT raised here
+        if (i < nF) {
+            const unsigned long long up =
+                __builtin_amdgcn_ballot_w64(fsum > max_prob) & lanes_below(nF) & ~lanes_below(i);
+            WN_COPY_SET(up);
+        }
+        WSWAP();
+        n_edges = nF;
+        // :186-196 the first edge with the strictly highest sum above 0
+        const double highest = wave_max(lane < nF ? fsum : -INFINITY);
+        if (!(highest > 0)) { status = SA_MEA_NO_PATH; goto done; }
+        const unsigned long long at = __builtin_amdgcn_ballot_w64(fsum == highest) & lanes_below(nF);
+        const int best_id = rl(fid, __builtin_ctzll(at));
+        best_sum = highest;
+        n_path = mea_traceback(a_ref, a_ev, a_prev, best_id, P.out + J.out_off, J.out_cap, lane);
+        if (n_path < 0) { n_path = 0; status = SA_MEA_NO_PATH; }
+    }
+done:
+    if (lane == 0) {
+        P.status[jb] = status;
+        P.n_out[jb] = status == SA_MEA_OK ? n_path : 0;
+        P.n_edges[jb] = n_edges;
+        P.sum[jb] = best_sum;
+    }
+#undef WN_SET
+#undef WN_COPY_SET
+#undef WARENA_PUSH
+#undef WSWAP
+}
+
+__device__ __forceinline__ MeaEdge uni_edge(const MeaEdge &e) {   // every lane read the same entry
+    MeaEdge u;
+    u.sum = uni(e.sum); u.ref = uni(e.ref); u.id = uni(e.id);
+    return u;
 }
 
 template <bool GLOBAL_FRONT>
@@ -93,7 +375,7 @@ __global__ __launch_bounds__(64) void k_mea(MeaPlan P, const int *__restrict__ i
     MeaEdge *const gfront = GLOBAL_FRONT ? P.gf + J.gf_off : nullptr;
     int fo = 0, no = cap;
 #define FRONT(idx_) (*(GLOBAL_FRONT ? &gfront[idx_] : &s_front[idx_]))
-#define F_AT(i_) FRONT(fo + (i_))
+#define F_AT(i_) uni_edge(FRONT(fo + (i_)))
     int nF = 0, nN = 0, na = 0, status = SA_MEA_OK, n_edges = 0, n_path = 0;
     double best_sum = 0.0;
 
@@ -118,22 +400,8 @@ __global__ __launch_bounds__(64) void k_mea(MeaPlan P, const int *__restrict__ i
     if (n <= 0) { status = SA_MEA_EMPTY; goto done; }
     {
         // :41-58 the first event: its entries up to the largest posterior, kept while they do not fall
-        int smallest = 0x7fffffff;
-        for (int j = lane; j < n; j += 64) smallest = min(smallest, rows[j]);
-        smallest = wave_min(smallest);
-        double mx = -INFINITY;
-        for (int j = lane; j < n; j += 64)
-            if (rows[j] == smallest) mx = fmax(mx, data[j]);
-        mx = wave_max(mx);
-        int jstar = 0x7fffffff;   // np.argmax: the first maximum of the masked data
-        for (int j = lane; j < n; j += 64)
-            if (rows[j] == smallest && data[j] == mx) jstar = min(jstar, j);
-        jstar = wave_min(jstar);
-        int num_first = 0, arg = 0;
-        for (int j = lane; j < n; j += 64)
-            if (rows[j] == smallest) { num_first++; arg += j < jstar; }
-        num_first = wave_sum(num_first);
-        arg = min(wave_sum(arg), n - 1);
+        int num_first, arg;
+        mea_first_event(rows, data, n, lane, num_first, arg);
         double max_prob = 0;
         for (int x = 0; x <= arg; x++) {   // x indexes the unmasked arrays, as the reference does
             const double d = data[x];
@@ -277,28 +545,8 @@ __global__ __launch_bounds__(64) void k_mea(MeaPlan P, const int *__restrict__ i
         }
         if (best_id < 0) { status = SA_MEA_NO_PATH; goto done; }
         best_sum = highest;
-        // :248-264 traceback: the arena comes back in blocks of 64 consecutive records (one coalesced load each; back
-        // pointers are short, so a block serves many steps), the walk inside a block is v_readlane
-        __threadfence();
-        int q = best_id, w = J.out_cap;
-        int2 *out = P.out + J.out_off;
-        while (q >= 0) {
-            const int lo = max(0, q - 63);
-            const int idx = lo + lane;
-            int rr = 0, ee = 0, pp = -1;
-            if (idx <= q) { rr = a_ref[idx]; ee = a_ev[idx]; pp = a_prev[idx]; }
-            while (q >= lo) {
-                const int l = q - lo;
-                const int r_ = rl(rr, l), e_ = rl(ee, l);
-                const int nq = rl(pp, l);
-                // cannot happen: back pointers fall strictly and a path holds one pair per event at most
-                if (w <= 0 || nq >= q) { status = SA_MEA_NO_PATH; goto done; }
-                q = nq;
-                w--;
-                if (lane == 0) out[w] = make_int2(r_, e_);
-                n_path++;
-            }
-        }
+        n_path = mea_traceback(a_ref, a_ev, a_prev, best_id, P.out + J.out_off, J.out_cap, lane);
+        if (n_path < 0) { n_path = 0; status = SA_MEA_NO_PATH; }
     }
 done:
     if (lane == 0) {
@@ -416,38 +664,53 @@ extern "C" int sa_mea_batch(const sa_mea_job_t *jobs, int64_t n_jobs, int device
         P.out = (int2 *) (d + o_out);
         P.sum = (double *) (d + o_sum);
         P.n_out = (int *) (d + o_res); P.n_edges = P.n_out + nj; P.status = P.n_edges + nj;
-        MEACHK(hipEventRecord(W.e0, 0));
-        hipLaunchKernelGGL(k_mea<false>, dim3((unsigned) nj), dim3(64), 0, 0, P, (const int *) nullptr, (int) nj);
-        MEACHK(hipEventRecord(W.e1, 0));
-        MEACHK(hipGetLastError());
-        MEACHK(hipMemcpyAsync(W.h_res, d + o_out, res_bytes, hipMemcpyDeviceToHost, 0));
-        MEACHK(hipStreamSynchronize(0));
-        MEACHK(hipEventElapsedTime(&kms, W.e0, W.e1));
-        // reads whose front outgrew LDS: same body, fronts in global memory (two lists of n + 2 entries each)
+        // three tiers of the same algorithm: fronts in registers (64 edges), in LDS (256), in global memory (any length);
+        // a read whose front outgrows a tier is handed to the next one.  SA_MEA_TIER=1|2 starts lower (tests).
+        const char *tier_env = getenv("SA_MEA_TIER");
+        int tier = tier_env ? atoi(tier_env) : 0;
+        tier = tier < 0 ? 0 : (tier > 2 ? 2 : tier);
         const int *h_status = (const int *) ((const char *) W.h_res + (o_res - o_out)) + 2 * nj;
-        size_t gf_tot = 0;
-        for (size_t j = 0; j < nj; j++)
-            if (h_status[j] == MEA_ST_OVERFLOW) {
-                redo.push_back((int) j);
-                hj[j].gf_off = (long long) gf_tot;
-                gf_tot += 2 * ((size_t) hj[j].n + 2);
+        bool all = true;                       // first launch: every read, no id list
+        for (; tier < 3; tier++) {
+            const unsigned grid = all ? (unsigned) nj : (unsigned) redo.size();
+            const int *d_ids = all ? nullptr : (const int *) (d + o_ids);
+            if (tier == 2) {                   // two lists of n + 2 entries per read
+                size_t gf_tot = 0;
+                for (size_t q = 0; q < (all ? nj : redo.size()); q++) {
+                    const size_t j = all ? q : (size_t) redo[q];
+                    hj[j].gf_off = (long long) gf_tot;
+                    gf_tot += 2 * ((size_t) hj[j].n + 2);
+                }
+                if ((rc = W.dev(&W.d_gf, &W.d_gf_cap, sizeof(MeaEdge) * gf_tot, device)) != SA_OK) goto done;
+                P.gf = (MeaEdge *) W.d_gf;
+                MEACHK(hipMemcpyAsync(d + o_jobs, hj.data(), sizeof(MeaJob) * nj, hipMemcpyHostToDevice, 0));
             }
-        if (!redo.empty()) {
-            if ((rc = W.dev(&W.d_gf, &W.d_gf_cap, sizeof(MeaEdge) * gf_tot, device)) != SA_OK) goto done;
-            P.gf = (MeaEdge *) W.d_gf;
-            MEACHK(hipMemcpyAsync(d + o_jobs, hj.data(), sizeof(MeaJob) * nj, hipMemcpyHostToDevice, 0));
-            MEACHK(hipMemcpyAsync(d + o_ids, redo.data(), 4 * redo.size(), hipMemcpyHostToDevice, 0));
+            if (!all) MEACHK(hipMemcpyAsync(d + o_ids, redo.data(), 4 * redo.size(), hipMemcpyHostToDevice, 0));
             MEACHK(hipEventRecord(W.e0, 0));
-            hipLaunchKernelGGL(k_mea<true>, dim3((unsigned) redo.size()), dim3(64), 0, 0, P, (const int *) (d + o_ids),
-                               (int) redo.size());
+            if (tier == 0) {
+                if (!all) { rc = SA_EINVAL; goto done; }   // the register tier is only ever the first
+                hipLaunchKernelGGL(k_mea_wave, dim3(grid), dim3(64), 0, 0, P, (int) nj);
+            } else if (tier == 1) {
+                hipLaunchKernelGGL(k_mea<false>, dim3(grid), dim3(64), 0, 0, P, d_ids, (int) grid);
+            } else {
+                hipLaunchKernelGGL(k_mea<true>, dim3(grid), dim3(64), 0, 0, P, d_ids, (int) grid);
+            }
             MEACHK(hipEventRecord(W.e1, 0));
             MEACHK(hipGetLastError());
-            MEACHK(hipMemcpyAsync(W.h_res, d + o_out, res_bytes, hipMemcpyDeviceToHost, 0));
+            MEACHK(hipMemcpyAsync((void *) h_status, P.status, 4 * nj, hipMemcpyDeviceToHost, 0));
             MEACHK(hipStreamSynchronize(0));
             MEACHK(hipEventElapsedTime(&kms2, W.e0, W.e1));
+            kms += kms2;
+            redo.clear();
+            for (size_t j = 0; j < nj; j++)
+                if (h_status[j] == MEA_ST_OVERFLOW) redo.push_back((int) j);
+            all = false;
+            if (redo.empty()) break;
         }
+        MEACHK(hipMemcpyAsync(W.h_res, d + o_out, res_bytes, hipMemcpyDeviceToHost, 0));
+        MEACHK(hipStreamSynchronize(0));
     }
-    if (kernel_ms_out) *kernel_ms_out = (double) kms + (double) kms2;
+    if (kernel_ms_out) *kernel_ms_out = (double) kms;
     {
         const char *hr = (const char *) W.h_res;
         const int2 *h_out = (const int2 *) hr;

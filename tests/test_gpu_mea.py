@@ -46,7 +46,10 @@ def test_reference_known_answer_matrix():
         assert path.tolist() == [[0, 0], [1, 1], [1, 2], [3, 3], [4, 4]]
 
 
-def test_random_matrices_bit_identical_to_the_oracle(oracle):
+@pytest.mark.parametrize("tier", [0, 1, 2])
+def test_random_matrices_bit_identical_to_the_oracle(oracle, monkeypatch, tier):
+    # tier 0: fronts in registers (the default first stop), 1: in LDS, 2: in global memory -- the same answers
+    monkeypatch.setenv("SA_MEA_TIER", str(tier))
     rng = np.random.default_rng(5)
     jobs = []
     for it in range(300):
@@ -74,7 +77,8 @@ def test_exception_cases_become_status_words(oracle):
 
 
 def test_front_longer_than_the_lds_share_takes_the_global_pass(oracle):
-    # a first event with 700 rising posteriors seeds a 700-edge front (LDS holds 256); later events keep it long
+    # a first event with 700 rising posteriors seeds a 700-edge front (registers hold 64, LDS 256): the read falls
+    # through both faster tiers
     rng = np.random.default_rng(3)
     n_ref, n_ev = 700, 40
     m = np.zeros((n_ev, n_ref))
@@ -89,6 +93,20 @@ def test_front_longer_than_the_lds_share_takes_the_global_pass(oracle):
     got = sa.mea_batch(jobs)
     _check_against_oracle(oracle, jobs, got)
     assert got[1][2] == 0 and got[1][3] > 256        # the final front itself is longer than the LDS share
+
+
+def test_front_between_64_and_256_edges_takes_the_lds_pass(oracle):
+    rng = np.random.default_rng(4)
+    n_ref, n_ev = 150, 30
+    m = np.zeros((n_ev, n_ref))
+    m[0, :] = np.sort(rng.random(n_ref)) / n_ref
+    for ev in range(1, n_ev):
+        cols = rng.choice(n_ref, 20, replace=False)
+        m[ev, cols] = rng.random(20) / 20
+    jobs = [_job(m, np.zeros(n_ev))]
+    got = sa.mea_batch(jobs)
+    _check_against_oracle(oracle, jobs, got)
+    assert got[0][2] == 0
 
 
 def test_posteriors_of_the_hip_aligner(oracle):
