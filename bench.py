@@ -123,6 +123,15 @@ def bench_mea(args):
         pr = b.pairs(j)
         ev, rf, po, sh = sa.mea_params(pr["x"], pr["y"], np.round(pr["prob_e7"] / 1e7, 6))
         jobs.append(dict(event_idx=ev, ref_idx=rf, posterior=po, shortest=sh))
+    # the chained form: matrices built on the device from the pairs the batch left in HBM (sa_batch_mea)
+    cst = {}
+    for _ in range(max(args.warmup, 1)):
+        b.mea(stats=cst)
+    ckms = ccms = 0.0
+    for _ in range(args.steps):
+        chained = b.mea(stats=cst)
+        ckms += cst["kernel_ms"]
+        ccms += cst["call_ms"]
     b.close()
     entries = float(sum(len(j["posterior"]) for j in jobs))
     stats = {}
@@ -142,6 +151,8 @@ def bench_mea(args):
            "config": {"workload": "maximum expected accuracy path (src/signalalign/mea_algorithm.py:25-264) over the posteriors "
                                   "of %d synthetic %d-event reads" % (args.reads, args.events),
                       "kernel_ms": kms / K, "c_call_ms": cms / K, "kernel_entries_per_s": entries / (kms / K * 1e-3),
+                      "chained_kernel_ms": ckms / K, "chained_c_call_ms": ccms / K,
+                      "chained_paths_found": int(sum(1 for o in chained if o[2] == 0)),
                       "entries_per_read": entries / max(len(jobs), 1),
                       "paths_found": int(sum(1 for o in out if o[2] == 0)),
                       "mean_path_length": float(np.mean([len(o[0]) for o in out]))}}

@@ -229,7 +229,17 @@ typedef struct sa_mea_pair {
  * number of final forward edges (return_all=True); any of the last four pointers may be NULL. */
 int sa_mea_batch(const sa_mea_job_t *jobs, int64_t n_jobs, int device, unsigned flags, sa_mea_pair_t **path_out,
                  int64_t *n_path_out, double *sum_out, int32_t *status_out, int32_t *n_edges_out, double *kernel_ms_out);
-void sa_mea_release(void); /* returns the scratch sa_mea_batch keeps between calls */
+void sa_mea_release(void); /* returns the scratch sa_mea_batch and sa_batch_mea keep between calls */
+/* The same step chained onto a finished batch (after sa_batch_run), as mea_alignment_from_signal_align
+ * (mea_algorithm.py:323-341) chains it onto signalAlign's output: every read's aligned pairs are still in HBM, one wave
+ * per read builds the posterior matrix and shortest_ref_per_event from them there (what get_mea_params_from_events does
+ * with the event table; the posterior is the one the TSV prints, six decimals) and the path kernels follow; only the
+ * paths come back.  path_out[j] holds (ref_idx = x, event_idx = y) in the coordinates of sa_pair_t.  One entry per job
+ * of the batch in every output array. */
+int sa_batch_mea(sa_batch_t *b, unsigned flags, sa_mea_pair_t **path_out, int64_t *n_path_out, double *sum_out,
+                 int32_t *status_out, double *kernel_ms_out);
+/* "%f" of prob_e7 / 1e7 read back as a double: the posterior_probability column of the event table */
+double sa_mea_printed_posterior(int64_t prob_e7);
 /* get_mea_params_from_events (mea_algorithm.py:267-320), host side, sparse: from the reference_index, event_index and
  * posterior_probability columns of an event table (any row order) to the COO entries and shortest_ref_per_event.
  * The outputs need room for n entries / (max event - min event + 1) events; returns the number of COO entries and the

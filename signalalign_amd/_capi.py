@@ -77,7 +77,7 @@ EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alp
            "sa_model_set_to_hdp_expected_values", "sa_kmer_id", "sa_default_ambig", "sa_load_ambig",
            "sa_batch_create", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_stats",
            "sa_batch_job_cells", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_plan_describe", "sa_plan_digest",
-           "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_device_count", "sa_strerror",
+           "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_device_count", "sa_strerror",
            "sa_version", "sa_free"]
 
 
@@ -145,6 +145,9 @@ def lib():
                                        C.POINTER(C.c_int32), dp, dp]
     i32p = C.POINTER(C.c_int32)
     L.sa_mea_batch.argtypes = [C.POINTER(MeaJob), C.c_int64, C.c_int, C.c_uint, C.POINTER(C.c_void_p), ip, dp, i32p, i32p, dp]
+    L.sa_batch_mea.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_void_p), ip, dp, i32p, dp]
+    L.sa_mea_printed_posterior.restype = C.c_double
+    L.sa_mea_printed_posterior.argtypes = [C.c_int64]
     L.sa_mea_params.restype = C.c_int64
     L.sa_mea_params.argtypes = [ip, ip, dp, C.c_int64, i32p, i32p, dp, i32p, ip]
     L.sa_free.argtypes = [C.c_void_p]
@@ -278,6 +281,30 @@ class Batch:
         n = C.c_int64()
         _chk(lib().sa_batch_n_pairs(self._h, job, C.byref(n)), "sa_batch_n_pairs")
         return n.value
+
+    def mea(self, stats=None):
+        """sa_batch_mea: the maximum-expected-accuracy path of every read of this (finished) batch, built from the pairs
+        that are still on the device.  Returns per job (path [n, 2] of (x, y), best sum, status)."""
+        n = self.n_jobs
+        ptrs = (C.c_void_p * max(n, 1))()
+        cnt = np.zeros(max(n, 1), dtype=np.int64)
+        sums = np.zeros(max(n, 1), dtype=np.float64)
+        st = np.zeros(max(n, 1), dtype=np.int32)
+        kms = C.c_double()
+        t0 = time.perf_counter()
+        _chk(lib().sa_batch_mea(self._h, 0, ptrs, _ip(cnt), _dp(sums), st.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(kms)),
+             "sa_batch_mea")
+        if stats is not None:
+            stats["kernel_ms"] = kms.value
+            stats["call_ms"] = (time.perf_counter() - t0) * 1e3
+        out = []
+        for i in range(n):
+            a = np.zeros((int(cnt[i]), 2), dtype=np.int32)
+            if cnt[i]:
+                C.memmove(a.ctypes.data, ptrs[i], 8 * int(cnt[i]))
+            lib().sa_free(ptrs[i])
+            out.append((a, float(sums[i]), int(st[i])))
+        return out
 
     def stats(self):
         s = BatchStats()

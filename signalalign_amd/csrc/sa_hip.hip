@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "sa_internal.h"
+#include "sa_scratch.h"
 
 #define NEG_INF (-__builtin_inf())
 
@@ -846,6 +847,9 @@ struct sa_batch {
     sa_pair_t *h_pairs;      // pinned host copy of all pairs, job after job
     long long h_pairs_cap, n_pairs_total;
     std::vector<long long> job_off;
+    std::vector<long long> job_dev_off;   // where a job's pairs start in d_out (device finalisation only)
+    sa_pair_t *d_pairs_up;                // host-finalised pairs uploaded for a downstream device step (sa_batch_mea)
+    long long d_pairs_up_cap;
     bool ran;
     sa_batch_stats_t stats;
     hipEvent_t ev[8];
@@ -909,6 +913,7 @@ void sa_batch_destroy(sa_batch_t *b) {
         if (b->cstream[i]) (void) hipStreamDestroy(b->cstream[i]);
     if (b->pair_stream) (void) hipStreamDestroy(b->pair_stream);
     if (b->h_pairs) (void) hipHostFree(b->h_pairs);
+    if (b->d_pairs_up) (void) hipFree(b->d_pairs_up);
     if (b->h_seg_off) (void) hipHostFree(b->h_seg_off);
     if (b->h_overflow) (void) hipHostFree(b->h_overflow);
     sa_plan_free(b->plan);
@@ -971,6 +976,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     }
     b->cand_alloc = 0; b->out_alloc = 0;
     b->h_pairs = nullptr; b->h_pairs_cap = 0; b->n_pairs_total = 0;
+    b->d_pairs_up = nullptr; b->d_pairs_up_cap = 0;
     memset(&b->stats, 0, sizeof(b->stats));
     for (int i = 0; i < 8; i++) b->ev[i] = nullptr;
 #define TRY(x) do { int rc_ = (x); if (rc_) { sa_batch_destroy(b); return rc_; } } while (0)
@@ -1359,6 +1365,7 @@ int sa_batch_run(sa_batch_t *b) {
         }
         b->job_off[pl->n_jobs] = total;
         b->n_pairs_total = total;
+        b->job_dev_off.clear();
         b->ran = true;
         return SA_OK;
     }
@@ -1425,6 +1432,7 @@ int sa_batch_run(sa_batch_t *b) {
         for (size_t g = 0; g < ng; g++)
             for (long long sg = b->groups[g].seg0; sg < b->groups[g].seg1; sg++) seg_group[sg] = (int) g;
         long long next = gbase[ng];
+        b->job_dev_off.assign((size_t) pl->n_jobs, 0);
         for (long long j = pl->n_jobs - 1; j >= 0; j--) {
             const sa_jobinfo_t *J = &pl->jobs[j];
             long long first_seg = -1;
@@ -1433,6 +1441,8 @@ int sa_batch_run(sa_batch_t *b) {
             if (first_seg >= 0) {
                 int g = seg_group[first_seg];
                 next = gbase[g] + b->h_seg_off[first_seg + g];
+                // the group's pairs sit in d_out from its first segment's candidate slot on
+                b->job_dev_off[j] = pl->segs[b->groups[g].seg0].cand_off + b->h_seg_off[first_seg + g];
             }
             b->job_off[j] = next;  // jobs without segments are empty ranges in front of the next job
         }
@@ -1440,6 +1450,39 @@ int sa_batch_run(sa_batch_t *b) {
         b->n_pairs_total = gbase[ng];
     }
     b->ran = true;
+    return SA_OK;
+}
+
+// Device-side view of the results for a downstream device step (sa_mea.hip): per job the first pair in *pairs and the
+// number of pairs and of events.  After host finalisation (SA_FLAG_EXACT) the pairs are uploaded once.
+int sa_batch_device_view(sa_batch_t *b, const sa_pair_t **pairs, std::vector<long long> *first, std::vector<long long> *count,
+                         std::vector<long long> *n_events, int *device) {
+    if (!b || !pairs || !first || !count || !n_events || !device) return SA_EINVAL;
+    if (!b->ran) return SA_ESTATE;
+    const sa_plan_t *pl = b->plan;
+    const size_t nj = (size_t) pl->n_jobs;
+    first->assign(nj, 0); count->assign(nj, 0); n_events->assign(nj, 0);
+    for (size_t j = 0; j < nj; j++) {
+        (*count)[j] = b->job_off[j + 1] - b->job_off[j];
+        (*n_events)[j] = pl->jobs[j].n_events;
+    }
+    *device = b->device;
+    HIPCHK(hipSetDevice(b->device));
+    if (b->job_dev_off.size() == nj) {
+        *pairs = b->d_out;
+        for (size_t j = 0; j < nj; j++) (*first)[j] = b->job_dev_off[j];
+        return SA_OK;
+    }
+    if (b->n_pairs_total > b->d_pairs_up_cap) {
+        if (b->d_pairs_up) HIPCHK(hipFree(b->d_pairs_up));
+        b->d_pairs_up = nullptr; b->d_pairs_up_cap = 0;
+        HIPCHK(hipMalloc((void **) &b->d_pairs_up, sizeof(sa_pair_t) * (size_t) b->n_pairs_total));
+        b->d_pairs_up_cap = b->n_pairs_total;
+    }
+    if (b->n_pairs_total)
+        HIPCHK(hipMemcpy(b->d_pairs_up, b->h_pairs, sizeof(sa_pair_t) * (size_t) b->n_pairs_total, hipMemcpyHostToDevice));
+    *pairs = b->d_pairs_up;
+    for (size_t j = 0; j < nj; j++) (*first)[j] = b->job_off[j];
     return SA_OK;
 }
 

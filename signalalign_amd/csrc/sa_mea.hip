@@ -50,6 +50,7 @@ struct MeaPlan {
     int *n_out, *n_edges, *status;
     double *sum;
     struct MeaEdge *gf;          // global fronts (k_mea<true>)
+    const int *n_dev;            // entries per read when the matrices were built on the device (sa_batch_mea), else NULL
 };
 struct __attribute__((aligned(16))) MeaEdge {   // one front entry, read and written as a single 16-byte word
     double sum;
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(64) void k_mea_wave(MeaPlan P, int n_jobs) {
     const double *__restrict__ data = P.data + J.off;
     const int *__restrict__ shortest = P.shortest + J.sh_off;
     int *a_ref = P.a_ref + J.off, *a_ev = P.a_ev + J.off, *a_prev = P.a_prev + J.off;
-    const int n = J.n;
+    const int n = P.n_dev ? P.n_dev[jb] : J.n;
     int fref = 0, fid = 0, nref = 0, nid = 0;   // F[lane] (lane < nF), N[lane] (lane < nN)
     double fsum = 0, nsum = 0;
     int nF = 0, nN = 0, na = 0, status = SA_MEA_OK, n_edges = 0, n_path = 0;
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(64) void k_mea(MeaPlan P, const int *__restrict__ i
     const double *__restrict__ data = P.data + J.off;
     const int *__restrict__ shortest = P.shortest + J.sh_off;
     int *a_ref = P.a_ref + J.off, *a_ev = P.a_ev + J.off, *a_prev = P.a_prev + J.off;
-    const int n = J.n;
+    const int n = P.n_dev ? P.n_dev[jb] : J.n;
 
     __shared__ MeaEdge s_front[2 * MEA_FRONT_CAP];
     const int cap = GLOBAL_FRONT ? n + 2 : MEA_FRONT_CAP;
@@ -568,9 +569,13 @@ struct MeaWorkspace : SaScratch {
 };
 static MeaWorkspace g_mea_ws;
 
+static void mea_chain_release();
 extern "C" void sa_mea_release(void) {
-    std::lock_guard<std::mutex> guard(g_mea_ws.mu);
-    g_mea_ws.release();
+    {
+        std::lock_guard<std::mutex> guard(g_mea_ws.mu);
+        g_mea_ws.release();
+    }
+    mea_chain_release();
 }
 
 #define MEACHK(call)                                                                                        \
@@ -582,6 +587,59 @@ extern "C" void sa_mea_release(void) {
             goto done;                                                                                      \
         }                                                                                                   \
     } while (0)
+
+// Three tiers of the same algorithm: fronts in registers (64 edges), in LDS (256), in global memory (any length); a read
+// whose front outgrows a tier is handed to the next one.  SA_MEA_TIER=1|2 starts lower (tests).  h_status: pinned, one
+// word per read.
+static int mea_run_tiers(MeaWorkspace &W, MeaPlan &P, std::vector<MeaJob> &hj, char *d, size_t o_jobs, size_t o_ids,
+                         int *h_status, int device, float *kms_out) {
+    const size_t nj = hj.size();
+    int rc = SA_OK;
+    float kms2 = 0;
+    std::vector<int> redo;
+    const char *tier_env = getenv("SA_MEA_TIER");
+    int tier = tier_env ? atoi(tier_env) : 0;
+    tier = tier < 0 ? 0 : (tier > 2 ? 2 : tier);
+    bool all = true;                       // first launch: every read, no id list
+    for (; tier < 3; tier++) {
+        const unsigned grid = all ? (unsigned) nj : (unsigned) redo.size();
+        const int *d_ids = all ? nullptr : (const int *) (d + o_ids);
+        if (tier == 2) {                   // two lists of n + 2 entries per read
+            size_t gf_tot = 0;
+            for (size_t q = 0; q < (all ? nj : redo.size()); q++) {
+                const size_t j = all ? q : (size_t) redo[q];
+                hj[j].gf_off = (long long) gf_tot;
+                gf_tot += 2 * ((size_t) hj[j].n + 2);
+            }
+            if ((rc = W.dev(&W.d_gf, &W.d_gf_cap, sizeof(MeaEdge) * gf_tot, device)) != SA_OK) goto done;
+            P.gf = (MeaEdge *) W.d_gf;
+            MEACHK(hipMemcpyAsync(d + o_jobs, hj.data(), sizeof(MeaJob) * nj, hipMemcpyHostToDevice, 0));
+        }
+        if (!all) MEACHK(hipMemcpyAsync(d + o_ids, redo.data(), 4 * redo.size(), hipMemcpyHostToDevice, 0));
+        MEACHK(hipEventRecord(W.e0, 0));
+        if (tier == 0) {
+            if (!all) { rc = SA_EINVAL; goto done; }   // the register tier is only ever the first
+            hipLaunchKernelGGL(k_mea_wave, dim3(grid), dim3(64), 0, 0, P, (int) nj);
+        } else if (tier == 1) {
+            hipLaunchKernelGGL(k_mea<false>, dim3(grid), dim3(64), 0, 0, P, d_ids, (int) grid);
+        } else {
+            hipLaunchKernelGGL(k_mea<true>, dim3(grid), dim3(64), 0, 0, P, d_ids, (int) grid);
+        }
+        MEACHK(hipEventRecord(W.e1, 0));
+        MEACHK(hipGetLastError());
+        MEACHK(hipMemcpyAsync(h_status, P.status, 4 * nj, hipMemcpyDeviceToHost, 0));
+        MEACHK(hipStreamSynchronize(0));
+        MEACHK(hipEventElapsedTime(&kms2, W.e0, W.e1));
+        *kms_out += kms2;
+        redo.clear();
+        for (size_t j = 0; j < nj; j++)
+            if (h_status[j] == MEA_ST_OVERFLOW) redo.push_back((int) j);
+        all = false;
+        if (redo.empty()) break;
+    }
+done:
+    return rc;
+}
 
 extern "C" int sa_mea_batch(const sa_mea_job_t *jobs, int64_t n_jobs, int device, unsigned flags, sa_mea_pair_t **path_out,
                             int64_t *n_path_out, double *sum_out, int32_t *status_out, int32_t *n_edges_out,
@@ -630,8 +688,7 @@ extern "C" int sa_mea_batch(const sa_mea_job_t *jobs, int64_t n_jobs, int device
     const size_t res_bytes = o_ids - o_out;
     MeaPlan P;
     memset(&P, 0, sizeof(P));
-    float kms = 0, kms2 = 0;
-    std::vector<int> redo;
+    float kms = 0;
     if ((rc = W.pin(&W.h_in, &W.h_in_cap, in_bytes ? in_bytes : 8, device)) != SA_OK) return rc;
     {
         char *h = (char *) W.h_in;
@@ -664,49 +721,7 @@ extern "C" int sa_mea_batch(const sa_mea_job_t *jobs, int64_t n_jobs, int device
         P.out = (int2 *) (d + o_out);
         P.sum = (double *) (d + o_sum);
         P.n_out = (int *) (d + o_res); P.n_edges = P.n_out + nj; P.status = P.n_edges + nj;
-        // three tiers of the same algorithm: fronts in registers (64 edges), in LDS (256), in global memory (any length);
-        // a read whose front outgrows a tier is handed to the next one.  SA_MEA_TIER=1|2 starts lower (tests).
-        const char *tier_env = getenv("SA_MEA_TIER");
-        int tier = tier_env ? atoi(tier_env) : 0;
-        tier = tier < 0 ? 0 : (tier > 2 ? 2 : tier);
-        const int *h_status = (const int *) ((const char *) W.h_res + (o_res - o_out)) + 2 * nj;
-        bool all = true;                       // first launch: every read, no id list
-        for (; tier < 3; tier++) {
-            const unsigned grid = all ? (unsigned) nj : (unsigned) redo.size();
-            const int *d_ids = all ? nullptr : (const int *) (d + o_ids);
-            if (tier == 2) {                   // two lists of n + 2 entries per read
-                size_t gf_tot = 0;
-                for (size_t q = 0; q < (all ? nj : redo.size()); q++) {
-                    const size_t j = all ? q : (size_t) redo[q];
-                    hj[j].gf_off = (long long) gf_tot;
-                    gf_tot += 2 * ((size_t) hj[j].n + 2);
-                }
-                if ((rc = W.dev(&W.d_gf, &W.d_gf_cap, sizeof(MeaEdge) * gf_tot, device)) != SA_OK) goto done;
-                P.gf = (MeaEdge *) W.d_gf;
-                MEACHK(hipMemcpyAsync(d + o_jobs, hj.data(), sizeof(MeaJob) * nj, hipMemcpyHostToDevice, 0));
-            }
-            if (!all) MEACHK(hipMemcpyAsync(d + o_ids, redo.data(), 4 * redo.size(), hipMemcpyHostToDevice, 0));
-            MEACHK(hipEventRecord(W.e0, 0));
-            if (tier == 0) {
-                if (!all) { rc = SA_EINVAL; goto done; }   // the register tier is only ever the first
-                hipLaunchKernelGGL(k_mea_wave, dim3(grid), dim3(64), 0, 0, P, (int) nj);
-            } else if (tier == 1) {
-                hipLaunchKernelGGL(k_mea<false>, dim3(grid), dim3(64), 0, 0, P, d_ids, (int) grid);
-            } else {
-                hipLaunchKernelGGL(k_mea<true>, dim3(grid), dim3(64), 0, 0, P, d_ids, (int) grid);
-            }
-            MEACHK(hipEventRecord(W.e1, 0));
-            MEACHK(hipGetLastError());
-            MEACHK(hipMemcpyAsync((void *) h_status, P.status, 4 * nj, hipMemcpyDeviceToHost, 0));
-            MEACHK(hipStreamSynchronize(0));
-            MEACHK(hipEventElapsedTime(&kms2, W.e0, W.e1));
-            kms += kms2;
-            redo.clear();
-            for (size_t j = 0; j < nj; j++)
-                if (h_status[j] == MEA_ST_OVERFLOW) redo.push_back((int) j);
-            all = false;
-            if (redo.empty()) break;
-        }
+        if ((rc = mea_run_tiers(W, P, hj, d, o_jobs, o_ids, (int *) ((char *) W.h_res + (o_res - o_out)) + 2 * nj, device, &kms)) != SA_OK) goto done;
         MEACHK(hipMemcpyAsync(W.h_res, d + o_out, res_bytes, hipMemcpyDeviceToHost, 0));
         MEACHK(hipStreamSynchronize(0));
     }
@@ -802,4 +817,263 @@ extern "C" int64_t sa_mea_params(const int64_t *reference_index, const int64_t *
     }
     if (n_events_out) *n_events_out = n_ev;
     return m;
+}
+
+// ---- chained onto a finished batch: the posterior matrices are built on the device ---------------------------------
+// sa_batch_run leaves every read's aligned pairs in HBM.  mea_alignment_from_signal_align (mea_algorithm.py:323-341)
+// would read them back from the TSV / fast5 table and run get_mea_params_from_events; here one wave per read turns the
+// pairs into the COO matrix and shortest_ref_per_event in place (k_mea_from_pairs) and the MEA kernels follow, so
+// nothing but the final paths crosses PCIe.
+//
+// The event table's posterior_probability is what the TSV prints, "%f" of prob_e7 / 1e7, six decimals: a decimal
+// rounding of a binary double.  Only a last digit of 5 can tie; then the sign of q * 1e7 - prob_e7 (one fma, exact in
+// sign) says on which side of the tie the double q = prob_e7 / 1e7 lies, and an exact tie goes to even as glibc's
+// printf does.  tests/test_host_mea.py checks every value of prob_e7 against Python's "%f".
+__host__ __device__ static inline double mea_printed_posterior(long long prob_e7) {
+    long long k = prob_e7 / 10;
+    const long long rem = prob_e7 % 10;
+    if (rem > 5) {
+        k++;
+    } else if (rem == 5) {
+        const double q = (double) prob_e7 / 1e7;
+        const double side = fma(q, 1e7, -(double) prob_e7);
+        if (side > 0 || (side == 0 && (k & 1))) k++;
+    }
+    return (double) k / 1e6;
+}
+extern "C" double sa_mea_printed_posterior(int64_t prob_e7) { return mea_printed_posterior((long long) prob_e7); }
+
+struct MeaChain {
+    long long pair_off;   // first pair of the read in the batch's device results
+    int n_raw, n_events;  // pairs and events of the read
+};
+
+__device__ __forceinline__ int wave_max_i(int v) {
+    for (int o = 32; o; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return uni(v);
+}
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// next cell of an event's bucket [b0, b1) in reference order: the smallest reference position above `last`, and the
+// smallest prob_e7 among its rows (numpy's field-order tie break leaves the lowest posterior first, and the first row
+// of a cell is the one get_mea_params_from_events keeps)
+__device__ __forceinline__ bool mea_next_cell(const int *sr, const int *sp, int b0, int b1, int last, int &ref, int &prob) {
+    int best = 0x7fffffff;
+    for (int t = b0; t < b1; t++) {
+        const int r = sr[t];
+        if (r > last && r < best) best = r;
+    }
+    if (best == 0x7fffffff) return false;
+    int mp = 0x7fffffff;
+    for (int t = b0; t < b1; t++)
+        if (sr[t] == best) mp = min(mp, sp[t]);
+    ref = best;
+    prob = mp;
+    return true;
+}
+
+__global__ __launch_bounds__(64) void k_mea_from_pairs(const sa_pair_t *__restrict__ pairs, const MeaChain *__restrict__ chain,
+                                                       MeaPlan P, int *fill, int *s_ref, int *s_prob, int *n_dev, int *mins,
+                                                       int n_jobs) {
+    const int jb = blockIdx.x, lane = threadIdx.x;
+    const MeaChain C = chain[jb];
+    const MeaJob J = P.jobs[jb];
+    const sa_pair_t *pr = pairs + C.pair_off;
+    int *fl = fill + J.sh_off, *sr = s_ref + J.off, *sp = s_prob + J.off;
+    int *rows = const_cast<int *>(P.rows) + J.off, *cols = const_cast<int *>(P.cols) + J.off;
+    double *data = const_cast<double *>(P.data) + J.off;
+    int *sh = const_cast<int *>(P.shortest) + J.sh_off;
+    const int n = C.n_raw;
+    int xmin = 0x7fffffff, ymin = 0x7fffffff, ymax = -0x7fffffff;
+    for (int j = lane; j < n; j += 64) {
+        const int x = (int) pr[j].x, y = (int) pr[j].y;
+        xmin = min(xmin, x); ymin = min(ymin, y); ymax = max(ymax, y);
+    }
+    xmin = wave_min(xmin); ymin = wave_min(ymin); ymax = wave_max_i(ymax);
+    const int n_ev = n > 0 ? ymax - ymin + 1 : 0;
+    if (n <= 0 || n_ev > J.n_sh) {   // no pairs (the MEA kernels report SA_MEA_EMPTY); the second cannot happen
+        if (lane == 0) { n_dev[jb] = 0; mins[2 * jb] = 0; mins[2 * jb + 1] = 0; }
+        return;
+    }
+    // rows per event -> bucket starts -> rows placed by event (order inside a bucket is irrelevant: mea_next_cell)
+    for (int e = lane; e < n_ev; e += 64) fl[e] = 0;
+    __threadfence();
+    for (int j = lane; j < n; j += 64) atomicAdd(&fl[(int) pr[j].y - ymin], 1);
+    __threadfence();
+    int carry = 0;
+    for (int base = 0; base < n_ev; base += 64) {
+        const int e = base + lane;
+        const int c = e < n_ev ? fl[e] : 0;
+        const int incl = wave_incl_scan(c, lane);
+        if (e < n_ev) fl[e] = carry + incl - c;
+        carry += rl(incl, 63);
+    }
+    __threadfence();
+    for (int j = lane; j < n; j += 64) {
+        const int pos = atomicAdd(&fl[(int) pr[j].y - ymin], 1);   // fl[e] ends as the END of bucket e
+        sr[pos] = (int) pr[j].x - xmin;
+        sp[pos] = (int) pr[j].prob_e7;
+    }
+    __threadfence();
+    // the COO matrix, events ascending, reference positions ascending inside an event, zeros dropped
+    int n_out = 0;
+    for (int base = 0; base < n_ev; base += 64) {
+        const int e = base + lane;
+        int b0 = 0, b1 = 0;
+        if (e < n_ev) { b1 = fl[e]; b0 = e ? fl[e - 1] : 0; }
+        int kept = 0, last = -1, ref = 0, prob = 0;
+        while (mea_next_cell(sr, sp, b0, b1, last, ref, prob)) {
+            last = ref;
+            kept += mea_printed_posterior(prob) != 0.0;
+        }
+        const int incl = wave_incl_scan(kept, lane);
+        int w = n_out + incl - kept;
+        last = -1;
+        while (mea_next_cell(sr, sp, b0, b1, last, ref, prob)) {
+            last = ref;
+            const double p = mea_printed_posterior(prob);
+            if (p != 0.0) { rows[w] = e; cols[w] = ref; data[w] = p; w++; }
+        }
+        n_out += rl(incl, 63);
+    }
+    // :305-318 shortest_ref_per_event: the lowest reference position of this and every later event (zeros count), inf for
+    // an event without rows
+    int below = SA_MEA_INF;
+    for (int base = ((n_ev - 1) / 64) * 64; base >= 0; base -= 64) {
+        const int e = base + lane;
+        int mn = SA_MEA_INF;
+        bool any = false;
+        if (e < n_ev) {
+            const int b1 = fl[e], b0 = e ? fl[e - 1] : 0;
+            any = b1 > b0;
+            for (int t = b0; t < b1; t++) mn = min(mn, sr[t]);
+        }
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_down(mn, o);
+            if (lane + o < 64) mn = min(mn, t);
+        }
+        mn = min(mn, below);
+        if (e < n_ev) sh[e] = any ? mn : SA_MEA_INF;
+        below = rl(mn, 0);
+    }
+    if (lane == 0) { n_dev[jb] = n_out; mins[2 * jb] = xmin; mins[2 * jb + 1] = ymin; }
+}
+
+struct MeaChainWorkspace : MeaWorkspace {
+    void *d_aux = nullptr;
+    size_t d_aux_cap = 0;
+};
+static MeaChainWorkspace g_mea_chain_ws;
+static void mea_chain_release() {
+    std::lock_guard<std::mutex> guard(g_mea_chain_ws.mu);
+    g_mea_chain_ws.release();
+}
+
+extern "C" int sa_batch_mea(sa_batch_t *b, unsigned flags, sa_mea_pair_t **path_out, int64_t *n_path_out, double *sum_out,
+                            int32_t *status_out, double *kernel_ms_out) {
+    (void) flags;
+    if (!b || !path_out || !n_path_out) return SA_EINVAL;
+    const sa_pair_t *d_pairs = nullptr;
+    std::vector<long long> first, count, n_events;
+    int device = 0;
+    int rc = sa_batch_device_view(b, &d_pairs, &first, &count, &n_events, &device);
+    if (rc) return rc;
+    const size_t nj = first.size();
+    for (size_t j = 0; j < nj; j++) {
+        path_out[j] = nullptr; n_path_out[j] = 0;
+        if (status_out) status_out[j] = 0;
+        if (sum_out) sum_out[j] = 0.0;
+    }
+    if (kernel_ms_out) *kernel_ms_out = 0.0;
+    if (nj == 0) return SA_OK;
+    std::vector<MeaJob> hj(nj);
+    std::vector<MeaChain> hc(nj);
+    size_t n_tot = 0, sh_tot = 0, out_tot = 0;
+    for (size_t j = 0; j < nj; j++) {
+        if (count[j] > (1ll << 30) || n_events[j] > (1ll << 30)) return SA_EINVAL;
+        MeaJob &J = hj[j];
+        memset(&J, 0, sizeof(J));
+        J.off = (long long) n_tot; J.sh_off = (long long) sh_tot; J.out_off = (long long) out_tot;
+        J.n = (int) count[j]; J.n_sh = (int) n_events[j] + 1;
+        J.out_cap = (int) (count[j] < n_events[j] ? count[j] : n_events[j]);
+        hc[j].pair_off = first[j]; hc[j].n_raw = (int) count[j]; hc[j].n_events = (int) n_events[j];
+        n_tot += (size_t) count[j]; sh_tot += (size_t) n_events[j] + 1; out_tot += (size_t) J.out_cap;
+    }
+    MeaChainWorkspace &W = g_mea_chain_ws;
+    std::lock_guard<std::mutex> guard(W.mu);
+    // device: [jobs | chain | data f64 | rows | cols | shortest | arena ref, ev, prev | out | sum | n_out, n_edges, status | mins | ids]
+    // aux (dead after k_mea_from_pairs): [fill | sorted ref | sorted prob]
+    const size_t o_jobs = 0, o_chain = sa_up256(sizeof(MeaJob) * nj), o_data = sa_up256(o_chain + sizeof(MeaChain) * nj),
+                 o_rows = sa_up256(o_data + 8 * n_tot), o_cols = sa_up256(o_rows + 4 * n_tot), o_sh = sa_up256(o_cols + 4 * n_tot),
+                 o_arena = sa_up256(o_sh + 4 * sh_tot), o_out = sa_up256(o_arena + 12 * n_tot),
+                 o_sum = sa_up256(o_out + 8 * out_tot), o_res = o_sum + 8 * nj, o_mins = o_res + 12 * nj,
+                 o_ndev = o_mins + 8 * nj, o_ids = sa_up256(o_ndev + 4 * nj), dev_bytes = o_ids + 4 * nj;
+    const size_t res_bytes = o_ids - o_out;
+    const size_t a_fill = 0, a_sref = sa_up256(4 * sh_tot), a_sprob = sa_up256(a_sref + 4 * n_tot), aux_bytes = a_sprob + 4 * n_tot;
+    MeaPlan P;
+    memset(&P, 0, sizeof(P));
+    float kms = 0, kms0 = 0;
+    if ((rc = W.dev(&W.d_ws, &W.d_ws_cap, dev_bytes, device)) != SA_OK) return rc;
+    if ((rc = W.dev(&W.d_aux, &W.d_aux_cap, aux_bytes ? aux_bytes : 256, device)) != SA_OK) return rc;
+    if ((rc = W.pin(&W.h_res, &W.h_res_cap, res_bytes, device)) != SA_OK) return rc;
+    if ((rc = W.events()) != SA_OK) return rc;
+    {
+        char *d = (char *) W.d_ws, *a = (char *) W.d_aux;
+        MEACHK(hipMemcpyAsync(d + o_jobs, hj.data(), sizeof(MeaJob) * nj, hipMemcpyHostToDevice, 0));
+        MEACHK(hipMemcpyAsync(d + o_chain, hc.data(), sizeof(MeaChain) * nj, hipMemcpyHostToDevice, 0));
+        P.jobs = (const MeaJob *) (d + o_jobs);
+        P.data = (const double *) (d + o_data);
+        P.rows = (const int *) (d + o_rows);
+        P.cols = (const int *) (d + o_cols);
+        P.shortest = (const int *) (d + o_sh);
+        P.a_ref = (int *) (d + o_arena); P.a_ev = P.a_ref + n_tot; P.a_prev = P.a_ev + n_tot;
+        P.out = (int2 *) (d + o_out);
+        P.sum = (double *) (d + o_sum);
+        P.n_out = (int *) (d + o_res); P.n_edges = P.n_out + nj; P.status = P.n_edges + nj;
+        P.n_dev = (const int *) (d + o_ndev);
+        MEACHK(hipEventRecord(W.e0, 0));
+        hipLaunchKernelGGL(k_mea_from_pairs, dim3((unsigned) nj), dim3(64), 0, 0, d_pairs, (const MeaChain *) (d + o_chain), P,
+                           (int *) (a + a_fill), (int *) (a + a_sref), (int *) (a + a_sprob), (int *) (d + o_ndev),
+                           (int *) (d + o_mins), (int) nj);
+        MEACHK(hipEventRecord(W.e1, 0));
+        MEACHK(hipGetLastError());
+        MEACHK(hipStreamSynchronize(0));
+        MEACHK(hipEventElapsedTime(&kms0, W.e0, W.e1));
+        if ((rc = mea_run_tiers(W, P, hj, d, o_jobs, o_ids, (int *) ((char *) W.h_res + (o_res - o_out)) + 2 * nj, device, &kms)) != SA_OK)
+            goto done;
+        MEACHK(hipMemcpyAsync(W.h_res, d + o_out, res_bytes, hipMemcpyDeviceToHost, 0));
+        MEACHK(hipStreamSynchronize(0));
+    }
+    if (kernel_ms_out) *kernel_ms_out = (double) kms + (double) kms0;
+    {
+        const char *hr = (const char *) W.h_res;
+        const int2 *h_out = (const int2 *) hr;
+        const double *h_sum = (const double *) (hr + (o_sum - o_out));
+        const int *h_n = (const int *) (hr + (o_res - o_out)), *h_status = h_n + 2 * nj;
+        const int *h_mins = (const int *) (hr + (o_mins - o_out));
+        for (size_t j = 0; j < nj; j++) {
+            const int n = h_n[j];
+            if (status_out) status_out[j] = h_status[j];
+            if (sum_out) sum_out[j] = h_sum[j];
+            n_path_out[j] = n;
+            path_out[j] = (sa_mea_pair_t *) malloc(sizeof(sa_mea_pair_t) * (size_t) (n > 0 ? n : 1));
+            if (!path_out[j]) { rc = SA_ENOMEM; goto done; }
+            const int2 *src = h_out + hj[j].out_off + hj[j].out_cap - n;
+            const int x0 = h_mins[2 * j], y0 = h_mins[2 * j + 1];
+            for (int i = 0; i < n; i++) {   // back to the batch's own coordinates
+                path_out[j][i].ref_idx = src[i].x + x0;
+                path_out[j][i].event_idx = src[i].y + y0;
+            }
+        }
+    }
+done:
+    if (rc != SA_OK)
+        for (size_t j = 0; j < nj; j++) { free(path_out[j]); path_out[j] = nullptr; n_path_out[j] = 0; }
+    return rc;
 }

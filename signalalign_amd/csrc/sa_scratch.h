@@ -62,6 +62,11 @@ struct SaScratch {
         return SA_OK;
     }
 };
+// sa_hip.hip: device-side view of a finished batch for a downstream device step (per job: first pair in *pairs, number
+// of pairs, number of events)
+int sa_batch_device_view(sa_batch_t *b, const sa_pair_t **pairs, std::vector<long long> *first, std::vector<long long> *count,
+                         std::vector<long long> *n_events, int *device);
+
 static inline size_t sa_up256(size_t x) { return (x + 255) & ~(size_t) 255; }
 
 #endif

@@ -133,3 +133,51 @@ def test_posteriors_of_the_hip_aligner(oracle):
         assert np.all(np.diff(path[:, 0]) >= 0) and np.all(np.diff(path[:, 1]) > 0)
         # nearly every event of the read is on the path, and the path's expected accuracy is most of the mass
         assert len(path) > 0.9 * len(np.unique(job["event_idx"]))
+
+
+@pytest.mark.parametrize("flags", [0, sa.FLAG_EXACT])
+def test_chained_onto_a_finished_batch(oracle, flags):
+    """sa_batch_mea builds the matrices on the device from the pairs sa_batch_run left there: the same paths as the
+    explicit route (pairs to the host, "%f", get_mea_params_from_events, maximum_expected_accuracy_alignment) through
+    the CPU restatement."""
+    pm = sa.Model.load(cases.MODEL_6MER)
+    p = sa.default_params()
+    reads = cases.synthetic_jobs(cases.MODEL_6MER, 8, 1200, 300)
+    b = sa.Batch(pm, p, reads, flags=flags)
+    b.run()
+    got = b.mea()
+    assert len(got) == len(reads)
+    for j in range(len(reads)):
+        pr = b.pairs(j)
+        post = np.array([float("%f" % (q / 1e7)) for q in pr["prob_e7"]])
+        ev, rf, po, sh = oracle.mea_params(pr["x"], pr["y"], post)
+        est, epath, ebest = oracle.mea(ev, rf, po, sh)
+        path, best, st = got[j]
+        assert st == est == 0
+        assert best == ebest
+        x0, y0 = int(pr["x"].min()), int(pr["y"].min())
+        assert np.array_equal(path[:, 0] - x0, epath[:, 0]) and np.array_equal(path[:, 1] - y0, epath[:, 1])
+        # every pair of the path is one of the read's aligned pairs
+        have = set(zip(pr["x"].tolist(), pr["y"].tolist()))
+        assert all((int(x), int(y)) in have for x, y in path)
+    b.close()
+
+
+def test_chained_with_ambiguous_positions_and_an_empty_read(oracle):
+    # several paths per cell (duplicate (x, y) rows with different posteriors): the lowest posterior of a cell stays
+    pm = sa.Model.load(cases.MODEL_CPG)
+    p = sa.default_params()
+    reads = cases.synthetic_jobs(cases.MODEL_CPG, 3, 600, 40, cpg_ambiguous=True)
+    b = sa.Batch(pm, p, reads, ambig=sa.default_ambig({"X": "CE"}))
+    b.run()
+    got = b.mea()
+    for j in range(len(reads)):
+        pr = b.pairs(j)
+        post = np.array([float("%f" % (q / 1e7)) for q in pr["prob_e7"]])
+        ev, rf, po, sh = oracle.mea_params(pr["x"], pr["y"], post)
+        est, epath, ebest = oracle.mea(ev, rf, po, sh)
+        path, best, st = got[j]
+        assert st == est and best == ebest
+        x0, y0 = int(pr["x"].min()), int(pr["y"].min())
+        assert np.array_equal(path[:, 0] - x0, epath[:, 0]) and np.array_equal(path[:, 1] - y0, epath[:, 1])
+    b.close()

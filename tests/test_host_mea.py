@@ -26,3 +26,15 @@ def test_params_edge_cases(oracle):
     assert g[3].tolist() == [0, 1, sa.MEA_INF, 4]
     one = sa.mea_params([42], [7], [0.25])
     assert one[0].tolist() == [0] and one[1].tolist() == [0] and one[3].tolist() == [0]
+
+
+def test_printed_posterior_is_what_percent_f_prints():
+    """sa_mea_printed_posterior(prob_e7) == float("%f" % (prob_e7 / 1e7)): the device builds the event table's
+    posterior column with this formula.  Every value whose seventh decimal is a 5 (the only candidates for a tie) in a
+    stride, plus random others, against Python's own formatting."""
+    L = sa.lib()
+    rng = np.random.default_rng(1)
+    values = list(range(5, 10_000_000, 10 * 97)) + list(range(0, 2000)) + [9_999_995, 10_000_000, 78125, 234375] \
+        + rng.integers(0, 10_000_001, 20000).tolist()
+    for v in values:
+        assert L.sa_mea_printed_posterior(int(v)) == float("%f" % (v / 1e7)), v
