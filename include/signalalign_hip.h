@@ -240,6 +240,8 @@ int sa_batch_mea(sa_batch_t *b, unsigned flags, sa_mea_pair_t **path_out, int64_
                  int32_t *status_out, double *kernel_ms_out);
 /* "%f" of prob_e7 / 1e7 read back as a double: the posterior_probability column of the event table */
 double sa_mea_printed_posterior(int64_t prob_e7);
+/* the same, evaluated by the GPU for prob_e7 = first .. first + n - 1 (test hook: host and device must agree) */
+int sa_mea_printed_posterior_device(int64_t first, int64_t n, double *out, int device);
 /* get_mea_params_from_events (mea_algorithm.py:267-320), host side, sparse: from the reference_index, event_index and
  * posterior_probability columns of an event table (any row order) to the COO entries and shortest_ref_per_event.
  * The outputs need room for n entries / (max event - min event + 1) events; returns the number of COO entries and the

@@ -1077,3 +1077,24 @@ done:
         for (size_t j = 0; j < nj; j++) { free(path_out[j]); path_out[j] = nullptr; n_path_out[j] = 0; }
     return rc;
 }
+
+// the device's evaluation of mea_printed_posterior for prob_e7 = first .. first + n - 1 (tests: it must agree with the host's
+// for every value; both are the same source, but the division and the fma are the device's own)
+__global__ void k_printed_posterior(long long first, long long n, double *out) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = mea_printed_posterior(first + i);
+}
+extern "C" int sa_mea_printed_posterior_device(int64_t first, int64_t n, double *out, int device) {
+    if (n < 0 || (n > 0 && !out) || n > (1ll << 31)) return SA_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SA_ENODEVICE;
+    if (device < 0 || device >= ndev) return SA_EINVAL;
+    if (n == 0) return SA_OK;
+    double *d = nullptr;
+    if (hipSetDevice(device) != hipSuccess) return SA_ENODEVICE;
+    if (hipMalloc((void **) &d, sizeof(double) * (size_t) n) != hipSuccess) return SA_ENOMEM;
+    hipLaunchKernelGGL(k_printed_posterior, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, (long long) first, (long long) n, d);
+    hipError_t e = hipMemcpy(out, d, sizeof(double) * (size_t) n, hipMemcpyDeviceToHost);
+    (void) hipFree(d);
+    return e == hipSuccess ? SA_OK : SA_ENODEVICE;
+}

@@ -181,3 +181,23 @@ def test_chained_with_ambiguous_positions_and_an_empty_read(oracle):
         x0, y0 = int(pr["x"].min()), int(pr["y"].min())
         assert np.array_equal(path[:, 0] - x0, epath[:, 0]) and np.array_equal(path[:, 1] - y0, epath[:, 1])
     b.close()
+
+
+def test_device_rounds_every_posterior_as_percent_f_does():
+    """All 10^7 + 1 values of prob_e7: the GPU's printed posterior equals the host's (same source, the device's own
+    division and fma), and the host's is checked against Python's "%f" in tests/test_host_mea.py."""
+    import ctypes as C
+    L = sa.lib()
+    n = 10_000_001
+    dev = np.zeros(n)
+    assert L.sa_mea_printed_posterior_device(0, n, dev.ctypes.data_as(C.POINTER(C.c_double)), 0) == 0
+    # the host formula, vectorised: k = prob // 10 rounded on the seventh decimal
+    prob = np.arange(n, dtype=np.int64)
+    k, rem = prob // 10, prob % 10
+    up = rem > 5
+    tie = rem == 5
+    for v in prob[tie][:: 997]:                       # spot-check the vector formula's tie branch against the C one
+        assert L.sa_mea_printed_posterior(int(v)) == dev[v]
+    assert np.array_equal(dev[~tie], ((k + up)[~tie]) / 1e6)
+    host_ties = np.array([L.sa_mea_printed_posterior(int(v)) for v in prob[tie][:: 13]])
+    assert np.array_equal(dev[tie][:: 13], host_ties)
