@@ -61,11 +61,23 @@ __device__ __forceinline__ double ea_emit(const double *kc, double e, const EaJo
     return J.lvar + (c + (-0.5 * a * a));
 }
 
-__global__ __launch_bounds__(64) void k_event_align(EaPlan P, int n_jobs) {
+// One block of 128 threads (two waves) per read: thread o owns band offset o (100 of them).  What a band cell needs
+// from memory -- its event's mean, its k-mer's three constants -- is data dependent (the band's position is decided
+// band by band) but only ever advances by one event or one k-mer per band, so both streams are staged ahead of the band
+// in LDS circular buffers (256 slots each, refilled 64 at a time by coalesced loads well before the band arrives) and
+// the serial chain of a band never waits for HBM: per band it is LDS reads, the emission, three scores and a barrier.
+#define EA_THREADS 128
+#define EA_SLOTS 256   // power of two, >= band width + refill chunk + lead
+// UNIT_VAR: every read of the launch has var == 1 (the reference always aligns with var = 1, impl/eventAligner.c:845-849):
+// x / 1.0 == x, one division per cell less.
+template <bool UNIT_VAR>
+__global__ __launch_bounds__(EA_THREADS) void k_event_align(EaPlan P, int n_jobs) {
     __shared__ double ring[3][EA_BW];
+    __shared__ double kmu[EA_SLOTS], ksd[EA_SLOTS], kcc[EA_SLOTS], ebuf[EA_SLOTS];
+    __shared__ int s_fills;
     const int job = blockIdx.x;
     if (job >= n_jobs) return;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const EaJob J = P.jobs[job];
     const double *ev = P.ev + J.ev_off;
     const double *kc = P.kc + 3 * J.kc_off;
@@ -76,27 +88,70 @@ __global__ __launch_bounds__(64) void k_event_align(EaPlan P, int n_jobs) {
     const long long n_bands = (long long) (n_events + 1) + (n_kmers + 1);
 
     int my_fills = 0;
-    for (int i = lane; i < n_events; i += 64) col[i] = EA_NEG_INF;
-    for (int o = lane; o < EA_BW; o += 64) {
+    if (tid == 0) s_fills = 0;
+    for (int i = tid; i < n_events; i += EA_THREADS) col[i] = EA_NEG_INF;
+    for (int o = tid; o < EA_BW; o += EA_THREADS) {
         ring[0][o] = (o == EA_HALF) ? 0.0 : EA_NEG_INF;        // band 0: (event -1, k-mer -1) at offset 50
         ring[1][o] = (o == EA_HALF) ? J.lp_trim : EA_NEG_INF;  // band 1: first event trimmed
     }
+    // first 192 k-mers and events (the first bands reach k-mer 48 and event 50 at most)
+    int k_loaded = 0, e_loaded = 0;
+    for (; k_loaded < n_kmers && k_loaded < 192; k_loaded += 64)
+        if (tid < 64 && k_loaded + tid < n_kmers) {
+            const int idx = k_loaded + tid;
+            kmu[idx & (EA_SLOTS - 1)] = kc[3ll * idx]; ksd[idx & (EA_SLOTS - 1)] = kc[3ll * idx + 1];
+            kcc[idx & (EA_SLOTS - 1)] = kc[3ll * idx + 2];
+        }
+    for (; e_loaded < n_events && e_loaded < 192; e_loaded += 64)
+        if (tid >= 64 && e_loaded + tid - 64 < n_events) ebuf[(e_loaded + tid - 64) & (EA_SLOTS - 1)] = ev[e_loaded + tid - 64];
     int ll_ev1 = EA_HALF, ll_km1 = -1 - EA_HALF;   // band b-1
     int ll_ev2 = EA_HALF - 1, ll_km2 = -1 - EA_HALF;  // band b-2
-    if (lane == 0) {
+    if (tid == 0) {
         ll[0] = ll_ev2; ll[1] = ll_km2;
         ll[2] = ll_ev1; ll[3] = ll_km1;
     }
     __syncthreads();
-    for (long long b = 2; b < n_bands; b++) {
-        const double *prev1 = ring[(b - 1) % 3], *prev2 = ring[(b - 2) % 3];
-        double *cur = ring[b % 3];
+    const int o = tid;
+    // ring rows of bands b-2, b-1, b (rotated, not recomputed with % 3); clamped neighbour offsets
+    int r2 = 0, r1 = 1, r0 = 2;
+    const int om1 = o > 0 ? o - 1 : 0, oc = o < EA_BW ? o : EA_BW - 1, op1 = o + 1 < EA_BW ? o + 1 : EA_BW - 1;
+    for (int b = 2; b < (int) n_bands; b++) {
+        const double *prev1 = ring[r1], *prev2 = ring[r2];
+        double *cur = ring[r0];
+        // Everything this band can need from LDS is requested in ONE batch before the band's position is known: the two
+        // band ends that decide the move, the three neighbours of either move in band b-1 and the two possible diagonal
+        // neighbours in band b-2, and the operands of both candidate cells (k-mer km or km + 1, event e or e + 1).  One
+        // LDS round trip per band instead of five dependent ones.
+        const int dk = ll_km1 - ll_km2;                      // 0 or 1: the move that produced band b-1
         const double lo = prev1[0], hi = prev1[EA_BW - 1];
+        const double p1m = prev1[om1], p1c = prev1[oc], p1p = prev1[op1];
+        const int od0 = o - 1 + dk;                          // diagonal neighbour if this band moves down, +1 if right
+        const double p2a = prev2[od0 < 0 ? 0 : (od0 < EA_BW ? od0 : EA_BW - 1)];
+        const double p2b = prev2[od0 + 1 < 0 ? 0 : (od0 + 1 < EA_BW ? od0 + 1 : EA_BW - 1)];
+        const int km_d = ll_km1 + o, e_r = ll_ev1 - o;      // cell of offset o after a down move / a right move
+        const double mu_d = kmu[km_d & (EA_SLOTS - 1)], sd_d = ksd[km_d & (EA_SLOTS - 1)], c_d = kcc[km_d & (EA_SLOTS - 1)];
+        const double mu_r = kmu[(km_d + 1) & (EA_SLOTS - 1)], sd_r = ksd[(km_d + 1) & (EA_SLOTS - 1)],
+                     c_r = kcc[(km_d + 1) & (EA_SLOTS - 1)];
+        const double ev_r = ebuf[e_r & (EA_SLOTS - 1)], ev_d = ebuf[(e_r + 1) & (EA_SLOTS - 1)];
         bool right;
         if (lo == EA_NEG_INF && hi == EA_NEG_INF) right = (b % 2) == 1;  // both ends outside the matrix: alternate
         else right = lo < hi;                                           // Suzuki's rule
         const int ll_ev = ll_ev1 + (right ? 0 : 1), ll_km = ll_km1 + (right ? 1 : 0);
-        if (lane == 0) { ll[2 * b] = ll_ev; ll[2 * b + 1] = ll_km; }
+        if (tid == 0) { ll[2 * b] = ll_ev; ll[2 * b + 1] = ll_km; }
+        // keep the streams ahead of the band: k-mers up to ll_km + 99 and events up to ll_ev are needed now; a chunk
+        // lands at least 32 bands before its first use and overwrites slots the band left 60 and more bands ago
+        if (k_loaded < n_kmers && ll_km + EA_BW + 32 > k_loaded) {
+            if (tid < 64 && k_loaded + tid < n_kmers) {
+                const int idx = k_loaded + tid;
+                kmu[idx & (EA_SLOTS - 1)] = kc[3ll * idx]; ksd[idx & (EA_SLOTS - 1)] = kc[3ll * idx + 1];
+                kcc[idx & (EA_SLOTS - 1)] = kc[3ll * idx + 2];
+            }
+            k_loaded += 64;
+        }
+        if (e_loaded < n_events && ll_ev + 1 + 32 > e_loaded) {
+            if (tid >= 64 && e_loaded + tid - 64 < n_events) ebuf[(e_loaded + tid - 64) & (EA_SLOTS - 1)] = ev[e_loaded + tid - 64];
+            e_loaded += 64;
+        }
         int o_min = 0 - ll_km, o_max = n_kmers - ll_km;
         const int e_min = ll_ev - (n_events - 1), e_max = ll_ev + 1;
         o_min = e_min > o_min ? e_min : o_min;
@@ -104,10 +159,7 @@ __global__ __launch_bounds__(64) void k_event_align(EaPlan P, int n_jobs) {
         o_max = e_max < o_max ? e_max : o_max;
         o_max = o_max > EA_BW ? EA_BW : o_max;
         const int trim_o = -1 - ll_km;
-#pragma unroll
-        for (int rep = 0; rep < 2; rep++) {
-            const int o = lane + 64 * rep;
-            if (o >= EA_BW) break;
+        if (o < EA_BW) {
             double val = EA_NEG_INF;
             if (o == trim_o) {  // k-mer -1: every event so far trimmed
                 const int e = ll_ev - o;
@@ -115,11 +167,18 @@ __global__ __launch_bounds__(64) void k_event_align(EaPlan P, int n_jobs) {
             }
             if (o >= o_min && o < o_max) {
                 const int e = ll_ev - o, km = ll_km + o;
-                const int o_up = ll_ev1 - (e - 1), o_left = (km - 1) - ll_km1, o_diag = (km - 1) - ll_km2;
-                const float up = (o_up >= 0 && o_up < EA_BW) ? (float) prev1[o_up] : -__builtin_inff();
-                const float left = (o_left >= 0 && o_left < EA_BW) ? (float) prev1[o_left] : -__builtin_inff();
-                const float diag = (o_diag >= 0 && o_diag < EA_BW) ? (float) prev2[o_diag] : -__builtin_inff();
-                const double lp_em = ea_emit(kc + 3ll * km, ev[e], J);
+                // o_up = ll_ev1 - (e - 1) = o + 1 (right) or o (down); o_left = (km - 1) - ll_km1 = o (right) or o - 1
+                // (down); o_diag = (km - 1) - ll_km2 = o - 1 + dk (+ 1 if right)
+                const int o_up = right ? o + 1 : o, o_left = right ? o : o - 1, o_diag = od0 + (right ? 1 : 0);
+                const float up = (o_up >= 0 && o_up < EA_BW) ? (float) (right ? p1p : p1c) : -__builtin_inff();
+                const float left = (o_left >= 0 && o_left < EA_BW) ? (float) (right ? p1c : p1m) : -__builtin_inff();
+                const float diag = (o_diag >= 0 && o_diag < EA_BW) ? (float) (right ? p2b : p2a) : -__builtin_inff();
+                // ea_emit on the staged operands (same operations, same order)
+                const double mu = right ? mu_r : mu_d, sd = right ? sd_r : sd_d, c = right ? c_r : c_d;
+                const double num = (right ? ev_r : ev_d) + J.var * mu - J.scale * mu - J.shift;
+                const double en = UNIT_VAR ? num : num / J.var;
+                const double a = (en - mu) / sd;
+                const double lp_em = J.lvar + (c + (-0.5 * a * a));
                 const float s_d = (float) ((double) diag + J.lp_step + lp_em);
                 const float s_u = (float) ((double) up + J.lp_stay + lp_em);
                 const float s_l = (float) ((double) left + J.lp_skip);
@@ -130,7 +189,7 @@ __global__ __launch_bounds__(64) void k_event_align(EaPlan P, int n_jobs) {
                 best = s_l > best ? s_l : best;
                 from = best == s_l ? 2 : from;        // FROM_L
                 val = (double) best;
-                trace[b * EA_BW + o] = from;
+                trace[(long long) b * EA_BW + o] = from;
                 if (km == n_kmers - 1) col[e] = val;
                 my_fills++;
             }
@@ -138,8 +197,15 @@ __global__ __launch_bounds__(64) void k_event_align(EaPlan P, int n_jobs) {
         }
         ll_ev2 = ll_ev1; ll_km2 = ll_km1;
         ll_ev1 = ll_ev; ll_km1 = ll_km;
+        { const int t = r2; r2 = r1; r1 = r0; r0 = t; }
         __syncthreads();
     }
+    for (int off = 32; off > 0; off >>= 1) my_fills += __shfl_xor(my_fills, off, 64);
+    if (lane == 0) atomicAdd(&s_fills, my_fills);
+    __threadfence();   // the second wave's col[] entries, read by the first below
+    __syncthreads();
+    if (tid >= 64) return;
+    my_fills = s_fills;
     // best (event, last k-mer) cell with the events behind it trimmed: first maximum, as the reference's scan
     float best = -__builtin_inff();
     int best_ev = 0x7fffffff;
@@ -152,7 +218,6 @@ __global__ __launch_bounds__(64) void k_event_align(EaPlan P, int n_jobs) {
         const int oe = __shfl_xor(best_ev, off, 64);
         if (ob > best || (ob == best && oe < best_ev)) { best = ob; best_ev = oe; }
     }
-    for (int off = 32; off > 0; off >>= 1) my_fills += __shfl_xor(my_fills, off, 64);
     if (lane != 0) return;
     P.fills[job] = my_fills;
     // traceback (lane 0): the scan starts from event 0 when nothing scored (best == -inf), like the reference
@@ -312,6 +377,7 @@ extern "C" int sa_event_align_batch(const sa_model_t *m, const sa_ea_job_t *jobs
     }
     size_t ev_n = 0, kc_n = 0;
     long long trace_tot = 0, ll_tot = 0, col_tot = 0, out_tot = 0;
+    bool all_unit_var = true;
     for (int64_t j = 0; j < n_jobs; j++) {
         const sa_ea_job_t *jb = &jobs[j];
         const int64_t n_kmers = jb->seq_len - (m->k - 1);
@@ -338,6 +404,7 @@ extern "C" int sa_event_align_batch(const sa_model_t *m, const sa_ea_job_t *jobs
         J.lp_step = log(1.0 - exp(J.lp_skip) - exp(J.lp_stay));
         J.lp_trim = log(0.01);
         J.scale = jb->scale; J.shift = jb->shift; J.var = jb->var;
+        all_unit_var = all_unit_var && jb->var == 1.0;
         J.lvar = log((1 / jb->var));
     }
     EaPlan P;
@@ -369,7 +436,10 @@ extern "C" int sa_event_align_batch(const sa_model_t *m, const sa_ea_job_t *jobs
             hipLaunchKernelGGL(k_ea_expand, dim3((unsigned) ((n_pos + 255) / 256)), dim3(256), 0, 0, d_kt,
                                (const int32_t *) (d_kt + kt_n), (double *) (d + o_kc), n_pos);
         }
-        hipLaunchKernelGGL(k_event_align, dim3((unsigned) n_jobs), dim3(64), 0, 0, P, (int) n_jobs);
+        if (all_unit_var)
+            hipLaunchKernelGGL(k_event_align<true>, dim3((unsigned) n_jobs), dim3(EA_THREADS), 0, 0, P, (int) n_jobs);
+        else
+            hipLaunchKernelGGL(k_event_align<false>, dim3((unsigned) n_jobs), dim3(EA_THREADS), 0, 0, P, (int) n_jobs);
         EACHK(hipEventRecord(W.e1, 0));
         EACHK(hipGetLastError());
         EACHK(hipMemcpyAsync(W.h_res, d + o_out, res_bytes, hipMemcpyDeviceToHost, 0));
