@@ -7,9 +7,10 @@
 // best (event, last k-mer) cell; three quality checks.
 //
 // Mapping: one wave per read.  The recurrence is serial in the band index (~ events + k-mers steps), the 100 cells of a
-// band are independent: lane l computes offsets l and l+64.  The three live bands sit in LDS (the neighbours of a
-// cell are at the same or an adjacent offset of the two previous bands, which one depends on the moves taken); the
-// trace (one byte per cell) and the band origins go to global memory for the traceback, which lane 0 walks at the end.
+// band are independent: lane l computes offsets l and l+64.  The live bands and every cell's operands stay in registers
+// (neighbours are DPP wave rotates, the move taken is a wave-uniform branch; see k_event_align); the trace (one byte per
+// cell) and the band origins go to global memory for the traceback, which the wave walks at the end through 64-band
+// blocks staged in LDS.
 // Arithmetic follows the reference's order of operations and float casts (the file is compiled with
 // -ffp-contract=off), with the emission of the memory-resident EXACT kernels: results are bit-identical to the CPU
 // restatement in oracle/sa_oracle.c.  PARITY UNPINNED against the reference itself: its tests of this function need
@@ -61,23 +62,97 @@ __device__ __forceinline__ double ea_emit(const double *kc, double e, const EaJo
     return J.lvar + (c + (-0.5 * a * a));
 }
 
-// One block of 128 threads (two waves) per read: thread o owns band offset o (100 of them).  What a band cell needs
-// from memory -- its event's mean, its k-mer's three constants -- is data dependent (the band's position is decided
-// band by band) but only ever advances by one event or one k-mer per band, so both streams are staged ahead of the band
-// in LDS circular buffers (256 slots each, refilled 64 at a time by coalesced loads well before the band arrives) and
-// the serial chain of a band never waits for HBM: per band it is LDS reads, the emission, three scores and a barrier.
-#define EA_THREADS 128
-#define EA_SLOTS 256   // power of two, >= band width + refill chunk + lead
+// ONE WAVE PER READ, THE BAND IN REGISTERS.  The band is 100 offsets: lane l owns offset l ("rep 0") and, for l < 36,
+// offset 64 + l ("rep 1").  A band differs from the previous one by a single move, right (k-mer + 1) or down (event + 1),
+// decided from the two end cells (Suzuki-Kasahara); which move it is is a wave-uniform scalar, so the loop body exists
+// twice, once per move, each with STATIC neighbour shifts:
+//   right:  up = prev[o + 1], left = prev[o],     the lane's k-mer operands shift one offset down, a fresh k-mer enters at 99
+//   down:   up = prev[o],     left = prev[o - 1], the lane's event shifts one offset up, a fresh event enters at 0
+// and the diagonal neighbour (band b-2) is one of the two shifted copies the band before already made.  Neighbours are
+// DPP wave rotates (with the lane 63 -> rep 1 hand-over patched by one v_cndmask), fresh operands come out of a 64-entry
+// register buffer per stream by v_readlane (refilled with one coalesced load every 64 moves of its kind): the serial
+// chain of a band holds no LDS access, no barrier and no memory load.  An earlier version (two waves per read, band and
+// operand streams in LDS, one barrier per band) ran at 1.1 us per band, LDS throughput (30 wave-wide reads per band,
+// 8 reads resident per CU) and the barrier being the limit.
 // UNIT_VAR: every read of the launch has var == 1 (the reference always aligns with var = 1, impl/eventAligner.c:845-849):
 // x / 1.0 == x, one division per cell less.
+#define EA_THREADS 64
+#define EA_LAST1 (EA_BW - 65)   // lane of offset 99 in rep 1
+
+__device__ __forceinline__ int ea_from_next(int v) { return __builtin_amdgcn_mov_dpp(v, 0x134, 0xF, 0xF, false); }  // lane l <- l+1
+__device__ __forceinline__ int ea_from_prev(int v) { return __builtin_amdgcn_mov_dpp(v, 0x13C, 0xF, 0xF, false); }  // lane l <- l-1
+// x[o] <- x[o + 1] over the 100 offsets, `fill` enters at offset 99
+__device__ __forceinline__ void ea_shl(int &x0, int &x1, int fill, int lane) {
+    const int n0 = ea_from_next(x0), n1 = ea_from_next(x1);   // n1[63] = x1[0]
+    x0 = lane == 63 ? n1 : n0;
+    x1 = lane == EA_LAST1 ? fill : n1;
+}
+// x[o] <- x[o - 1], `fill` enters at offset 0
+__device__ __forceinline__ void ea_shr(int &x0, int &x1, int fill, int lane) {
+    const int p0 = ea_from_prev(x0), p1 = ea_from_prev(x1);   // p0[0] = x0[63]
+    x1 = lane == 0 ? p0 : p1;
+    x0 = lane == 0 ? fill : p0;
+}
+__device__ __forceinline__ void ea_shl(double &x0, double &x1, double fill, int lane) {
+    int a0 = __double2loint(x0), a1 = __double2loint(x1), b0 = __double2hiint(x0), b1 = __double2hiint(x1);
+    ea_shl(a0, a1, __double2loint(fill), lane);
+    ea_shl(b0, b1, __double2hiint(fill), lane);
+    x0 = __hiloint2double(b0, a0); x1 = __hiloint2double(b1, a1);
+}
+__device__ __forceinline__ void ea_shr(double &x0, double &x1, double fill, int lane) {
+    int a0 = __double2loint(x0), a1 = __double2loint(x1), b0 = __double2hiint(x0), b1 = __double2hiint(x1);
+    ea_shr(a0, a1, __double2loint(fill), lane);
+    ea_shr(b0, b1, __double2hiint(fill), lane);
+    x0 = __hiloint2double(b0, a0); x1 = __hiloint2double(b1, a1);
+}
+__device__ __forceinline__ void ea_shl(float &x0, float &x1, float fill, int lane) {
+    int a0 = __float_as_int(x0), a1 = __float_as_int(x1);
+    ea_shl(a0, a1, __float_as_int(fill), lane);
+    x0 = __int_as_float(a0); x1 = __int_as_float(a1);
+}
+__device__ __forceinline__ void ea_shr(float &x0, float &x1, float fill, int lane) {
+    int a0 = __float_as_int(x0), a1 = __float_as_int(x1);
+    ea_shr(a0, a1, __float_as_int(fill), lane);
+    x0 = __int_as_float(a0); x1 = __int_as_float(a1);
+}
+// A loaded value passed through a VALU move: the wait for the load is then placed HERE (inside the refill branch that
+// executes once per 64 moves) and not before the buffer's use in every band, where "s_waitcnt vmcnt(0)" would also wait
+// for all the trace stores of the previous band (one counter orders loads and stores).
+__device__ __forceinline__ double ea_settle(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v), lo2, hi2;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(lo2) : "v"(lo));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(hi2) : "v"(hi));
+    return __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double ea_rld(double v, int k) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), k), __builtin_amdgcn_readlane(__double2loint(v), k));
+}
+
+// one cell: the reference's three scores in float, emission in double (ea_emit's operations in ea_emit's order)
+template <bool UNIT_VAR>
+__device__ __forceinline__ double ea_cell(const EaJob &J, float up, float left, float diag, double mu, double sd, double c, double e,
+                                          unsigned char &from) {
+    const double num = e + J.var * mu - J.scale * mu - J.shift;
+    const double en = UNIT_VAR ? num : num / J.var;
+    const double a = (en - mu) / sd;
+    const double lp_em = J.lvar + (c + (-0.5 * a * a));
+    const float s_d = (float) ((double) diag + J.lp_step + lp_em);
+    const float s_u = (float) ((double) up + J.lp_stay + lp_em);
+    const float s_l = (float) ((double) left + J.lp_skip);
+    float best = s_d;
+    from = 0;                             // FROM_D
+    best = s_u > best ? s_u : best;
+    from = best == s_u ? 1 : from;        // FROM_U
+    best = s_l > best ? s_l : best;
+    from = best == s_l ? 2 : from;        // FROM_L
+    return (double) best;
+}
+
 template <bool UNIT_VAR>
 __global__ __launch_bounds__(EA_THREADS) void k_event_align(EaPlan P, int n_jobs) {
-    __shared__ double ring[3][EA_BW];
-    __shared__ double kmu[EA_SLOTS], ksd[EA_SLOTS], kcc[EA_SLOTS], ebuf[EA_SLOTS];
-    __shared__ int s_fills;
     const int job = blockIdx.x;
     if (job >= n_jobs) return;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = threadIdx.x;
     const EaJob J = P.jobs[job];
     const double *ev = P.ev + J.ev_off;
     const double *kc = P.kc + 3 * J.kc_off;
@@ -85,73 +160,49 @@ __global__ __launch_bounds__(EA_THREADS) void k_event_align(EaPlan P, int n_jobs
     int *ll = P.ll + 2 * J.ll_off;
     double *col = P.col + J.col_off;
     const int n_events = J.n_events, n_kmers = J.n_kmers;
-    const long long n_bands = (long long) (n_events + 1) + (n_kmers + 1);
+    const int n_bands = (n_events + 1) + (n_kmers + 1);
+    const float NINF = -__builtin_inff();
 
     int my_fills = 0;
-    if (tid == 0) s_fills = 0;
-    for (int i = tid; i < n_events; i += EA_THREADS) col[i] = EA_NEG_INF;
-    for (int o = tid; o < EA_BW; o += EA_THREADS) {
-        ring[0][o] = (o == EA_HALF) ? 0.0 : EA_NEG_INF;        // band 0: (event -1, k-mer -1) at offset 50
-        ring[1][o] = (o == EA_HALF) ? J.lp_trim : EA_NEG_INF;  // band 1: first event trimmed
-    }
-    // first 192 k-mers and events (the first bands reach k-mer 48 and event 50 at most)
-    int k_loaded = 0, e_loaded = 0;
-    for (; k_loaded < n_kmers && k_loaded < 192; k_loaded += 64)
-        if (tid < 64 && k_loaded + tid < n_kmers) {
-            const int idx = k_loaded + tid;
-            kmu[idx & (EA_SLOTS - 1)] = kc[3ll * idx]; ksd[idx & (EA_SLOTS - 1)] = kc[3ll * idx + 1];
-            kcc[idx & (EA_SLOTS - 1)] = kc[3ll * idx + 2];
-        }
-    for (; e_loaded < n_events && e_loaded < 192; e_loaded += 64)
-        if (tid >= 64 && e_loaded + tid - 64 < n_events) ebuf[(e_loaded + tid - 64) & (EA_SLOTS - 1)] = ev[e_loaded + tid - 64];
-    int ll_ev1 = EA_HALF, ll_km1 = -1 - EA_HALF;   // band b-1
-    int ll_ev2 = EA_HALF - 1, ll_km2 = -1 - EA_HALF;  // band b-2
-    if (tid == 0) {
-        ll[0] = ll_ev2; ll[1] = ll_km2;
+    for (int i = lane; i < n_events; i += 64) col[i] = EA_NEG_INF;
+    // band 1 (the band "b-1" of the first iteration): offset 50 holds the first event trimmed; band 0: 0.0 at offset 50
+    int ll_ev1 = EA_HALF, ll_km1 = -1 - EA_HALF;
+    if (lane == 0) {
+        ll[0] = EA_HALF - 1; ll[1] = -1 - EA_HALF;
         ll[2] = ll_ev1; ll[3] = ll_km1;
     }
-    __syncthreads();
-    const int o = tid;
-    // ring rows of bands b-2, b-1, b (rotated, not recomputed with % 3); clamped neighbour offsets
-    int r2 = 0, r1 = 1, r0 = 2;
-    const int om1 = o > 0 ? o - 1 : 0, oc = o < EA_BW ? o : EA_BW - 1, op1 = o + 1 < EA_BW ? o + 1 : EA_BW - 1;
-    for (int b = 2; b < (int) n_bands; b++) {
-        const double *prev1 = ring[r1], *prev2 = ring[r2];
-        double *cur = ring[r0];
-        // Everything this band can need from LDS is requested in ONE batch before the band's position is known: the two
-        // band ends that decide the move, the three neighbours of either move in band b-1 and the two possible diagonal
-        // neighbours in band b-2, and the operands of both candidate cells (k-mer km or km + 1, event e or e + 1).  One
-        // LDS round trip per band instead of five dependent ones.
-        const int dk = ll_km1 - ll_km2;                      // 0 or 1: the move that produced band b-1
-        const double lo = prev1[0], hi = prev1[EA_BW - 1];
-        const double p1m = prev1[om1], p1c = prev1[oc], p1p = prev1[op1];
-        const int od0 = o - 1 + dk;                          // diagonal neighbour if this band moves down, +1 if right
-        const double p2a = prev2[od0 < 0 ? 0 : (od0 < EA_BW ? od0 : EA_BW - 1)];
-        const double p2b = prev2[od0 + 1 < 0 ? 0 : (od0 + 1 < EA_BW ? od0 + 1 : EA_BW - 1)];
-        const int km_d = ll_km1 + o, e_r = ll_ev1 - o;      // cell of offset o after a down move / a right move
-        const double mu_d = kmu[km_d & (EA_SLOTS - 1)], sd_d = ksd[km_d & (EA_SLOTS - 1)], c_d = kcc[km_d & (EA_SLOTS - 1)];
-        const double mu_r = kmu[(km_d + 1) & (EA_SLOTS - 1)], sd_r = ksd[(km_d + 1) & (EA_SLOTS - 1)],
-                     c_r = kcc[(km_d + 1) & (EA_SLOTS - 1)];
-        const double ev_r = ebuf[e_r & (EA_SLOTS - 1)], ev_d = ebuf[(e_r + 1) & (EA_SLOTS - 1)];
+    float vf0 = lane == EA_HALF ? (float) J.lp_trim : NINF, vf1 = NINF;   // band b-1 as its readers see it
+    // band b-2 as band b's diagonal: band 0 -> band 1 was a DOWN move (ll_ev 49 -> 50), so o_diag = o - 1 if band 2 moves
+    // down, o if it moves right; band 0 is 0.0 at offset 50
+    float dd0 = lane == EA_HALF + 1 ? 0.0f : NINF, dd1 = NINF;            // diagonal neighbour if this band moves down
+    float dr0 = lane == EA_HALF ? 0.0f : NINF, dr1 = NINF;                // ... if it moves right
+    double lo = EA_NEG_INF, hi = EA_NEG_INF;                              // band b-1 at offsets 0 and 99
+    // operands of band b-1's cells: k-mer ll_km1 + o, event ll_ev1 - o
+    double mu0 = 0, sd0 = 1, c0 = 0, mu1 = 0, sd1 = 1, c1 = 0, e0 = 0, e1 = 0;
+    {
+        const int ka = ll_km1 + lane, kb = ll_km1 + 64 + lane, ea = ll_ev1 - lane, eb = ll_ev1 - 64 - lane;
+        if (ka >= 0 && ka < n_kmers) { mu0 = kc[3ll * ka]; sd0 = kc[3ll * ka + 1]; c0 = kc[3ll * ka + 2]; }
+        if (kb >= 0 && kb < n_kmers && lane <= EA_LAST1) { mu1 = kc[3ll * kb]; sd1 = kc[3ll * kb + 1]; c1 = kc[3ll * kb + 2]; }
+        if (ea >= 0 && ea < n_events) e0 = ev[ea];
+        if (eb >= 0 && eb < n_events) e1 = ev[eb];
+    }
+    // streams: the next k-mer to enter at offset 99 is ll_km1 + 100, the next event to enter at offset 0 is ll_ev1 + 1
+    int ks = ll_km1 + EA_BW, kb_base = ks, es = ll_ev1 + 1, eb_base = es;
+    double kb_mu = 0, kb_sd = 1, kb_c = 0, eb_v = 0;
+    {
+        const int k = kb_base + lane, e = eb_base + lane;
+        if (k >= 0 && k < n_kmers) { kb_mu = kc[3ll * k]; kb_sd = kc[3ll * k + 1]; kb_c = kc[3ll * k + 2]; }
+        if (e >= 0 && e < n_events) eb_v = ev[e];
+    }
+    kb_mu = ea_settle(kb_mu); kb_sd = ea_settle(kb_sd); kb_c = ea_settle(kb_c); eb_v = ea_settle(eb_v);
+    mu0 = ea_settle(mu0); sd0 = ea_settle(sd0); c0 = ea_settle(c0); mu1 = ea_settle(mu1); sd1 = ea_settle(sd1); c1 = ea_settle(c1);
+    e0 = ea_settle(e0); e1 = ea_settle(e1);
+    for (int b = 2; b < n_bands; b++) {
         bool right;
         if (lo == EA_NEG_INF && hi == EA_NEG_INF) right = (b % 2) == 1;  // both ends outside the matrix: alternate
         else right = lo < hi;                                           // Suzuki's rule
         const int ll_ev = ll_ev1 + (right ? 0 : 1), ll_km = ll_km1 + (right ? 1 : 0);
-        if (tid == 0) { ll[2 * b] = ll_ev; ll[2 * b + 1] = ll_km; }
-        // keep the streams ahead of the band: k-mers up to ll_km + 99 and events up to ll_ev are needed now; a chunk
-        // lands at least 32 bands before its first use and overwrites slots the band left 60 and more bands ago
-        if (k_loaded < n_kmers && ll_km + EA_BW + 32 > k_loaded) {
-            if (tid < 64 && k_loaded + tid < n_kmers) {
-                const int idx = k_loaded + tid;
-                kmu[idx & (EA_SLOTS - 1)] = kc[3ll * idx]; ksd[idx & (EA_SLOTS - 1)] = kc[3ll * idx + 1];
-                kcc[idx & (EA_SLOTS - 1)] = kc[3ll * idx + 2];
-            }
-            k_loaded += 64;
-        }
-        if (e_loaded < n_events && ll_ev + 1 + 32 > e_loaded) {
-            if (tid >= 64 && e_loaded + tid - 64 < n_events) ebuf[(e_loaded + tid - 64) & (EA_SLOTS - 1)] = ev[e_loaded + tid - 64];
-            e_loaded += 64;
-        }
+        if (lane == 0) { ll[2 * b] = ll_ev; ll[2 * b + 1] = ll_km; }
         int o_min = 0 - ll_km, o_max = n_kmers - ll_km;
         const int e_min = ll_ev - (n_events - 1), e_max = ll_ev + 1;
         o_min = e_min > o_min ? e_min : o_min;
@@ -159,53 +210,79 @@ __global__ __launch_bounds__(EA_THREADS) void k_event_align(EaPlan P, int n_jobs
         o_max = e_max < o_max ? e_max : o_max;
         o_max = o_max > EA_BW ? EA_BW : o_max;
         const int trim_o = -1 - ll_km;
-        if (o < EA_BW) {
-            double val = EA_NEG_INF;
+        float up0, up1, lf0, lf1, dg0, dg1;
+        if (right) {
+            // a fresh k-mer enters at offset 99
+            if (ks - kb_base == 64) {
+                kb_base += 64;
+                const int k = kb_base + lane;
+                kb_mu = 0; kb_sd = 1; kb_c = 0;
+                if (k >= 0 && k < n_kmers) { kb_mu = kc[3ll * k]; kb_sd = kc[3ll * k + 1]; kb_c = kc[3ll * k + 2]; }
+                kb_mu = ea_settle(kb_mu); kb_sd = ea_settle(kb_sd); kb_c = ea_settle(kb_c);
+            }
+            const int q = ks - kb_base;
+            ks++;
+            ea_shl(mu0, mu1, ea_rld(kb_mu, q), lane);
+            ea_shl(sd0, sd1, ea_rld(kb_sd, q), lane);
+            ea_shl(c0, c1, ea_rld(kb_c, q), lane);
+            lf0 = vf0; lf1 = vf1;
+            up0 = vf0; up1 = vf1;
+            ea_shl(up0, up1, NINF, lane);          // prev[o + 1]; offset 100 does not exist
+            dg0 = dr0; dg1 = dr1;
+            dr0 = up0; dr1 = up1;                  // for the NEXT band: band b-1 at o + 1 (dk = 1, right) ...
+            dd0 = lf0; dd1 = lf1;                  // ... and at o (dk = 1, down)
+        } else {
+            if (es - eb_base == 64) {
+                eb_base += 64;
+                const int e = eb_base + lane;
+                eb_v = (e >= 0 && e < n_events) ? ev[e] : 0.0;
+                eb_v = ea_settle(eb_v);
+            }
+            const int q = es - eb_base;
+            es++;
+            ea_shr(e0, e1, ea_rld(eb_v, q), lane);
+            up0 = vf0; up1 = vf1;
+            lf0 = vf0; lf1 = vf1;
+            ea_shr(lf0, lf1, NINF, lane);          // prev[o - 1]; offset -1 does not exist
+            dg0 = dd0; dg1 = dd1;
+            dr0 = up0; dr1 = up1;                  // for the NEXT band: band b-1 at o (dk = 0, right) ...
+            dd0 = lf0; dd1 = lf1;                  // ... and at o - 1 (dk = 0, down)
+        }
+        double val0 = EA_NEG_INF, val1 = EA_NEG_INF;
+        {
+            const int o = lane;
             if (o == trim_o) {  // k-mer -1: every event so far trimmed
                 const int e = ll_ev - o;
-                if (e >= 0 && e < n_events) val = J.lp_trim * (double) (e + 1);
+                if (e >= 0 && e < n_events) val0 = J.lp_trim * (double) (e + 1);
             }
             if (o >= o_min && o < o_max) {
-                const int e = ll_ev - o, km = ll_km + o;
-                // o_up = ll_ev1 - (e - 1) = o + 1 (right) or o (down); o_left = (km - 1) - ll_km1 = o (right) or o - 1
-                // (down); o_diag = (km - 1) - ll_km2 = o - 1 + dk (+ 1 if right)
-                const int o_up = right ? o + 1 : o, o_left = right ? o : o - 1, o_diag = od0 + (right ? 1 : 0);
-                const float up = (o_up >= 0 && o_up < EA_BW) ? (float) (right ? p1p : p1c) : -__builtin_inff();
-                const float left = (o_left >= 0 && o_left < EA_BW) ? (float) (right ? p1c : p1m) : -__builtin_inff();
-                const float diag = (o_diag >= 0 && o_diag < EA_BW) ? (float) (right ? p2b : p2a) : -__builtin_inff();
-                // ea_emit on the staged operands (same operations, same order)
-                const double mu = right ? mu_r : mu_d, sd = right ? sd_r : sd_d, c = right ? c_r : c_d;
-                const double num = (right ? ev_r : ev_d) + J.var * mu - J.scale * mu - J.shift;
-                const double en = UNIT_VAR ? num : num / J.var;
-                const double a = (en - mu) / sd;
-                const double lp_em = J.lvar + (c + (-0.5 * a * a));
-                const float s_d = (float) ((double) diag + J.lp_step + lp_em);
-                const float s_u = (float) ((double) up + J.lp_stay + lp_em);
-                const float s_l = (float) ((double) left + J.lp_skip);
-                float best = s_d;
-                unsigned char from = 0;               // FROM_D
-                best = s_u > best ? s_u : best;
-                from = best == s_u ? 1 : from;        // FROM_U
-                best = s_l > best ? s_l : best;
-                from = best == s_l ? 2 : from;        // FROM_L
-                val = (double) best;
+                unsigned char from;
+                val0 = ea_cell<UNIT_VAR>(J, up0, lf0, dg0, mu0, sd0, c0, e0, from);
                 trace[(long long) b * EA_BW + o] = from;
-                if (km == n_kmers - 1) col[e] = val;
+                if (ll_km + o == n_kmers - 1) col[ll_ev - o] = val0;
                 my_fills++;
             }
-            cur[o] = val;
         }
-        ll_ev2 = ll_ev1; ll_km2 = ll_km1;
+        if (lane <= EA_LAST1) {
+            const int o = 64 + lane;
+            if (o == trim_o) {
+                const int e = ll_ev - o;
+                if (e >= 0 && e < n_events) val1 = J.lp_trim * (double) (e + 1);
+            }
+            if (o >= o_min && o < o_max) {
+                unsigned char from;
+                val1 = ea_cell<UNIT_VAR>(J, up1, lf1, dg1, mu1, sd1, c1, e1, from);
+                trace[(long long) b * EA_BW + o] = from;
+                if (ll_km + o == n_kmers - 1) col[ll_ev - o] = val1;
+                my_fills++;
+            }
+        }
+        vf0 = (float) val0; vf1 = (float) val1;
+        lo = ea_rld(val0, 0); hi = ea_rld(val1, EA_LAST1);
         ll_ev1 = ll_ev; ll_km1 = ll_km;
-        { const int t = r2; r2 = r1; r1 = r0; r0 = t; }
-        __syncthreads();
     }
     for (int off = 32; off > 0; off >>= 1) my_fills += __shfl_xor(my_fills, off, 64);
-    if (lane == 0) atomicAdd(&s_fills, my_fills);
-    __threadfence();   // the second wave's col[] entries, read by the first below
-    __syncthreads();
-    if (tid >= 64) return;
-    my_fills = s_fills;
+    __threadfence();   // col[] entries written by other lanes, read below
     // best (event, last k-mer) cell with the events behind it trimmed: first maximum, as the reference's scan
     float best = -__builtin_inff();
     int best_ev = 0x7fffffff;
@@ -218,32 +295,65 @@ __global__ __launch_bounds__(EA_THREADS) void k_event_align(EaPlan P, int n_jobs
         const int oe = __shfl_xor(best_ev, off, 64);
         if (ob > best || (ob == best && oe < best_ev)) { best = ob; best_ev = oe; }
     }
-    if (lane != 0) return;
-    P.fills[job] = my_fills;
-    // traceback (lane 0): the scan starts from event 0 when nothing scored (best == -inf), like the reference
-    int cur_ev = (best > -__builtin_inff()) ? best_ev : 0, cur_km = n_kmers - 1;
+    if (lane == 0) P.fills[job] = my_fills;
+    // Traceback by the whole wave.  A pointer walk would be two dependent HBM loads per step (the band's origin, then
+    // the trace byte at an offset that depends on it).  Instead the trace rows and origins of 64 consecutive bands are
+    // staged with coalesced loads (rows into LDS, origins one per lane) and the walk inside the block is LDS reads and
+    // v_readlane; a step moves one or two bands down, so a block serves 32-64 steps.  The scan starts from event 0 when
+    // nothing scored (best == -inf), like the reference.
+    __shared__ unsigned int tr_rows[64 * EA_BW / 4];
+    const float best_u = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(best)));
+    int cur_ev = (best_u > -__builtin_inff()) ? __builtin_amdgcn_readfirstlane(best_ev) : 0, cur_km = n_kmers - 1;
     int *out = P.out + 2 * J.out_off;
-    int n = 0, cur_gap = 0, max_gap = 0;
-    double sum_em = 0;
+    int n = 0, cur_gap = 0, max_gap = 0, first_km = -1, last_km = -1;
     while (cur_km >= 0 && cur_ev >= 0) {
-        out[2 * n] = cur_km; out[2 * n + 1] = cur_ev; n++;
-        sum_em += ea_emit(kc + 3ll * cur_km, ev[cur_ev], J);
-        const long long b = (long long) (cur_ev + 1) + (cur_km + 1);
-        const int o = ll[2 * b] - cur_ev;
-        const unsigned char from = trace[b * EA_BW + o];
-        if (from == 0) { cur_km--; cur_ev--; cur_gap = 0; }
-        else if (from == 1) { cur_ev--; cur_gap = 0; }
-        else { cur_km--; cur_gap++; max_gap = cur_gap > max_gap ? cur_gap : max_gap; }
+        const int b_hi = cur_ev + cur_km + 2, b_lo = b_hi - 63 > 0 ? b_hi - 63 : 0;
+        const unsigned int *src = (const unsigned int *) (trace + (long long) b_lo * EA_BW);   // 100-byte rows: 4-byte aligned
+        const int n_words = (b_hi - b_lo + 1) * (EA_BW / 4);
+        {   // all 25 loads of a lane in flight together, then the LDS writes
+            unsigned int w[EA_BW / 4];
+#pragma unroll
+            for (int q = 0; q < EA_BW / 4; q++) w[q] = lane + 64 * q < n_words ? src[lane + 64 * q] : 0u;
+#pragma unroll
+            for (int q = 0; q < EA_BW / 4; q++) tr_rows[lane + 64 * q] = w[q];
+        }
+        const int llv = (b_hi - lane >= b_lo) ? ll[2 * (b_hi - lane)] : 0;                      // origin (event) of band b_hi - lane
+        const unsigned char *rows = (const unsigned char *) tr_rows;
+        while (cur_km >= 0 && cur_ev >= 0) {
+            const int b = cur_ev + cur_km + 2;
+            if (b < b_lo) break;
+            const int o = __builtin_amdgcn_readlane(llv, b_hi - b) - cur_ev;
+            const int from = __builtin_amdgcn_readfirstlane((int) rows[(b - b_lo) * EA_BW + o]);
+            if (lane == 0) { out[2 * n] = cur_km; out[2 * n + 1] = cur_ev; }
+            if (n == 0) first_km = cur_km;
+            last_km = cur_km;
+            n++;
+            if (from == 0) { cur_km--; cur_ev--; cur_gap = 0; }
+            else if (from == 1) { cur_ev--; cur_gap = 0; }
+            else { cur_km--; cur_gap++; max_gap = cur_gap > max_gap ? cur_gap : max_gap; }
+        }
+    }
+    // the emissions along the path, summed in path order as the reference does while it walks: computed 64 at a time,
+    // folded by v_readlane
+    __threadfence();
+    double sum_em = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane, cnt = n - base < 64 ? n - base : 64;
+        double em = 0;
+        if (i < n) em = ea_emit(kc + 3ll * out[2 * i], ev[out[2 * i + 1]], J);
+        for (int k = 0; k < cnt; k++) sum_em += ea_rld(em, k);
     }
     int st = 0;
     const double avg = sum_em / (double) n;
     if (avg < -5.2) st |= 1;
     // pairs are in traceback order: the last one is the front of the reversed list
-    if (!(n > 0 && out[2 * (n - 1)] == 0 && out[0] == n_kmers - 1)) st |= 2;
+    if (!(n > 0 && last_km == 0 && first_km == n_kmers - 1)) st |= 2;
     if (max_gap > 50) st |= 4;
     if (J.events_per_kmer > 5.0) st |= 8;
-    P.status[job] = st;
-    P.n_out[job] = st ? 0 : n;
+    if (lane == 0) {
+        P.status[job] = st;
+        P.n_out[job] = st ? 0 : n;
+    }
 }
 
 // k-mer ids of every position as build_kmer_list (impl/eventAligner.c:772-790) lists them (for RNA, U reads as T and
