@@ -201,3 +201,29 @@ def test_device_rounds_every_posterior_as_percent_f_does():
     assert np.array_equal(dev[~tie], ((k + up)[~tie]) / 1e6)
     host_ties = np.array([L.sa_mea_printed_posterior(int(v)) for v in prob[tie][:: 13]])
     assert np.array_equal(dev[tie][:: 13], host_ties)
+
+
+def test_chained_over_several_storage_passes_and_result_groups(oracle, monkeypatch):
+    """The chained form finds each read's pairs where the result pipeline left them: several passes over the forward
+    storage, several result groups per pass, a read without any pair in the middle."""
+    pm = sa.Model.load(cases.MODEL_6MER)
+    p = sa.default_params()
+    reads = cases.synthetic_jobs(cases.MODEL_6MER, 7, 900, 4100)
+    reads.insert(3, dict(ref="ACGTACGT", events=np.zeros(0), ax=[], ay=[]))
+    plain = sa.Batch(pm, p, reads)
+    plain.run()
+    want = plain.mea()
+    plain.close()
+    assert want[3][2] == 1 and len(want[3][0]) == 0          # SA_MEA_EMPTY for the read without pairs
+    for env in ({"SA_F_BUDGET_CELLPATHS": "200000"}, {"SA_GROUPS": "3"}, {"SA_GROUPS": "2", "SA_F_BUDGET_CELLPATHS": "200000"}):
+        monkeypatch.delenv("SA_F_BUDGET_CELLPATHS", raising=False)
+        monkeypatch.delenv("SA_GROUPS", raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        b = sa.Batch(pm, p, reads)
+        for _ in range(2):                                   # the second run takes the overlapped-copy path
+            b.run()
+            got = b.mea()
+            for (gp, gs, gst), (wp, ws, wst) in zip(got, want):
+                assert gst == wst and gs == ws and np.array_equal(gp, wp), env
+        b.close()
