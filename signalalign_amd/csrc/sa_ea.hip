@@ -496,10 +496,7 @@ extern "C" int sa_event_align_batch(const sa_model_t *m, const sa_ea_job_t *jobs
         J.kc_off = (long long) (kc_n / 3);
         J.n_events = (int) jb->n_events;
         J.n_kmers = (int) n_kmers;
-        memcpy(ev + ev_n, jb->event_mean, sizeof(double) * (size_t) jb->n_events);
         ev_n += (size_t) jb->n_events;
-        int rck = ea_kmer_ids(m, jb->sequence, n_kmers, (flags & SA_FLAG_RNA) != 0, ids + kc_n / 3);
-        if (rck) return rck;
         kc_n += 3 * (size_t) n_kmers;
         const long long n_bands = (long long) (jb->n_events + 1) + (n_kmers + 1);
         J.trace_off = trace_tot; trace_tot += n_bands * EA_BW;
@@ -516,6 +513,17 @@ extern "C" int sa_event_align_batch(const sa_model_t *m, const sa_ea_job_t *jobs
         J.scale = jb->scale; J.shift = jb->shift; J.var = jb->var;
         all_unit_var = all_unit_var && jb->var == 1.0;
         J.lvar = log((1 / jb->var));
+    }
+    {   // the upload image, one read per task: event means copied, k-mer ids rolled
+        std::atomic<int> bad(SA_OK);
+        sa_parallel_for((size_t) n_jobs, [&](size_t j) {
+            const sa_ea_job_t *jb = &jobs[j];
+            const EaJob &J = hj[j];
+            memcpy(ev + J.ev_off, jb->event_mean, sizeof(double) * (size_t) jb->n_events);
+            const int rck = ea_kmer_ids(m, jb->sequence, J.n_kmers, (flags & SA_FLAG_RNA) != 0, ids + J.kc_off);
+            if (rck) bad = rck;
+        });
+        if (bad != SA_OK) return bad;
     }
     EaPlan P;
     memset(&P, 0, sizeof(P));
@@ -562,17 +570,21 @@ extern "C" int sa_event_align_batch(const sa_model_t *m, const sa_ea_job_t *jobs
     h_st = h_n + nj; h_fills = h_st + nj;
     if (cells_out)
         for (int64_t j = 0; j < n_jobs; j++) cells_out[j] = (double) h_fills[(size_t) j];
-    for (int64_t j = 0; j < n_jobs; j++) {
-        const int n = h_n[(size_t) j];
-        if (status_out) status_out[j] = h_st[(size_t) j];
-        n_pairs_out[j] = n;
-        pairs_out[j] = (sa_ea_pair_t *) malloc(sizeof(sa_ea_pair_t) * (size_t) (n > 0 ? n : 1));
-        if (!pairs_out[j]) { rc = SA_ENOMEM; goto done; }
-        const int *src = h_out + 2 * hj[(size_t) j].out_off;
-        for (int i = 0; i < n; i++) {  // stList_reverse: ascending order
-            pairs_out[j][i].kmer_idx = src[2 * (n - 1 - i)];
-            pairs_out[j][i].event_idx = src[2 * (n - 1 - i) + 1];
-        }
+    {
+        std::atomic<bool> oom(false);
+        sa_parallel_for(nj, [&](size_t j) {
+            const int n = h_n[j];
+            if (status_out) status_out[j] = h_st[j];
+            n_pairs_out[j] = n;
+            pairs_out[j] = (sa_ea_pair_t *) malloc(sizeof(sa_ea_pair_t) * (size_t) (n > 0 ? n : 1));
+            if (!pairs_out[j]) { oom = true; return; }
+            const int *src = h_out + 2 * hj[j].out_off;
+            for (int i = 0; i < n; i++) {  // stList_reverse: ascending order
+                pairs_out[j][i].kmer_idx = src[2 * (n - 1 - i)];
+                pairs_out[j][i].event_idx = src[2 * (n - 1 - i) + 1];
+            }
+        });
+        if (oom) rc = SA_ENOMEM;
     }
 done:
     if (rc != SA_OK)

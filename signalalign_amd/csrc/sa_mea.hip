@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <vector>
@@ -51,6 +52,7 @@ struct MeaPlan {
     double *sum;
     struct MeaEdge *gf;          // global fronts (k_mea<true>)
     const int *n_dev;            // entries per read when the matrices were built on the device (sa_batch_mea), else NULL
+    const int *mins;             // sa_batch_mea: (x, y) origin of each read's matrix, added back to the path; else NULL
 };
 struct __attribute__((aligned(16))) MeaEdge {   // one front entry, read and written as a single 16-byte word
     double sum;
@@ -106,7 +108,7 @@ __device__ __forceinline__ void mea_first_event(const int *__restrict__ rows, co
 // are short, so a block serves many steps), the walk inside a block is v_readlane.  Returns the path length, or -1 if
 // the arena is inconsistent (cannot happen: back pointers fall strictly, a path holds one pair per event at most).
 __device__ __forceinline__ int mea_traceback(const int *a_ref, const int *a_ev, const int *a_prev, int best_id, int2 *out,
-                                             int out_cap, int lane) {
+                                             int out_cap, int lane, int x0, int y0) {
     __threadfence();
     int q = best_id, w = out_cap, n_path = 0;
     while (q >= 0) {
@@ -121,7 +123,7 @@ __device__ __forceinline__ int mea_traceback(const int *a_ref, const int *a_ev, 
             if (w <= 0 || nq >= q) return -1;
             q = nq;
             w--;
-            if (lane == 0) out[w] = make_int2(r_, e_);
+            if (lane == 0) out[w] = make_int2(r_ + x0, e_ + y0);
             n_path++;
         }
     }
@@ -334,7 +336,8 @@ __global__ __launch_bounds__(64) void k_mea_wave(MeaPlan P, int n_jobs) {
         const unsigned long long at = __builtin_amdgcn_ballot_w64(fsum == highest) & lanes_below(nF);
         const int best_id = rl(fid, __builtin_ctzll(at));
         best_sum = highest;
-        n_path = mea_traceback(a_ref, a_ev, a_prev, best_id, P.out + J.out_off, J.out_cap, lane);
+        n_path = mea_traceback(a_ref, a_ev, a_prev, best_id, P.out + J.out_off, J.out_cap, lane, P.mins ? P.mins[2 * jb] : 0,
+                               P.mins ? P.mins[2 * jb + 1] : 0);
         if (n_path < 0) { n_path = 0; status = SA_MEA_NO_PATH; }
     }
 done:
@@ -546,7 +549,8 @@ __global__ __launch_bounds__(64) void k_mea(MeaPlan P, const int *__restrict__ i
         }
         if (best_id < 0) { status = SA_MEA_NO_PATH; goto done; }
         best_sum = highest;
-        n_path = mea_traceback(a_ref, a_ev, a_prev, best_id, P.out + J.out_off, J.out_cap, lane);
+        n_path = mea_traceback(a_ref, a_ev, a_prev, best_id, P.out + J.out_off, J.out_cap, lane, P.mins ? P.mins[2 * jb] : 0,
+                               P.mins ? P.mins[2 * jb + 1] : 0);
         if (n_path < 0) { n_path = 0; status = SA_MEA_NO_PATH; }
     }
 done:
@@ -692,18 +696,16 @@ extern "C" int sa_mea_batch(const sa_mea_job_t *jobs, int64_t n_jobs, int device
     if ((rc = W.pin(&W.h_in, &W.h_in_cap, in_bytes ? in_bytes : 8, device)) != SA_OK) return rc;
     {
         char *h = (char *) W.h_in;
-        size_t a = 0, s = 0;
-        for (size_t j = 0; j < nj; j++) {
+        sa_parallel_for(nj, [&](size_t j) {
             const sa_mea_job_t *jb = &jobs[j];
-            const size_t n = (size_t) jb->n, ns = (size_t) jb->n_events;
+            const size_t n = (size_t) jb->n, ns = (size_t) jb->n_events, a = (size_t) hj[j].off, s = (size_t) hj[j].sh_off;
             if (n) {
                 memcpy(h + 8 * a, jb->posterior, 8 * n);
                 memcpy(h + o_h_rows + 4 * a, jb->event_idx, 4 * n);
                 memcpy(h + o_h_cols + 4 * a, jb->ref_idx, 4 * n);
             }
             if (ns) memcpy(h + o_h_sh + 4 * s, jb->shortest_ref_per_event, 4 * ns);
-            a += n; s += ns;
-        }
+        });
     }
     if ((rc = W.dev(&W.d_ws, &W.d_ws_cap, dev_bytes, device)) != SA_OK) goto done;
     if ((rc = W.pin(&W.h_res, &W.h_res_cap, res_bytes, device)) != SA_OK) goto done;
@@ -731,16 +733,18 @@ extern "C" int sa_mea_batch(const sa_mea_job_t *jobs, int64_t n_jobs, int device
         const int2 *h_out = (const int2 *) hr;
         const double *h_sum = (const double *) (hr + (o_sum - o_out));
         const int *h_n = (const int *) (hr + (o_res - o_out)), *h_edges = h_n + nj, *h_status = h_edges + nj;
-        for (size_t j = 0; j < nj; j++) {
+        std::atomic<bool> oom(false);
+        sa_parallel_for(nj, [&](size_t j) {
             const int n = h_n[j];
             if (status_out) status_out[j] = h_status[j];
             if (sum_out) sum_out[j] = h_sum[j];
             if (n_edges_out) n_edges_out[j] = h_edges[j];
             n_path_out[j] = n;
             path_out[j] = (sa_mea_pair_t *) malloc(sizeof(sa_mea_pair_t) * (size_t) (n > 0 ? n : 1));
-            if (!path_out[j]) { rc = SA_ENOMEM; goto done; }
+            if (!path_out[j]) { oom = true; return; }
             if (n > 0) memcpy(path_out[j], h_out + hj[j].out_off + hj[j].out_cap - n, sizeof(sa_mea_pair_t) * (size_t) n);
-        }
+        });
+        if (oom) rc = SA_ENOMEM;
     }
 done:
     if (rc != SA_OK)
@@ -979,6 +983,9 @@ extern "C" int sa_batch_mea(sa_batch_t *b, unsigned flags, sa_mea_pair_t **path_
                             int32_t *status_out, double *kernel_ms_out) {
     (void) flags;
     if (!b || !path_out || !n_path_out) return SA_EINVAL;
+    const bool trace = getenv("SA_TRACE") != nullptr;
+    auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double t0 = now_ms();
     const sa_pair_t *d_pairs = nullptr;
     std::vector<long long> first, count, n_events;
     int device = 0;
@@ -1005,6 +1012,7 @@ extern "C" int sa_batch_mea(sa_batch_t *b, unsigned flags, sa_mea_pair_t **path_
         hc[j].pair_off = first[j]; hc[j].n_raw = (int) count[j]; hc[j].n_events = (int) n_events[j];
         n_tot += (size_t) count[j]; sh_tot += (size_t) n_events[j] + 1; out_tot += (size_t) J.out_cap;
     }
+    if (trace) fprintf(stderr, "[trace] mea: view+layout %.3f ms\n", now_ms() - t0);
     MeaChainWorkspace &W = g_mea_chain_ws;
     std::lock_guard<std::mutex> guard(W.mu);
     // device: [jobs | chain | data f64 | rows | cols | shortest | arena ref, ev, prev | out | sum | n_out, n_edges, status | mins | ids]
@@ -1037,6 +1045,7 @@ extern "C" int sa_batch_mea(sa_batch_t *b, unsigned flags, sa_mea_pair_t **path_
         P.sum = (double *) (d + o_sum);
         P.n_out = (int *) (d + o_res); P.n_edges = P.n_out + nj; P.status = P.n_edges + nj;
         P.n_dev = (const int *) (d + o_ndev);
+        P.mins = (const int *) (d + o_mins);
         MEACHK(hipEventRecord(W.e0, 0));
         hipLaunchKernelGGL(k_mea_from_pairs, dim3((unsigned) nj), dim3(64), 0, 0, d_pairs, (const MeaChain *) (d + o_chain), P,
                            (int *) (a + a_fill), (int *) (a + a_sref), (int *) (a + a_sprob), (int *) (d + o_ndev),
@@ -1045,10 +1054,13 @@ extern "C" int sa_batch_mea(sa_batch_t *b, unsigned flags, sa_mea_pair_t **path_
         MEACHK(hipGetLastError());
         MEACHK(hipStreamSynchronize(0));
         MEACHK(hipEventElapsedTime(&kms0, W.e0, W.e1));
+        if (trace) fprintf(stderr, "[trace] mea: matrices built at %.3f ms\n", now_ms() - t0);
         if ((rc = mea_run_tiers(W, P, hj, d, o_jobs, o_ids, (int *) ((char *) W.h_res + (o_res - o_out)) + 2 * nj, device, &kms)) != SA_OK)
             goto done;
+        if (trace) fprintf(stderr, "[trace] mea: paths done at %.3f ms\n", now_ms() - t0);
         MEACHK(hipMemcpyAsync(W.h_res, d + o_out, res_bytes, hipMemcpyDeviceToHost, 0));
         MEACHK(hipStreamSynchronize(0));
+        if (trace) fprintf(stderr, "[trace] mea: %zu bytes on the host at %.3f ms\n", res_bytes, now_ms() - t0);
     }
     if (kernel_ms_out) *kernel_ms_out = (double) kms + (double) kms0;
     {
@@ -1056,23 +1068,21 @@ extern "C" int sa_batch_mea(sa_batch_t *b, unsigned flags, sa_mea_pair_t **path_
         const int2 *h_out = (const int2 *) hr;
         const double *h_sum = (const double *) (hr + (o_sum - o_out));
         const int *h_n = (const int *) (hr + (o_res - o_out)), *h_status = h_n + 2 * nj;
-        const int *h_mins = (const int *) (hr + (o_mins - o_out));
-        for (size_t j = 0; j < nj; j++) {
+        std::atomic<bool> oom(false);
+        sa_parallel_for(nj, [&](size_t j) {
             const int n = h_n[j];
             if (status_out) status_out[j] = h_status[j];
             if (sum_out) sum_out[j] = h_sum[j];
             n_path_out[j] = n;
             path_out[j] = (sa_mea_pair_t *) malloc(sizeof(sa_mea_pair_t) * (size_t) (n > 0 ? n : 1));
-            if (!path_out[j]) { rc = SA_ENOMEM; goto done; }
-            const int2 *src = h_out + hj[j].out_off + hj[j].out_cap - n;
-            const int x0 = h_mins[2 * j], y0 = h_mins[2 * j + 1];
-            for (int i = 0; i < n; i++) {   // back to the batch's own coordinates
-                path_out[j][i].ref_idx = src[i].x + x0;
-                path_out[j][i].event_idx = src[i].y + y0;
-            }
-        }
+            if (!path_out[j]) { oom = true; return; }
+            // already in the batch's own coordinates: the traceback added the matrix origin back
+            if (n > 0) memcpy(path_out[j], h_out + hj[j].out_off + hj[j].out_cap - n, sizeof(sa_mea_pair_t) * (size_t) n);
+        });
+        if (oom) rc = SA_ENOMEM;
     }
 done:
+    if (trace) fprintf(stderr, "[trace] mea: outputs built at %.3f ms\n", now_ms() - t0);
     if (rc != SA_OK)
         for (size_t j = 0; j < nj; j++) { free(path_out[j]); path_out[j] = nullptr; n_path_out[j] = 0; }
     return rc;

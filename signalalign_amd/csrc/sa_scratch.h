@@ -6,7 +6,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <cstdlib>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "sa_internal.h"
@@ -66,6 +69,34 @@ struct SaScratch {
 // of pairs, number of events)
 int sa_batch_device_view(sa_batch_t *b, const sa_pair_t **pairs, std::vector<long long> *first, std::vector<long long> *count,
                          std::vector<long long> *n_events, int *device);
+
+// Host-side fan-out for per-read output building (fresh malloc'ed buffers are first-touch page faults: 60-100 MB of
+// them per call are 5-10 ms on one thread).  fn(j) for j in [0, n), work handed out in blocks; SA_HOST_THREADS overrides
+// the thread count (default: hardware threads, at most 16).
+template <class F>
+static inline void sa_parallel_for(size_t n, F fn) {
+    unsigned want = std::thread::hardware_concurrency();
+    if (const char *e = getenv("SA_HOST_THREADS")) want = (unsigned) atoi(e);
+    want = want < 1 ? 1 : (want > 16 ? 16 : want);
+    const size_t block = 16;
+    if (want == 1 || n <= block) {
+        for (size_t j = 0; j < n; j++) fn(j);
+        return;
+    }
+    std::atomic<size_t> next(0);
+    auto work = [&]() {
+        for (;;) {
+            const size_t a = next.fetch_add(block);
+            if (a >= n) return;
+            const size_t b = a + block < n ? a + block : n;
+            for (size_t j = a; j < b; j++) fn(j);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < want; t++) pool.emplace_back(work);
+    work();
+    for (std::thread &t : pool) t.join();
+}
 
 static inline size_t sa_up256(size_t x) { return (x + 255) & ~(size_t) 255; }
 
