@@ -227,3 +227,33 @@ def test_chained_over_several_storage_passes_and_result_groups(oracle, monkeypat
             for (gp, gs, gst), (wp, ws, wst) in zip(got, want):
                 assert gst == wst and gs == ws and np.array_equal(gp, wp), env
         b.close()
+
+
+@pytest.mark.parametrize("tier", [0, 1, 2])
+def test_ties_everywhere(oracle, monkeypatch, tier):
+    """Posteriors quantised to eighths: equal sums and equal posteriors are the rule, so every strict / non-strict
+    comparison of the reference decides something (first event kept while not falling, 'raises the maximum' strictly,
+    first best edge wins).  The register tier's ballots rely on sums never falling along a front; ties are where that
+    would show."""
+    monkeypatch.setenv("SA_MEA_TIER", str(tier))
+    rng = np.random.default_rng(99)
+    jobs = []
+    for it in range(400):
+        n_ev, n_ref = rng.integers(3, 40, 2)
+        m = rng.integers(0, 9, (int(n_ev), int(n_ref))) / 8.0
+        m[rng.random(m.shape) < 0.6] = 0.0
+        rows = np.nonzero(m.sum(axis=1))[0]
+        if len(rows) < 2:
+            continue
+        # shortest_ref_per_event as the reference derives it: lowest column of this and all later events
+        shortest = np.full(int(n_ev), np.inf)
+        low = np.inf
+        for e in range(int(n_ev) - 1, -1, -1):
+            nz = np.nonzero(m[e])[0]
+            if len(nz):
+                low = min(low, nz[0])
+                shortest[e] = low
+        jobs.append(_job(m, shortest))
+    got = sa.mea_batch(jobs)
+    _check_against_oracle(oracle, jobs, got)
+    assert sum(1 for g in got if g[2] == 0) > 300
