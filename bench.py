@@ -204,10 +204,17 @@ def main():
     import signalalign_amd as sa
     from signalalign_amd import synth
 
-    if args.workload == "mea":
-        return bench_mea(args)
-    if args.workload == "event_align":
-        return bench_event_align(args)
+    if args.workload in ("mea", "event_align"):
+        # the two "next" rows are single-GPU side benchmarks: under a multi-rank launch only rank 0 runs them
+        if world > 1:
+            dist.barrier()
+            if rank != 0:
+                dist.destroy_process_group()
+                return
+        res = bench_mea(args) if args.workload == "mea" else bench_event_align(args)
+        if world > 1:
+            dist.destroy_process_group()
+        return res
     gold = os.path.join(ROOT, "tests", "golden", "models")
     model_path, nhdp, ambig, read_kw, wl_name = MODEL, None, None, {}, "BASELINE configs[1]: R9.4 6-mer template Gaussian HMM"
     if args.workload == "cpg":
