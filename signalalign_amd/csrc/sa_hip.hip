@@ -194,13 +194,16 @@ __device__ __forceinline__ bool legal_any(const DevModel &m, float inv_pow, floa
 // impl/pairwiseAligner.c:852-858, :1280-1322).  Row layout: [cell-path][3].
 // ---------------------------------------------------------------------------------------------------
 template <bool RELAX>
-__global__ __launch_bounds__(64) void k_fwd_generic(DevPlan P, const int *region_ids, int n, int ring_cap) {
+__global__ __launch_bounds__(128) void k_fwd_generic(DevPlan P, const int *region_ids, int n, int ring_cap) {
     extern __shared__ __attribute__((aligned(32))) double dyn_lds[];
     double *LT = dyn_lds;                          // RELAX only
     double *lring = dyn_lds + LA_TAB_DOUBLES;      // RELAX && ring_cap > 0: rows d, d-1, d-2 as [cell-path][3]
     int w = blockIdx.x;
     if (w >= n) return;
-    const int lane = threadIdx.x;
+    // one lane per cell-path of a diagonal: 64 threads, or 128 (two waves sharing the LDS ring) when some diagonal of the
+    // launch holds more than 64 cell-paths -- ambiguous positions put ~70 on a 51-cell band, and a second pass of one
+    // wave over the last few would double the time of every diagonal
+    const int lane = threadIdx.x, nthr = blockDim.x;
     if (RELAX) {
         la_tab_init(LT, lane);
         __syncthreads();
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(64) void k_fwd_generic(DevPlan P, const int *region
     {   // diagonal 0: startStateProb / raggedStartStateProb (impl/stateMachine.c:1134-1143)
         sa_row_t r0 = rows[0];
         long long x0 = (0 + r0.xmyL) / 2;
-        for (int i = lane; i < r0.width; i += 64) {
+        for (int i = lane; i < r0.width; i += nthr) {
             long long x = x0 + i;
             int np = poff[x + 1] - poff[x];
             double *c = F + 3 * (r0.foff + poff[x] - poff[x0]);
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(64) void k_fwd_generic(DevPlan P, const int *region
         const int g0 = poff[x0];
         const int rowpaths = poff[x0 + rd.width] - g0;
         const bool lds0 = use_ring && rowpaths <= ring_cap;
-        for (int j = lane; j < rowpaths; j += 64) {
+        for (int j = lane; j < rowpaths; j += nthr) {
             const int g = g0 + j;
             const long long x = px[g];
             const int p = g - poff[x];
@@ -333,15 +336,19 @@ __device__ __forceinline__ void expect_flush(const DevPlan &P, long long ck, dou
 // (its "upper"), then from (x+1,y) (its "lower").  Backward rows live in a 3-row ring in memory.
 // ---------------------------------------------------------------------------------------------------
 template <bool EXPECT, bool RELAX>
-__global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_ids, int n, int ring_cap) {
+__global__ __launch_bounds__(128) void k_bwd_generic(DevPlan P, const int *seg_ids, int n, int ring_cap) {
     extern __shared__ __attribute__((aligned(32))) double dyn_lds[];
     double *LT = dyn_lds;                          // RELAX only
     double *lring = dyn_lds + LA_TAB_DOUBLES;      // RELAX && ring_cap > 0: backward rows e, e+1, e+2
     int w = blockIdx.x;
     if (w >= n) return;
-    const int lane = threadIdx.x;
+    // 64 or 128 threads (see k_fwd_generic): the cell-path sweep of a diagonal is shared by all threads; what follows a
+    // diagonal (checkpoint terms, candidates, expectations: per cell, wave-wide scans) is the first wave's alone, while
+    // the second goes on to the barrier of the next diagonal
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+    const bool first_wave = tid < 64;
     if (RELAX) {
-        la_tab_init(LT, lane);
+        la_tab_init(LT, tid);
         __syncthreads();
     }
     const bool use_ring = RELAX && ring_cap > 0;
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_id
         // one lane per cell-path of the diagonal
         const int g0 = poff[x0];
         const int rowpaths = poff[x0 + re.width] - g0;
-        for (int j = lane; j < rowpaths; j += 64) {
+        for (int j = tid; j < rowpaths; j += nthr) {
             const int g = g0 + j;
             const long long x = px[g];
             const int q = g - poff[x];
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_id
             }
         }
         __syncthreads();
-        if (e > from) continue;
+        if (e > from || !first_wave) continue;
         // ---- checkpoint: per-cell terms of diagonalCalculationTotalProbability (impl/pairwiseAligner.c:1335-1353)
         if ((from - e) % SA_CKPT_EVERY == 0) {
             if (EXPECT && e != from) expect_flush(P, S->ck_base + (from - e) / SA_CKPT_EVERY - 1, Mc, acc, lane);
@@ -620,8 +627,8 @@ __global__ __launch_bounds__(64) void k_bwd_generic(DevPlan P, const int *seg_id
         }
         }
     }
-    if (EXPECT && S->n_ck > 0) expect_flush(P, S->ck_base + S->n_ck - 1, Mc, acc, lane);
-    if (lane == 0) P.cand_count[seg] = count < S->cand_cap ? count : S->cand_cap;
+    if (EXPECT && S->n_ck > 0 && first_wave) expect_flush(P, S->ck_base + S->n_ck - 1, Mc, acc, lane);
+    if (tid == 0) P.cand_count[seg] = count < S->cand_cap ? count : S->cand_cap;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -828,6 +835,7 @@ struct sa_batch {
     bool expect;
     bool relax;              // memory-resident kernels in their RELAX flavour
     int ring_cap;            // cell-paths per diagonal of their LDS ring (0: rows stay in global memory)
+    int gen_threads;         // 64, or 128 when a diagonal of a memory-resident region holds more than 64 cell-paths
     double *d_tab6; int *d_hdp_slot; double *d_hdp_y, *d_hdp_slope, *d_hdp_grid, *d_hdp_tab;
     long long *d_prob; int *d_seg_pass; long long *d_seg_off; sa_pair_t *d_out;
     int *d_ids;  // region / segment id lists per launch
@@ -963,6 +971,10 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     b->expect = (flags & SA_FLAG_EXPECT_INTERNAL) != 0;
     b->relax = !(flags & SA_FLAG_EXACT) && !b->expect && m->hdp == nullptr;
     b->ring_cap = 0;
+    b->gen_threads = 64;
+    for (long long r = 0; r < pl->n_regions; r++)
+        if (pl->regions[r].kind == SA_KIND_GENERIC && pl->regions[r].max_rowpaths > 64) b->gen_threads = 128;
+    if (const char *envt = getenv("SA_GENERIC_THREADS")) b->gen_threads = atoi(envt) == 128 ? 128 : 64;  // test hook
     if (b->relax) {
         long long cap = 0;
         for (long long r = 0; r < pl->n_regions; r++)
@@ -1196,12 +1208,12 @@ static int submit_group(sa_batch *b, const DevPlan &P, int g, int which_stream, 
     HIPCHK(hipEventRecord(b->gev[4 * g], st));
     const size_t relax_lds = sizeof(double) * (size_t) (LA_TAB_DOUBLES + 9 * b->ring_cap);
     if (G.ngs && b->expect)
-        hipLaunchKernelGGL((k_bwd_generic<true, false>), dim3(G.ngs), dim3(64), 0, st, P, b->d_ids + G.ids_gs, G.ngs, 0);
+        hipLaunchKernelGGL((k_bwd_generic<true, false>), dim3(G.ngs), dim3(b->gen_threads), 0, st, P, b->d_ids + G.ids_gs, G.ngs, 0);
     else if (G.ngs && b->relax)
-        hipLaunchKernelGGL((k_bwd_generic<false, true>), dim3(G.ngs), dim3(64), relax_lds, st, P, b->d_ids + G.ids_gs, G.ngs,
+        hipLaunchKernelGGL((k_bwd_generic<false, true>), dim3(G.ngs), dim3(b->gen_threads), relax_lds, st, P, b->d_ids + G.ids_gs, G.ngs,
                            b->ring_cap);
     else if (G.ngs)
-        hipLaunchKernelGGL((k_bwd_generic<false, false>), dim3(G.ngs), dim3(64), 0, st, P, b->d_ids + G.ids_gs, G.ngs, 0);
+        hipLaunchKernelGGL((k_bwd_generic<false, false>), dim3(G.ngs), dim3(b->gen_threads), 0, st, P, b->d_ids + G.ids_gs, G.ngs, 0);
     if (G.nfs) launch_bwd_fast(P, b->d_ids + G.ids_fs, G.nfs, st);
     HIPCHK(hipEventRecord(b->gev[4 * g + 1], st));
     if (G.ck1 > G.ck0)
@@ -1232,10 +1244,10 @@ static int enqueue_pass(sa_batch *b, bool finalize, AfterGroup after_group) {
         const sa_launch_chunk &C = b->chunks[c];
         HIPCHK(hipEventRecord(b->cev[2 * c], s0));
         if (C.ngr && b->relax)
-            hipLaunchKernelGGL(k_fwd_generic<true>, dim3(C.ngr), dim3(64), sizeof(double) * (size_t) (LA_TAB_DOUBLES + 9 * b->ring_cap),
+            hipLaunchKernelGGL(k_fwd_generic<true>, dim3(C.ngr), dim3(b->gen_threads), sizeof(double) * (size_t) (LA_TAB_DOUBLES + 9 * b->ring_cap),
                                s0, P, b->d_ids + C.ids_gr, C.ngr, b->ring_cap);
         else if (C.ngr)
-            hipLaunchKernelGGL(k_fwd_generic<false>, dim3(C.ngr), dim3(64), 0, s0, P, b->d_ids + C.ids_gr, C.ngr, 0);
+            hipLaunchKernelGGL(k_fwd_generic<false>, dim3(C.ngr), dim3(b->gen_threads), 0, s0, P, b->d_ids + C.ids_gr, C.ngr, 0);
         if (C.nfr) launch_fwd_fast(P, b->d_ids + C.ids_fr, C.nfr, s0);
         HIPCHK(hipEventRecord(b->cev[2 * c + 1], s0));
         if (C.g1 - C.g0 > 1) HIPCHK(hipStreamWaitEvent(s1, b->cev[2 * c + 1], 0));
