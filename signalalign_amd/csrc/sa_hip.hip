@@ -189,6 +189,72 @@ __device__ __forceinline__ bool legal_any(const DevModel &m, float inv_pow, floa
     return from - fq * (int) m.pow_km1 == div_small(to, m.n_alpha, inv_alpha);
 }
 
+// One cell-path of forward diagonal d.  P1 / P2 are rows d-1 / d-2; the function is instantiated twice so that, when both
+// rows sit in the LDS ring (the rule), the compiler sees shared-memory pointers and emits ds_read: a pointer that may
+// be either LDS or global is a FLAT access, and flat loads wait on the vector-memory counter as well, i.e. on the
+// stores of the previous diagonal to the forward storage.
+template <bool RELAX>
+__device__ __forceinline__ void fwd_generic_cellpath(const DevModel &m, const ReadPar &rp, const double *LT, float inv_pow,
+                                                     float inv_alpha, const sa_row_t &rd, const sa_row_t &r1, const sa_row_t &r2,
+                                                     long long d, long long x01, long long x02, const int *poff, const int *pid,
+                                                     const int *px, const double *ev, const double4 *xc4, const double *P1,
+                                                     const double *P2, double *F, double *L0, int g0, int j, bool lds0) {
+    const int g = g0 + j;
+    const long long x = px[g];
+    const int p = g - poff[x];
+    const long long xmy = 2 * x - d, y = d - x;
+    double e = y >= 1 ? ev[y - 1] : NEG_INF;
+    const int id = pid[g];
+    double *cur = F + 3 * (rd.foff + j);
+    double *lcur = L0 + 3 * j;
+    long long i_lo = xmy - 1 - r1.xmyL, i_up = xmy + 1 - r1.xmyL, i_mid = xmy - r2.xmyL;
+    bool has_lo = x >= 1 && i_lo >= 0 && (i_lo >> 1) < r1.width;
+    bool has_up = i_up >= 0 && (i_up >> 1) < r1.width;
+    bool has_mid = d >= 2 && x >= 1 && i_mid >= 0 && (i_mid >> 1) < r2.width;
+    const double *lo = has_lo ? P1 + 3 * (poff[x - 1] - poff[x01]) : nullptr;
+    const double *up = has_up ? P1 + 3 * (poff[x] - poff[x01]) : nullptr;
+    const double *mid = has_mid ? P2 + 3 * (poff[x - 1] - poff[x02]) : nullptr;
+    int nq = x >= 1 ? poff[x] - poff[x - 1] : 0;
+    const int *idq = x >= 1 ? pid + poff[x - 1] : nullptr;
+    {
+        double sm = NEG_INF, sx = NEG_INF, sy = NEG_INF;
+        double eM, eY;  // match / gapY emission of this cell-path
+        if (RELAX) {
+            emit_gauss(xc4[g], e, eM, eY);
+        } else {
+            eM = has_mid ? emit_ref(m, rp, id, e, 1) : NEG_INF;
+            eY = has_up ? emit_ref(m, rp, id, e, 0) : NEG_INF;
+        }
+        if (has_lo) {
+            double eP = (m.hdp || id >= 0) ? SA_LOG_GAPX : NEG_INF;
+            for (int q = 0; q < nq; q++)
+                if (legal_any<RELAX>(m, inv_pow, inv_alpha, idq[q], id)) {
+                    sx = la_any<RELAX>(LT, sx, lo[3 * q + 0] + (eP + m.t_mx));
+                    sx = la_any<RELAX>(LT, sx, lo[3 * q + 1] + (eP + m.t_xx));
+                }
+        }
+        if (has_mid) {
+            double eP = eM;
+            for (int q = 0; q < nq; q++)
+                if (legal_any<RELAX>(m, inv_pow, inv_alpha, idq[q], id)) {
+                    sm = la_any<RELAX>(LT, sm, mid[3 * q + 0] + (eP + m.t_mm));
+                    sm = la_any<RELAX>(LT, sm, mid[3 * q + 1] + (eP + m.t_xm));
+                    sm = la_any<RELAX>(LT, sm, mid[3 * q + 2] + (eP + m.t_ym));
+                }
+        }
+        if (has_up) {
+            double eP = eY;
+            sy = la_any<RELAX>(LT, sy, up[3 * p + 0] + (eP + m.t_my));
+            sy = la_any<RELAX>(LT, sy, up[3 * p + 2] + (eP + m.t_yy));
+        }
+        cur[0] = sm;
+        cur[1] = sx;
+        cur[2] = sy;
+        if (lds0) { lcur[0] = sm; lcur[1] = sx; lcur[2] = sy; }
+    }
+
+}
+
 // ---------------------------------------------------------------------------------------------------
 // generic forward: cellCalculate with doTransitionForward (impl/stateMachine.c:1306-1437,
 // impl/pairwiseAligner.c:852-858, :1280-1322).  Row layout: [cell-path][3].
@@ -258,60 +324,16 @@ __global__ __launch_bounds__(128) void k_fwd_generic(DevPlan P, const int *regio
         const int g0 = poff[x0];
         const int rowpaths = poff[x0 + rd.width] - g0;
         const bool lds0 = use_ring && rowpaths <= ring_cap;
-        for (int j = lane; j < rowpaths; j += nthr) {
-            const int g = g0 + j;
-            const long long x = px[g];
-            const int p = g - poff[x];
-            const long long xmy = 2 * x - d, y = d - x;
-            double e = y >= 1 ? ev[y - 1] : NEG_INF;
-            const int id = pid[g];
-            double *cur = F + 3 * (rd.foff + j);
-            double *lcur = L0 + 3 * j;
-            long long i_lo = xmy - 1 - r1.xmyL, i_up = xmy + 1 - r1.xmyL, i_mid = xmy - r2.xmyL;
-            bool has_lo = x >= 1 && i_lo >= 0 && (i_lo >> 1) < r1.width;
-            bool has_up = i_up >= 0 && (i_up >> 1) < r1.width;
-            bool has_mid = d >= 2 && x >= 1 && i_mid >= 0 && (i_mid >> 1) < r2.width;
-            const double *lo = has_lo ? P1 + 3 * (poff[x - 1] - poff[x01]) : nullptr;
-            const double *up = has_up ? P1 + 3 * (poff[x] - poff[x01]) : nullptr;
-            const double *mid = has_mid ? P2 + 3 * (poff[x - 1] - poff[x02]) : nullptr;
-            int nq = x >= 1 ? poff[x] - poff[x - 1] : 0;
-            const int *idq = x >= 1 ? pid + poff[x - 1] : nullptr;
-            {
-                double sm = NEG_INF, sx = NEG_INF, sy = NEG_INF;
-                double eM, eY;  // match / gapY emission of this cell-path
-                if (RELAX) {
-                    emit_gauss(xc4[g], e, eM, eY);
-                } else {
-                    eM = has_mid ? emit_ref(m, rp, id, e, 1) : NEG_INF;
-                    eY = has_up ? emit_ref(m, rp, id, e, 0) : NEG_INF;
-                }
-                if (has_lo) {
-                    double eP = (m.hdp || id >= 0) ? SA_LOG_GAPX : NEG_INF;
-                    for (int q = 0; q < nq; q++)
-                        if (legal_any<RELAX>(m, inv_pow, inv_alpha, idq[q], id)) {
-                            sx = la_any<RELAX>(LT, sx, lo[3 * q + 0] + (eP + m.t_mx));
-                            sx = la_any<RELAX>(LT, sx, lo[3 * q + 1] + (eP + m.t_xx));
-                        }
-                }
-                if (has_mid) {
-                    double eP = eM;
-                    for (int q = 0; q < nq; q++)
-                        if (legal_any<RELAX>(m, inv_pow, inv_alpha, idq[q], id)) {
-                            sm = la_any<RELAX>(LT, sm, mid[3 * q + 0] + (eP + m.t_mm));
-                            sm = la_any<RELAX>(LT, sm, mid[3 * q + 1] + (eP + m.t_xm));
-                            sm = la_any<RELAX>(LT, sm, mid[3 * q + 2] + (eP + m.t_ym));
-                        }
-                }
-                if (has_up) {
-                    double eP = eY;
-                    sy = la_any<RELAX>(LT, sy, up[3 * p + 0] + (eP + m.t_my));
-                    sy = la_any<RELAX>(LT, sy, up[3 * p + 2] + (eP + m.t_yy));
-                }
-                cur[0] = sm;
-                cur[1] = sx;
-                cur[2] = sy;
-                if (lds0) { lcur[0] = sm; lcur[1] = sx; lcur[2] = sy; }
-            }
+        if (lds1 && (lds2 || d < 2)) {   // both previous rows in the ring: shared-memory accesses
+            const double *Q1 = lring + ((d - 1) % 3) * (long long) ring_cap * 3;
+            const double *Q2 = lring + ((d + 1) % 3) * (long long) ring_cap * 3;
+            for (int j = lane; j < rowpaths; j += nthr)
+                fwd_generic_cellpath<RELAX>(m, rp, LT, inv_pow, inv_alpha, rd, r1, r2, d, x01, x02, poff, pid, px, ev, xc4, Q1, Q2, F,
+                                            L0, g0, j, lds0);
+        } else {
+            for (int j = lane; j < rowpaths; j += nthr)
+                fwd_generic_cellpath<RELAX>(m, rp, LT, inv_pow, inv_alpha, rd, r1, r2, d, x01, x02, poff, pid, px, ev, xc4, P1, P2, F,
+                                            L0, g0, j, lds0);
         }
         __syncthreads();
     }
