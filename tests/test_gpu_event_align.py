@@ -95,3 +95,25 @@ def test_rna_kmer_list(oracle):
     om.set_read_params(sc, sh, 1.0)
     ek, ee, est = oracle.event_align(om, ev, ids)
     assert got[2] == est == 0 and np.array_equal(got[0], ek) and np.array_equal(got[1], ee)
+
+
+def test_non_unit_variance_and_a_long_read(oracle):
+    """var != 1 takes the kernel instance that keeps the division by var (the reference always passes 1, but the
+    arithmetic is part of the emission); a 12000-event read crosses many refills of the event and k-mer stream buffers
+    and many 64-band traceback blocks."""
+    pm, om, jobs, truth = _jobs(oracle, cases.MODEL_6MER, 3, 2500, first=31)
+    for j, v in zip(jobs, (1.3, 0.8, 1.0)):
+        j["var"] = v
+    long_pm, long_om, long_jobs, _ = _jobs(oracle, cases.MODEL_6MER, 1, 12000, first=5)
+    jobs = jobs + long_jobs
+    got = sa.event_align_batch(pm, jobs)
+    for j, job in enumerate(jobs):
+        om.set_read_params(job["scale"], job["shift"], job["var"])
+        ek, ee, est = oracle.event_align(om, job["event_mean"], oracle.kmer_ids_of(om, job["sequence"]))
+        gk, ge, gst = got[j]
+        assert gst == est, j
+        assert np.array_equal(gk, ek) and np.array_equal(ge, ee), j
+    assert got[3][2] == 0 and len(got[3][0]) > 12000
+    # all-unit batch again right after: the other kernel instance, same workspace
+    again = sa.event_align_batch(pm, long_jobs)
+    assert np.array_equal(again[0][0], got[3][0]) and np.array_equal(again[0][1], got[3][1])
