@@ -59,7 +59,10 @@ static void usage(void) {
     fprintf(stderr, "-D: Posterior probability threshold, keep aligned pairs with posterior prob >= this\n");
     fprintf(stderr, "-m: Constranint trim, how much to trim the guide alignment anchors by\n");
     fprintf(stderr, "-g: traceBackDiagonals, how many backward diagonals to calculate during traceback\n");
-    fprintf(stderr, "-r: boolean option if read is RNA\n\n");
+    fprintf(stderr, "-r: boolean option if read is RNA\n");
+    fprintf(stderr, "--batch <manifest>: align many reads in one process (one GPU batch per strand model)\n");
+    fprintf(stderr, "--device <n>: GPU to use\n");
+    fprintf(stderr, "--mea: also write <posteriors file>.mea, the rows of the full output on the maximum expected accuracy path\n\n");
 }
 
 static double descale(double e, double level, double scale, double shift, double var) {
@@ -259,6 +262,7 @@ static int load_strand_model(strand_model_t *sm, const char *model_path, const c
 /* options shared by every read of a run */
 typedef struct {
     int hdp, two_d, rna, expect_mode;
+    int mea; /* --mea: also write the maximum-expected-accuracy path of every read (not in the reference binary) */
     int64_t out_fmt, constraint_trim;
     const char *fwd_ref, *bwd_ref;
     sa_params_t p;
@@ -535,7 +539,39 @@ typedef struct {
     sa_pair_t ***pairs;   /* [strand][job] */
     int64_t **n_pairs;
     double (*score)[2];
+    sa_mea_pair_t ***mea; /* [strand][job], --mea only */
+    int64_t **n_mea;
 } out_job_t;
+
+/* The rows of the full output that lie on the maximum-expected-accuracy path -- what mea_alignment_from_signal_align
+ * (src/signalalign/mea_algorithm.py:323-341) returns as its final event table, here as a TSV next to the posteriors file.
+ * The path holds one (x, y) per event; where several rows share a cell (ambiguous positions) the row with the lowest
+ * posterior is the one the reference's matrix keeps (get_mea_params_from_events :305-318). */
+static void write_mea(const char *post_path, const out_ctx_t *o, const sa_mea_pair_t *path, int64_t n_path) {
+    char *out_path = malloc(strlen(post_path) + 8);
+    sprintf(out_path, "%s.mea", post_path);
+    int64_t y_max = -1;
+    for (int64_t i = 0; i < n_path; i++) y_max = path[i].event_idx > y_max ? path[i].event_idx : y_max;
+    int64_t *x_of = malloc(sizeof(int64_t) * (size_t) (y_max + 2)), *best = malloc(sizeof(int64_t) * (size_t) (y_max + 2));
+    for (int64_t y = 0; y <= y_max; y++) { x_of[y] = -1; best[y] = -1; }
+    for (int64_t i = 0; i < n_path; i++) x_of[path[i].event_idx] = path[i].ref_idx;
+    for (int64_t i = 0; i < o->n_pairs; i++) {
+        const sa_pair_t *p = &o->pairs[i];
+        if (p->y > y_max || x_of[p->y] != p->x) continue;
+        if (best[p->y] < 0 || p->prob_e7 < o->pairs[best[p->y]].prob_e7) best[p->y] = i;
+    }
+    sa_pair_t *rows = malloc(sizeof(sa_pair_t) * (size_t) (n_path > 0 ? n_path : 1));
+    int64_t n = 0;
+    for (int64_t i = 0; i < o->n_pairs; i++) {   /* output order of the posteriors file */
+        const sa_pair_t *p = &o->pairs[i];
+        if (p->y <= y_max && best[p->y] == i) rows[n++] = *p;
+    }
+    out_ctx_t m = *o;
+    m.pairs = rows;
+    m.n_pairs = n;
+    write_full(out_path, &m);
+    free(rows); free(x_of); free(best); free(out_path);
+}
 
 static void output_one(int64_t j, void *ctx) {
     out_job_t *c = ctx;
@@ -559,11 +595,13 @@ static void output_one(int64_t j, void *ctx) {
         o.rna = R->rna; o.event_offset = rd->t_lo; o.ref_offset = rd->r_shift_t; o.pairs = c->pairs[0][j];
         o.n_pairs = c->n_pairs[0][j]; o.score = c->score[j][0];
         output_alignment(R->out_fmt, rd->post_path, rd->post_path2, &o);
+        if (R->mea) write_mea(rd->post_path, &o, c->mea[0][j], c->n_mea[0][j]);
         if (R->two_d) {
             o.sm = &R->smc; o.npp = rd->np->complement_params; o.events = rd->np->complement_events;
             o.target = rd->complement_target; o.is_template = 0; o.event_offset = rd->c_lo; o.ref_offset = rd->r_shift_c;
             o.pairs = c->pairs[1][j]; o.n_pairs = c->n_pairs[1][j]; o.score = c->score[j][1];
             output_alignment(R->out_fmt, rd->post_path, rd->post_path2, &o);
+            if (R->mea) write_mea(rd->post_path, &o, c->mea[1][j], c->n_mea[1][j]);
         }
     }
 }
@@ -621,6 +659,7 @@ int main(int argc, char **argv) {
                                            {"ambig_model", optional_argument, 0, 'a'},
                                            {"batch", required_argument, 0, 1000},
                                            {"device", required_argument, 0, 1001},
+                                           {"mea", no_argument, 0, 1002},
                                            {0, 0, 0, 0}};
     for (;;) {
         int idx = 0;
@@ -653,6 +692,7 @@ int main(int argc, char **argv) {
             case 'i': post_path2 = optarg ? strdup(optarg) : NULL; break;
             case 1000: manifest = strdup(optarg); break;
             case 1001: device = atoi(optarg); break;
+            case 1002: R.mea = 1; break;
             default: usage(); return 1;
         }
     }
@@ -784,13 +824,33 @@ int main(int argc, char **argv) {
     int64_t *n_pairs_s[2] = {NULL, NULL};
     sa_pair_t ***pairs = pairs_s;
     int64_t **n_pairs = n_pairs_s;
+    sa_mea_pair_t **mea_s[2] = {NULL, NULL};
+    int64_t *n_mea_s[2] = {NULL, NULL};
+    sa_mea_pair_t ***mea = mea_s;
+    int64_t **n_mea = n_mea_s;
     for (int s = 0; s < n_strands; s++) {
         pairs[s] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(sa_pair_t *));
         n_pairs[s] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(int64_t));
         if (n_ok == 0) continue;
         fprintf(stderr, s == 0 ? "signalAlign - starting template alignment\n" : "signalAlign - starting complement alignment\n");
         for (int64_t j = 0; j < n_ok; j++) bj[j] = reads[who[j]].jobs[s];
-        int rc = sa_align_batch(sms[s]->model, &R.p, bj, n_ok, R.ambig, device, 0, pairs[s], n_pairs[s]);
+        int rc;
+        if (!R.mea) {
+            rc = sa_align_batch(sms[s]->model, &R.p, bj, n_ok, R.ambig, device, 0, pairs[s], n_pairs[s]);
+        } else { /* the same batch, kept alive for the path step: its pairs are still on the device */
+            sa_batch_t *b = NULL;
+            mea[s] = calloc((size_t) n_ok, sizeof(sa_mea_pair_t *));
+            n_mea[s] = calloc((size_t) n_ok, sizeof(int64_t));
+            rc = sa_batch_create(&b, sms[s]->model, &R.p, bj, n_ok, R.ambig, device, 0);
+            if (rc == SA_OK) rc = sa_batch_run(b);
+            for (int64_t j = 0; j < n_ok && rc == SA_OK; j++) {
+                sa_batch_n_pairs(b, j, &n_pairs[s][j]);
+                pairs[s][j] = malloc(sizeof(sa_pair_t) * (size_t) (n_pairs[s][j] > 0 ? n_pairs[s][j] : 1));
+                rc = sa_batch_pairs(b, j, pairs[s][j], n_pairs[s][j]);
+            }
+            if (rc == SA_OK) rc = sa_batch_mea(b, 0, mea[s], n_mea[s], NULL, NULL, NULL);
+            sa_batch_destroy(b);
+        }
         if (rc != SA_OK) {
             fprintf(stderr, "signalMachine: alignment failed: %s\n", sa_strerror(rc));
             return 1;
@@ -800,7 +860,7 @@ int main(int argc, char **argv) {
     /* ---- outputs: rendered in parallel (one file per read), summary lines in read order ---- */
     double (*score)[2] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(*score));
     {
-        out_job_t oc = {&R, reads, who, pairs, n_pairs, score};
+        out_job_t oc = {&R, reads, who, pairs, n_pairs, score, mea, n_mea};
         if (outputs_distinct(reads, who, n_ok)) parallel_for(n_ok, output_one, &oc);
         else for (int64_t j = 0; j < n_ok; j++) output_one(j, &oc);
     }
@@ -811,7 +871,10 @@ int main(int argc, char **argv) {
         if (R.two_d) fprintf(stdout, "%" PRId64 "(%f)\n", n_pairs[1][j], score[j][1]);
         else fprintf(stdout, "\n");
         fprintf(stderr, "signalAlign - SUCCESS: finished alignment of query %s, exiting\n", rd->label);
-        for (int s = 0; s < n_strands; s++) sa_free(pairs[s][j]);
+        for (int s = 0; s < n_strands; s++) {
+            sa_free(pairs[s][j]);
+            if (R.mea) sa_free(mea[s][j]);
+        }
     }
     int64_t n_failed = 0;
     for (int64_t i = 0; i < n_reads; i++) n_failed += reads[i].failed ? 1 : 0;

@@ -408,3 +408,58 @@ def test_signalmachine_hdp_model(oracle, tmp_path):
             assert abs(pv - 0.05) <= 2e-5, key  # only pairs sitting on the threshold may differ
             lonely += 1
     assert lonely <= 2
+
+
+@pytest.mark.parametrize("minus", [False, True])
+def test_signalmachine_mea_output(oracle, tmp_path, minus):
+    """--mea writes <posteriors>.mea: the rows of the full TSV on the maximum-expected-accuracy path.  Checked the way
+    the reference would produce it (mea_alignment_from_signal_align, src/signalalign/mea_algorithm.py:323-341): read
+    the TSV the binary just wrote, take its reference_index / event_index / posterior columns, run
+    get_mea_params_from_events + maximum_expected_accuracy_alignment (CPU restatement) and keep those rows -- for a
+    forward and for a reverse-strand read (where the table's reference indices fall along the read and the reference
+    flips them)."""
+    model = cases.MODEL_5MER
+    npread_path = os.path.join(cases.GOLDEN, "npReads", "c2925_ecoli_ch34_read1023.npRead")
+    r = oracle.parse_npread(npread_path)
+    read = r["template_read"]
+    start2, L = 6, len(read) - 14
+    part = read[start2:start2 + L]
+    pre, post = "GATTACA" * 9, "CCGGTTAA" * 6
+    fasta = str(tmp_path / "fwd.fa")
+    cigar = str(tmp_path / "guide.cigar")
+    argv = [BIN, "-T", model, "-q", npread_path, "-n", "chrM", "-p", cigar, "-L", "rm", "-g", "100", "-s", "0", "--mea"]
+    if minus:
+        contig = pre + _revcomp(part) + post
+        bfasta = str(tmp_path / "bwd.fa")
+        _write_fasta(bfasta, "chrM", contig.translate(str.maketrans("ACGT", "TGCA")))
+        with open(cigar, "w") as f:
+            f.write("cigar: rm %d %d + chrM %d %d - 1 M %d\n" % (start2, start2 + L, len(pre) + L, len(pre), L))
+        argv += ["-b", bfasta]
+    else:
+        contig = pre + part + post
+        with open(cigar, "w") as f:
+            f.write("cigar: rm %d %d + chrM %d %d + 1 M %d\n" % (start2, start2 + L, len(pre), len(pre) + L, L))
+    _write_fasta(fasta, "chrM", contig)
+    out = str(tmp_path / "post.tsv")
+    pr = subprocess.run(argv + ["-f", fasta, "-u", out], capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr
+    rows = [l.rstrip("\n").split("\t") for l in open(out)]
+    mea_rows = [l.rstrip("\n").split("\t") for l in open(out + ".mea")]
+    ref_index = np.array([int(g[1]) for g in rows])
+    event_index = np.array([int(g[5]) for g in rows])
+    posterior = np.array([float(g[12]) for g in rows])
+    if minus:
+        assert ref_index[0] > ref_index[-1]                 # the table really runs backwards along the reference
+    ev, rf, po, sh = oracle.mea_params(ref_index, event_index, posterior)
+    st, path, best = oracle.mea(ev, rf, po, sh)
+    assert st == 0 and len(path) > 300
+    # back from matrix indices to the table's own columns
+    e0 = event_index.min()
+    r_of = (lambda c: ref_index.max() - c) if minus else (lambda c: ref_index.min() + c)
+    want = {(r_of(int(c)), int(e) + e0) for c, e in path}
+    got = [(int(g[1]), int(g[5])) for g in mea_rows]
+    assert len(got) == len(set(got)) == len(want) and set(got) == want
+    # and they are rows of the posteriors file, in its order
+    index_of = {tuple(g): i for i, g in enumerate(rows)}
+    where = [index_of[tuple(g)] for g in mea_rows]
+    assert where == sorted(where)
