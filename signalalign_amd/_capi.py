@@ -82,7 +82,8 @@ EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alp
 
 
 def library_path():
-    return os.path.join(_HERE, "lib", "libsignalalign_hip.so")
+    # SA_LIBRARY: load another build of the same ABI (probes/host_asan.sh: the host sources under AddressSanitizer)
+    return os.environ.get("SA_LIBRARY") or os.path.join(_HERE, "lib", "libsignalalign_hip.so")
 
 
 def build(force=False):
@@ -91,7 +92,7 @@ def build(force=False):
     srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
     srcs.append(os.path.join(_HERE, "..", "include", "signalalign_hip.h"))
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
-    if stale:
+    if stale and not os.environ.get("SA_LIBRARY"):
         subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
     return so
 
