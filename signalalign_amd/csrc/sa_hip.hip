@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <time.h>
 #include <vector>
 
@@ -918,11 +919,70 @@ static DevPlan make_devplan(const sa_batch *b) {
     return P;
 }
 
+// Host -> device copies of the plan (several hundred MB per batch) through a persistent ring of pinned buffers: the
+// runtime's own staging of pageable memory moves about 3 GB/s; here the CPU copy into a pinned slot (all host threads)
+// overlaps the DMA of the previous slots.  One ring per process and device, calls serialise on it.
+struct SaUploader {
+    std::mutex mu;
+    int device = -1;
+    static const int SLOTS = 4;
+    static const size_t SLOT_BYTES = (size_t) 16 << 20;
+    void *slot[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t done[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t stream = nullptr;
+    int next = 0;
+    int bind(int dev) {
+        if (device == dev && stream) return SA_OK;
+        // (a process normally drives one GPU; a change of device rebuilds the ring)
+        for (int i = 0; i < SLOTS; i++) {
+            if (slot[i]) (void) hipHostFree(slot[i]);
+            if (done[i]) (void) hipEventDestroy(done[i]);
+            slot[i] = nullptr; done[i] = nullptr;
+        }
+        if (stream) (void) hipStreamDestroy(stream);
+        stream = nullptr;
+        device = dev;
+        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return SA_ENODEVICE;
+        for (int i = 0; i < SLOTS; i++) {
+            if (hipHostMalloc(&slot[i], SLOT_BYTES, hipHostMallocDefault) != hipSuccess) return SA_ENOMEM;
+            if (hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess) return SA_ENODEVICE;
+        }
+        return SA_OK;
+    }
+    int copy(void *dst, const void *src, size_t bytes) {
+        const char *s = (const char *) src;
+        char *d = (char *) dst;
+        while (bytes > 0) {
+            const size_t n = bytes < SLOT_BYTES ? bytes : SLOT_BYTES;
+            const int k = next;
+            next = (next + 1) % SLOTS;
+            HIPCHK(hipEventSynchronize(done[k]));            // the slot's previous DMA has left it
+            char *buf = (char *) slot[k];
+            const size_t piece = (size_t) 1 << 20;
+            sa_parallel_for((n + piece - 1) / piece, [&](size_t q) {
+                const size_t a = q * piece, len = a + piece < n ? piece : n - a;
+                memcpy(buf + a, s + a, len);
+            });
+            HIPCHK(hipMemcpyAsync(d, buf, n, hipMemcpyHostToDevice, stream));
+            HIPCHK(hipEventRecord(done[k], stream));
+            s += n; d += n; bytes -= n;
+        }
+        return SA_OK;
+    }
+    int drain() {
+        HIPCHK(hipStreamSynchronize(stream));
+        return SA_OK;
+    }
+};
+static SaUploader g_uploader;
+
 template <typename T>
-static int upload(T **dst, const T *src, long long n) {
-    size_t bytes = sizeof(T) * (size_t) (n > 0 ? n : 1);
+static int upload(T **dst, const T *src, long long n, long long pad = 0) {
+    // pad: extra zeroed elements behind the data (kernels that clamp an index may read one element past the end)
+    size_t bytes = sizeof(T) * (size_t) (n + pad > 0 ? n + pad : 1);
     HIPCHK(hipMalloc((void **) dst, bytes));
-    if (n > 0) HIPCHK(hipMemcpy(*dst, src, sizeof(T) * (size_t) n, hipMemcpyHostToDevice));
+    if (pad > 0) HIPCHK(hipMemsetAsync((char *) *dst + sizeof(T) * (size_t) n, 0, sizeof(T) * (size_t) pad, g_uploader.stream));
+    if (n > 0) return g_uploader.copy(*dst, src, sizeof(T) * (size_t) n);
     return SA_OK;
 }
 
@@ -1030,28 +1090,36 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     }
     for (int i = 0; i < 8; i++)
         if (hipEventCreate(&b->ev[i]) != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
+    std::unique_lock<std::mutex> up_lock(g_uploader.mu);
+    TRY(g_uploader.bind(device));
+    if (trace_c) fprintf(stderr, "[trace] create: upload ring ready at %.1f ms\n", now_ms_c() - tc0);
     TRY(upload(&b->d_regions, pl->regions, pl->n_regions));
     TRY(upload(&b->d_rows, pl->rows, pl->n_rows));
     TRY(upload(&b->d_pk, pl->pk, pl->n_pk));
     TRY(upload(&b->d_poff, pl->poff, pl->n_poff));
     TRY(upload(&b->d_pid, pl->pid, pl->n_pid));
-    {   // cell-path -> reference position, for the memory-resident kernels (one lane per cell-path)
-        std::vector<int> px((size_t) (pl->n_pid > 0 ? pl->n_pid : 1), 0);
-        for (long long r = 0; r < pl->n_regions; r++) {
-            const sa_region_t *R = &pl->regions[r];
-            if (R->kind != SA_KIND_GENERIC) continue;
-            const int32_t *po = pl->poff + R->poff_off;
-            for (long long x = 0; x <= R->lX; x++)
-                for (int g = po[x]; g < po[x + 1]; g++) px[(size_t) (R->pid_off + g)] = (int) x;
+    std::vector<int> px;   // (alive until the uploader has drained)
+    {   // cell-path -> reference position, for the memory-resident kernels (one lane per cell-path); register-kernel
+        // regions never read it
+        bool any_generic = false;
+        for (long long r = 0; r < pl->n_regions && !any_generic; r++) any_generic = pl->regions[r].kind == SA_KIND_GENERIC;
+        if (any_generic) {
+            px.assign((size_t) (pl->n_pid > 0 ? pl->n_pid : 1), 0);
+            for (long long r = 0; r < pl->n_regions; r++) {
+                const sa_region_t *R = &pl->regions[r];
+                if (R->kind != SA_KIND_GENERIC) continue;
+                const int32_t *po = pl->poff + R->poff_off;
+                for (long long x = 0; x <= R->lX; x++)
+                    for (int g = po[x]; g < po[x + 1]; g++) px[(size_t) (R->pid_off + g)] = (int) x;
+            }
+            TRY(upload(&b->d_px, px.data(), pl->n_pid));
+        } else {
+            TRY(upload(&b->d_px, (const int *) nullptr, 0));
         }
-        TRY(upload(&b->d_px, px.data(), pl->n_pid));
     }
     TRY(upload(&b->d_xc, pl->xc, 4 * pl->n_pid));
-    {   // one readable element of padding: the kernels clamp event indices to 0 even for reads without events
-        std::vector<double> evp((size_t) pl->n_ev + 8, 0.0);
-        if (pl->n_ev) memcpy(evp.data(), pl->ev, sizeof(double) * (size_t) pl->n_ev);
-        TRY(upload(&b->d_ev, evp.data(), (long long) evp.size()));
-    }
+    // readable padding behind the events: the kernels clamp event indices to 0 even for reads without events
+    TRY(upload(&b->d_ev, pl->ev, pl->n_ev, 8));
     TRY(upload(&b->d_segs, pl->segs, pl->n_segs));
     TRY(upload(&b->d_cks, pl->cks, pl->n_cks));
     {   // model tables
@@ -1086,6 +1154,8 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
             TRY(upload(&b->d_hdp_tab, tab.data(), (long long) tab.size()));
         }
     }
+    TRY(g_uploader.drain());
+    up_lock.unlock();
     if (trace_c) fprintf(stderr, "[trace] create: inputs uploaded at %.1f ms\n", now_ms_c() - tc0);
     // working buffers
     auto dalloc = [&](void **p_, long long bytes) -> int {
@@ -1198,7 +1268,12 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
             b->out_alloc = pl->n_cand;
         }
     }
-    TRY(upload(&b->d_ids, b->ids_flat.data(), (long long) b->ids_flat.size()));
+    {   // the launch lists (small)
+        std::lock_guard<std::mutex> g_(g_uploader.mu);
+        TRY(g_uploader.bind(device));
+        TRY(upload(&b->d_ids, b->ids_flat.data(), (long long) b->ids_flat.size()));
+        TRY(g_uploader.drain());
+    }
     if (trace_c) fprintf(stderr, "[trace] create: buffers allocated at %.1f ms\n", now_ms_c() - tc0);
     b->stats.cells_forward = pl->cells_fwd;
     b->stats.cells_backward = pl->cells_bwd;

@@ -23,6 +23,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "sa_internal.h"
@@ -712,18 +713,65 @@ static void *plan_worker(void *arg) {
     return NULL;
 }
 
-#define CAT(dst, field, count, type)                                                                    \
+/* Merge of the per-thread sub-plans into one plan.  The destination arrays are sized from the sub-plans' counts
+ * (ALLOC_CAT), then every thread copies ITS sub-plan to its place and shifts its offsets by what the threads before it
+ * hold (merge_worker): the copy is several hundred MB per batch and runs at memory bandwidth only when it is spread. */
+#define ALLOC_CAT(dst, field, count, type)                                                              \
     do {                                                                                                \
         int64_t tot_ = 0;                                                                               \
         for (int t_ = 0; t_ < T; t_++) tot_ += W[t_].pl->count;                                         \
         dst->field = malloc(sizeof(type) * (size_t) (tot_ > 0 ? tot_ : 1));                             \
-        if (!dst->field) { rc = SA_ENOMEM; break; }                                                     \
-        int64_t o_ = 0;                                                                                 \
-        for (int t_ = 0; t_ < T; t_++) {                                                                \
-            if (W[t_].pl->count) memcpy(dst->field + o_, W[t_].pl->field, sizeof(type) * (size_t) W[t_].pl->count); \
-            o_ += W[t_].pl->count;                                                                      \
-        }                                                                                               \
+        if (!dst->field) rc = SA_ENOMEM;                                                                \
     } while (0)
+#define COPY_CAT(field, count, type)                                                                    \
+    do {                                                                                                \
+        if (s->count) memcpy(pl->field + b->count, s->field, sizeof(type) * (size_t) s->count);         \
+    } while (0)
+
+typedef struct {
+    sa_plan_t *pl;        /* destination */
+    sa_plan_t *s;         /* this thread's sub-plan; freed by the worker once copied (munmap of several hundred MB is
+                           * 80 ms on one thread) */
+    sa_plan_t base;       /* counts held by the threads before it */
+    int64_t job_base;
+} merge_task_t;
+
+static void *merge_worker(void *arg) {
+    merge_task_t *k = arg;
+    sa_plan_t *pl = k->pl;
+    const sa_plan_t *s = k->s;
+    const sa_plan_t *b = &k->base;
+    COPY_CAT(regions, n_regions, sa_region_t);
+    COPY_CAT(rows, n_rows, sa_row_t);
+    COPY_CAT(pk, n_pk, int32_t);
+    COPY_CAT(poff, n_poff, int32_t);
+    COPY_CAT(pid, n_pid, int32_t);
+    COPY_CAT(ev, n_ev, double);
+    COPY_CAT(segs, n_segs, sa_seg_t);
+    COPY_CAT(cks, n_cks, sa_ck_t);
+    if (s->n_jobs) memcpy(pl->jobs + k->job_base, s->jobs, sizeof(sa_jobinfo_t) * (size_t) s->n_jobs);
+    if (s->n_pid) memcpy(pl->xc + 4 * b->n_pid, s->xc, sizeof(double) * 4 * (size_t) s->n_pid); /* four doubles per pid entry */
+    for (int64_t i = 0; i < s->n_jobs; i++) {
+        sa_jobinfo_t *J = &pl->jobs[k->job_base + i];
+        J->region_off += b->n_regions;
+        J->ev_off += b->n_ev;
+    }
+    for (int64_t i = 0; i < s->n_regions; i++) {
+        sa_region_t *R = &pl->regions[b->n_regions + i];
+        R->job += (int32_t) k->job_base;
+        R->row_off += b->n_rows; R->pk_off += b->n_pk; R->poff_off += b->n_poff; R->pid_off += b->n_pid;
+        R->ev_off += b->n_ev; R->seg_off += b->n_segs;
+    }
+    for (int64_t i = 0; i < s->n_segs; i++) {
+        sa_seg_t *S = &pl->segs[b->n_segs + i];
+        S->region += (int32_t) b->n_regions;
+        S->ck_base += b->n_cks; S->cand_off += b->n_cand; S->bscratch_off += b->n_bscratch;
+    }
+    for (int64_t i = 0; i < s->n_cks; i++) pl->cks[b->n_cks + i].voff += b->n_vbuf;
+    sa_plan_free(k->s);
+    k->s = NULL;
+    return NULL;
+}
 
 static __thread int plan_threads_override = 0; /* sa_plan_digest */
 static int plan_threads(int64_t n_jobs) {
@@ -744,6 +792,18 @@ int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, co
     const int T = plan_threads(n_jobs);
     sa_plan_t *pl = NULL;
     int rc = SA_OK;
+    const int trace = getenv("SA_TRACE") != NULL;
+    struct timespec ts0_;
+    clock_gettime(CLOCK_MONOTONIC, &ts0_);
+#define PLAN_TRACE(what)                                                                                   \
+    do {                                                                                                   \
+        if (trace) {                                                                                       \
+            struct timespec t_;                                                                            \
+            clock_gettime(CLOCK_MONOTONIC, &t_);                                                           \
+            fprintf(stderr, "[trace] plan (%d threads): %s at %.1f ms\n", T, what,                         \
+                    (t_.tv_sec - ts0_.tv_sec) * 1e3 + (t_.tv_nsec - ts0_.tv_nsec) * 1e-6);                   \
+        }                                                                                                  \
+    } while (0)
     if (T == 1) {
         pl = plan_new(m, p, flags, n_jobs);
         if (!pl) return SA_ENOMEM;
@@ -778,6 +838,7 @@ int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, co
         }
         for (int t = 0; t < T; t++)
             if (started[t]) pthread_join(th[t], NULL);
+        PLAN_TRACE("sub-plans built");
         for (int t = 0; t < T && rc == SA_OK; t++) rc = W[t].rc; /* the first failing job in job order decides */
         if (rc == SA_OK) {
             pl = plan_new(m, p, flags, n_jobs);
@@ -786,52 +847,31 @@ int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, co
         if (rc == SA_OK) {
             free(pl->jobs);
             pl->jobs = NULL;
-            do {
-                CAT(pl, jobs, n_jobs, sa_jobinfo_t);
-                CAT(pl, regions, n_regions, sa_region_t);
-                CAT(pl, rows, n_rows, sa_row_t);
-                CAT(pl, pk, n_pk, int32_t);
-                CAT(pl, poff, n_poff, int32_t);
-                CAT(pl, pid, n_pid, int32_t);
-                CAT(pl, ev, n_ev, double);
-                CAT(pl, segs, n_segs, sa_seg_t);
-                CAT(pl, cks, n_cks, sa_ck_t);
-                {   /* xc: four doubles per pid entry */
-                    int64_t tot = 0;
-                    for (int t = 0; t < T; t++) tot += W[t].pl->n_pid;
-                    pl->xc = malloc(sizeof(double) * 4 * (size_t) (tot > 0 ? tot : 1));
-                    if (!pl->xc) { rc = SA_ENOMEM; break; }
-                    int64_t o = 0;
-                    for (int t = 0; t < T; t++) {
-                        if (W[t].pl->n_pid) memcpy(pl->xc + 4 * o, W[t].pl->xc, sizeof(double) * 4 * (size_t) W[t].pl->n_pid);
-                        o += W[t].pl->n_pid;
-                    }
-                }
-            } while (0);
+            ALLOC_CAT(pl, jobs, n_jobs, sa_jobinfo_t);
+            ALLOC_CAT(pl, regions, n_regions, sa_region_t);
+            ALLOC_CAT(pl, rows, n_rows, sa_row_t);
+            ALLOC_CAT(pl, pk, n_pk, int32_t);
+            ALLOC_CAT(pl, poff, n_poff, int32_t);
+            ALLOC_CAT(pl, pid, n_pid, int32_t);
+            ALLOC_CAT(pl, ev, n_ev, double);
+            ALLOC_CAT(pl, segs, n_segs, sa_seg_t);
+            ALLOC_CAT(pl, cks, n_cks, sa_ck_t);
+            {
+                int64_t tot = 0;
+                for (int t = 0; t < T; t++) tot += W[t].pl->n_pid;
+                pl->xc = malloc(sizeof(double) * 4 * (size_t) (tot > 0 ? tot : 1));
+                if (!pl->xc) rc = SA_ENOMEM;
+            }
         }
         if (rc == SA_OK) {
+            merge_task_t *M = calloc((size_t) T, sizeof(*M));
+            if (!M) rc = SA_ENOMEM;
             sa_plan_t b; /* running bases */
             memset(&b, 0, sizeof(b));
             int64_t job_base = 0;
-            for (int t = 0; t < T; t++) {
-                const sa_plan_t *s = W[t].pl;
-                for (int64_t i = 0; i < s->n_jobs; i++) {
-                    sa_jobinfo_t *J = &pl->jobs[job_base + i];
-                    J->region_off += b.n_regions;
-                    J->ev_off += b.n_ev;
-                }
-                for (int64_t i = 0; i < s->n_regions; i++) {
-                    sa_region_t *R = &pl->regions[b.n_regions + i];
-                    R->job += (int32_t) job_base;
-                    R->row_off += b.n_rows; R->pk_off += b.n_pk; R->poff_off += b.n_poff; R->pid_off += b.n_pid;
-                    R->ev_off += b.n_ev; R->seg_off += b.n_segs;
-                }
-                for (int64_t i = 0; i < s->n_segs; i++) {
-                    sa_seg_t *S = &pl->segs[b.n_segs + i];
-                    S->region += (int32_t) b.n_regions;
-                    S->ck_base += b.n_cks; S->cand_off += b.n_cand; S->bscratch_off += b.n_bscratch;
-                }
-                for (int64_t i = 0; i < s->n_cks; i++) pl->cks[b.n_cks + i].voff += b.n_vbuf;
+            for (int t = 0; t < T && rc == SA_OK; t++) {
+                sa_plan_t *s = W[t].pl;
+                M[t].pl = pl; M[t].s = s; M[t].base = b; M[t].job_base = job_base;
                 job_base += s->n_jobs;
                 b.n_regions += s->n_regions; b.n_rows += s->n_rows; b.n_pk += s->n_pk; b.n_poff += s->n_poff;
                 b.n_pid += s->n_pid; b.n_ev += s->n_ev; b.n_segs += s->n_segs; b.n_cks += s->n_cks;
@@ -839,15 +879,28 @@ int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, co
                 b.cells_fwd += s->cells_fwd; b.cells_bwd += s->cells_bwd; b.n_fast_regions += s->n_fast_regions;
                 if (s->max_span > b.max_span) b.max_span = s->max_span;
             }
-            pl->n_regions = pl->cap_regions = b.n_regions; pl->n_rows = pl->cap_rows = b.n_rows;
-            pl->n_pk = pl->cap_pk = b.n_pk; pl->n_poff = pl->cap_poff = b.n_poff; pl->n_pid = pl->cap_pid = b.n_pid;
-            pl->n_ev = pl->cap_ev = b.n_ev; pl->n_segs = pl->cap_segs = b.n_segs; pl->n_cks = pl->cap_cks = b.n_cks;
-            pl->n_vbuf = b.n_vbuf; pl->n_cand = b.n_cand; pl->n_bscratch = b.n_bscratch;
-            pl->cells_fwd = b.cells_fwd; pl->cells_bwd = b.cells_bwd; pl->n_fast_regions = b.n_fast_regions;
-            pl->max_span = b.max_span;
+            if (rc == SA_OK) {
+                for (int t = 0; t < T; t++) {
+                    started[t] = 0;
+                    if (pthread_create(&th[t], NULL, merge_worker, &M[t]) == 0) started[t] = 1;
+                    else merge_worker(&M[t]);
+                }
+                for (int t = 0; t < T; t++)
+                    if (started[t]) pthread_join(th[t], NULL);
+                for (int t = 0; t < T; t++) W[t].pl = NULL; /* freed by their merge workers */
+                pl->n_regions = pl->cap_regions = b.n_regions; pl->n_rows = pl->cap_rows = b.n_rows;
+                pl->n_pk = pl->cap_pk = b.n_pk; pl->n_poff = pl->cap_poff = b.n_poff; pl->n_pid = pl->cap_pid = b.n_pid;
+                pl->n_ev = pl->cap_ev = b.n_ev; pl->n_segs = pl->cap_segs = b.n_segs; pl->n_cks = pl->cap_cks = b.n_cks;
+                pl->n_vbuf = b.n_vbuf; pl->n_cand = b.n_cand; pl->n_bscratch = b.n_bscratch;
+                pl->cells_fwd = b.cells_fwd; pl->cells_bwd = b.cells_bwd; pl->n_fast_regions = b.n_fast_regions;
+                pl->max_span = b.max_span;
+            }
+            free(M);
         }
+        PLAN_TRACE("merged");
         for (int t = 0; t < T; t++) sa_plan_free(W[t].pl);
         free(W); free(th); free(started);
+        PLAN_TRACE("sub-plans freed");
     }
     if (rc != SA_OK) {
         sa_plan_free(pl);
