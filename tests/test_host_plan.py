@@ -218,3 +218,51 @@ def test_scalings_by_method_of_moments(oracle):
     with pytest.raises(sa.SaError) as ei:
         sa.scalings_mom(pm, "ACGTNACGTACGT", ev)        # a letter outside the model's alphabet
     assert ei.value.code == -4
+
+
+def test_plan_geometry_random_anchor_sets(oracle):
+    """Many small matrices with arbitrary (sorted, strictly increasing) anchor sets -- dense, sparse, hugging a border,
+    none at all -- and several band expansions / split limits: regions, every band row and the announced work equal the
+    oracle's.  Complements the synthetic-read cases above, whose anchors always follow the read's own event map."""
+    alpha, k, t10, tab = synth.parse_model_table(cases.MODEL_5MER)
+    m = sa.Model.create(alpha, k, t10, tab)
+    om = oracle.Model(alpha, k, t10, tab)
+    rng = np.random.default_rng(2024)
+    for it in range(60):
+        n_events = int(rng.integers(1, 400))
+        job = synth.make_read(int(rng.integers(0, 10 ** 6)), n_events, alpha, k, tab)
+        lX, lY = len(job["ref"]) - (k - 1), len(job["events"])
+        n_anchor = int(rng.integers(0, min(lX, lY) + 1))
+        style = it % 4
+        if style == 0 or n_anchor == 0 or lX < 2 or lY < 2:
+            ax = ay = np.zeros(0, dtype=np.int64)
+        else:
+            ax = np.sort(rng.choice(lX, size=min(n_anchor, lX), replace=False))
+            ay = np.sort(rng.choice(lY, size=min(n_anchor, lY), replace=False))
+            n = min(len(ax), len(ay))
+            ax, ay = ax[:n].astype(np.int64), ay[:n].astype(np.int64)
+            if style == 2:
+                ay = np.minimum(ay, np.arange(n))          # hugging the lower border
+                ay = np.maximum.accumulate(ay)
+                keep = np.concatenate([[True], np.diff(ay) > 0])
+                ax, ay = ax[keep], ay[keep]
+        job["ax"], job["ay"] = ax, ay
+        p = sa.default_params(expansion=int(rng.choice([0, 2, 10, 50])), trace_back=int(rng.choice([5, 30, 100])),
+                              min_diags=int(rng.choice([120, 1000])), split=int(rng.choice([40 * 40, 3000 * 3000])))
+        if p.trace_back_diagonals + 1 >= p.min_diags_between_trace_back:
+            continue
+        op = cases.oracle_params(oracle, p)
+        info, regions, rows, segs = sa.plan_describe(m, p, job)
+        exp_regions = oracle.split_points(ax, ay, lX, lY, p.split_matrix_bigger_than_this, 1, 1)
+        assert np.array_equal(regions, exp_regions), it
+        off = 0
+        for r, (x1, y1, x2, y2) in enumerate(regions):
+            sel = (ax + ay >= x1 + y1) & (ax + ay < x2 + y2)
+            L, R = oracle.band(ax[sel] - x1, ay[sel] - y1, x2 - x1, y2 - y1, p.diagonal_expansion)
+            n = len(L)
+            assert np.array_equal(rows[off:off + n, 1], L) and np.array_equal(rows[off:off + n, 2], R), (it, r)
+            off += n
+        om.set_read_params(job["scale"], job["shift"], job["var"])
+        _, st = oracle.align(om, job["ref"], job["events"], ax, ay, op, want_stats=True)
+        assert info.cells_forward == st.cells_forward and info.cells_backward == st.cells_backward, it
+        assert info.n_segments == st.n_tracebacks, it
