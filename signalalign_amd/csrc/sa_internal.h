@@ -147,6 +147,8 @@ typedef struct sa_plan {
     double cells_fwd, cells_bwd;
     int64_t n_fast_regions;
     int64_t max_span;
+    int32_t borrowed;     /* planner thread's sub-plan: rows, pk, poff, pid, xc, ev are slices of the final plan's arrays (sized
+                           * exactly by a counting pass): never grown, never freed here */
 } sa_plan_t;
 
 /* sa_plan.c */

@@ -243,6 +243,9 @@ int sa_load_ambig(const char *path, const char **map) {
 #define GROW(pl, arr, n, cap, need, type)                                  \
     do {                                                                   \
         if ((pl)->n + (need) > (pl)->cap) {                                \
+            if ((pl)->borrowed && (void *) (pl)->arr != (void *) (pl)->regions && (void *) (pl)->arr != (void *) (pl)->segs && \
+                (void *) (pl)->arr != (void *) (pl)->cks)                  \
+                return SA_EINVAL; /* the counting pass undercounted */     \
             int64_t nc = (pl)->cap ? (pl)->cap * 2 : 1024;                 \
             while (nc < (pl)->n + (need)) nc *= 2;                         \
             void *np_ = realloc((pl)->arr, sizeof(type) * (size_t) nc);    \
@@ -370,7 +373,8 @@ static int64_t expand_kmer(const sa_model_t *m, const char *s, const char *const
 /* ---- plan -------------------------------------------------------------------------------------- */
 void sa_plan_free(sa_plan_t *pl) {
     if (!pl) return;
-    free(pl->jobs); free(pl->regions); free(pl->rows); free(pl->pk); free(pl->poff); free(pl->pid); free(pl->xc); free(pl->ev);
+    free(pl->jobs); free(pl->regions);
+    if (!pl->borrowed) { free(pl->rows); free(pl->pk); free(pl->poff); free(pl->pid); free(pl->xc); free(pl->ev); }
     free(pl->segs); free(pl->cks);
     free(pl);
 }
@@ -430,6 +434,10 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
         return rcode;
     }
     if (pl->n_rows + N + 1 > pl->cap_rows) {
+        if (pl->borrowed) {
+            free(lo); free(hi);
+            return SA_EINVAL; /* the counting pass undercounted */
+        }
         int64_t nc = pl->cap_rows ? pl->cap_rows * 2 : 4096;
         while (nc < pl->n_rows + N + 1) nc *= 2;
         void *np_ = realloc(pl->rows, sizeof(sa_row_t) * (size_t) nc);
@@ -585,7 +593,7 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
  * carried out symbolically. */
 static int fill_xc(sa_plan_t *pl) {
     const sa_model_t *m = pl->model;
-    pl->xc = malloc(sizeof(double) * 4 * (size_t) (pl->n_pid > 0 ? pl->n_pid : 1));
+    if (!pl->borrowed) pl->xc = malloc(sizeof(double) * 4 * (size_t) (pl->n_pid > 0 ? pl->n_pid : 1));
     if (!pl->xc) return SA_ENOMEM;
     for (int64_t r = 0; r < pl->n_regions; r++) {
         const sa_region_t *R = &pl->regions[r];
@@ -642,7 +650,9 @@ static int plan_job(sa_plan_t *pl, int64_t j, const sa_job_t *jb, const char *co
             (i > 0 && (jb->anchor_x[i] <= jb->anchor_x[i - 1] || jb->anchor_y[i] <= jb->anchor_y[i - 1])))
             return SA_EBAND;
     /* events: keep only the mean column */
-    if (pl->n_ev + lY + 1 > pl->cap_ev) {
+    if (pl->borrowed) {
+        if (pl->n_ev + lY > pl->cap_ev) return SA_EINVAL; /* the counting pass undercounted */
+    } else if (pl->n_ev + lY + 1 > pl->cap_ev) {
         int64_t nc = pl->cap_ev ? pl->cap_ev * 2 : 4096;
         while (nc < pl->n_ev + lY + 1) nc *= 2;
         void *np_ = realloc(pl->ev, sizeof(double) * (size_t) nc);
@@ -710,6 +720,60 @@ static void *plan_worker(void *arg) {
     w->rc = SA_OK;
     for (int64_t j = 0; j < w->n && w->rc == SA_OK; j++) w->rc = plan_job(w->pl, j, &w->jobs[j], w->ambig);
     if (w->rc == SA_OK) w->rc = fill_xc(w->pl);
+    if (w->rc == SA_OK && w->pl->borrowed &&
+        (w->pl->n_rows != w->pl->cap_rows || w->pl->n_pk != w->pl->cap_pk || w->pl->n_poff != w->pl->cap_poff ||
+         w->pl->n_pid != w->pl->cap_pid || w->pl->n_ev != w->pl->cap_ev))
+        w->rc = SA_EINVAL; /* the counting pass overcounted: the slices would not be contiguous */
+    return NULL;
+}
+
+/* Counting pass of the threaded planner: how many entries of the big arrays (band rows, packed words, path offsets and
+ * ids, emission constants, events) a range of jobs will occupy -- exactly, so that every thread can then write its
+ * sub-plan straight into its slice of the final arrays (copying several hundred MB of sub-plans and handing them back
+ * to the kernel cost more than planning them).  Follows plan_job / add_region; a job those would reject counts as
+ * whatever it counts, the planning pass then fails with its error code. */
+static void *count_worker(void *arg) {
+    plan_worker_t *w = arg;
+    const sa_model_t *m = w->pl->model;
+    const sa_params_t *p = &w->pl->params;
+    sa_plan_t *c = w->pl; /* cap_* fields receive the counts */
+    int nopt[256];
+    for (int ch = 0; ch < 256; ch++) nopt[ch] = (w->ambig && w->ambig[ch]) ? (int) strlen(w->ambig[ch]) : 1;
+    w->rc = SA_OK;
+    for (int64_t j = 0; j < w->n; j++) {
+        const sa_job_t *jb = &w->jobs[j];
+        if (!jb->ref || jb->ref_len < 0 || jb->n_events < 0 || jb->n_anchors < 0 || (jb->n_events && !jb->events) ||
+            (jb->n_anchors && (!jb->anchor_x || !jb->anchor_y)))
+            return NULL; /* plan_job rejects it */
+        int64_t lX = jb->ref_len == 0 ? 0 : jb->ref_len - (m->k - 1);
+        if (lX < 0) lX = 0;
+        const int64_t lY = jb->n_events;
+        for (int64_t i = 0; i < jb->n_anchors; i++)
+            if (jb->anchor_x[i] < 0 || jb->anchor_y[i] < 0 || jb->anchor_x[i] >= lX || jb->anchor_y[i] >= lY ||
+                (i > 0 && (jb->anchor_x[i] <= jb->anchor_x[i - 1] || jb->anchor_y[i] <= jb->anchor_y[i - 1])))
+                return NULL;
+        c->cap_ev += lY;
+        rect_t *rects = malloc(sizeof(rect_t) * (size_t) (jb->n_anchors + 2));
+        if (!rects) { w->rc = SA_ENOMEM; return NULL; }
+        const int64_t nr = split_regions(jb->anchor_x, jb->anchor_y, jb->n_anchors, lX, lY, p->split_matrix_bigger_than_this,
+                                         1, 1, rects);
+        for (int64_t i = 0; i < nr; i++) {
+            const int64_t rX = rects[i].x2 - rects[i].x1, rY = rects[i].y2 - rects[i].y1, N = rX + rY;
+            if (N == 0) continue;
+            c->cap_rows += N + 1;
+            c->cap_pk += N + 1 + SA_PK_PAD + 160;
+            c->cap_poff += rX + 2;
+            int64_t paths = 1; /* the NULL k-mer of x = 0 */
+            for (int64_t x = 1; x <= rX; x++) {
+                const unsigned char *s = (const unsigned char *) jb->ref + rects[i].x1 + (x - 1);
+                int64_t total = 1;
+                for (int q = 0; q < m->k; q++) total *= nopt[s[q]];
+                paths += total;
+            }
+            c->cap_pid += paths;
+        }
+        free(rects);
+    }
     return NULL;
 }
 
@@ -742,15 +806,10 @@ static void *merge_worker(void *arg) {
     const sa_plan_t *s = k->s;
     const sa_plan_t *b = &k->base;
     COPY_CAT(regions, n_regions, sa_region_t);
-    COPY_CAT(rows, n_rows, sa_row_t);
-    COPY_CAT(pk, n_pk, int32_t);
-    COPY_CAT(poff, n_poff, int32_t);
-    COPY_CAT(pid, n_pid, int32_t);
-    COPY_CAT(ev, n_ev, double);
     COPY_CAT(segs, n_segs, sa_seg_t);
     COPY_CAT(cks, n_cks, sa_ck_t);
     if (s->n_jobs) memcpy(pl->jobs + k->job_base, s->jobs, sizeof(sa_jobinfo_t) * (size_t) s->n_jobs);
-    if (s->n_pid) memcpy(pl->xc + 4 * b->n_pid, s->xc, sizeof(double) * 4 * (size_t) s->n_pid); /* four doubles per pid entry */
+    /* rows, pk, poff, pid, xc, ev were written in place (borrowed slices) */
     for (int64_t i = 0; i < s->n_jobs; i++) {
         sa_jobinfo_t *J = &pl->jobs[k->job_base + i];
         J->region_off += b->n_regions;
@@ -832,6 +891,42 @@ int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, co
             W[t].pl = plan_new(m, p, flags, W[t].n);
             if (!W[t].pl) rc = SA_ENOMEM;
         }
+        /* round 1: exact sizes of the big arrays per thread (cap_* of the sub-plans receive the counts) */
+        for (int t = 0; t < T && rc == SA_OK; t++) {
+            if (pthread_create(&th[t], NULL, count_worker, &W[t]) == 0) started[t] = 1;
+            else count_worker(&W[t]);
+        }
+        for (int t = 0; t < T; t++)
+            if (started[t]) { pthread_join(th[t], NULL); started[t] = 0; }
+        for (int t = 0; t < T && rc == SA_OK; t++) rc = W[t].rc;
+        PLAN_TRACE("sizes counted");
+        /* the final plan, its big arrays sized once; every sub-plan gets its slices */
+        if (rc == SA_OK) {
+            pl = plan_new(m, p, flags, n_jobs);
+            if (!pl) rc = SA_ENOMEM;
+        }
+        if (rc == SA_OK) {
+            int64_t tr = 0, tk = 0, to = 0, ti = 0, te = 0;
+            for (int t = 0; t < T; t++) {
+                tr += W[t].pl->cap_rows; tk += W[t].pl->cap_pk; to += W[t].pl->cap_poff; ti += W[t].pl->cap_pid; te += W[t].pl->cap_ev;
+            }
+            pl->rows = malloc(sizeof(sa_row_t) * (size_t) (tr > 0 ? tr : 1));
+            pl->pk = malloc(sizeof(int32_t) * (size_t) (tk > 0 ? tk : 1));
+            pl->poff = malloc(sizeof(int32_t) * (size_t) (to > 0 ? to : 1));
+            pl->pid = malloc(sizeof(int32_t) * (size_t) (ti > 0 ? ti : 1));
+            pl->xc = malloc(sizeof(double) * 4 * (size_t) (ti > 0 ? ti : 1));
+            pl->ev = malloc(sizeof(double) * (size_t) (te > 0 ? te : 1));
+            if (!pl->rows || !pl->pk || !pl->poff || !pl->pid || !pl->xc || !pl->ev) rc = SA_ENOMEM;
+            tr = tk = to = ti = te = 0;
+            for (int t = 0; t < T && rc == SA_OK; t++) {
+                sa_plan_t *s = W[t].pl;
+                s->borrowed = 1;
+                s->rows = pl->rows + tr; s->pk = pl->pk + tk; s->poff = pl->poff + to; s->pid = pl->pid + ti;
+                s->xc = pl->xc + 4 * ti; s->ev = pl->ev + te;
+                tr += s->cap_rows; tk += s->cap_pk; to += s->cap_poff; ti += s->cap_pid; te += s->cap_ev;
+            }
+        }
+        /* round 2: the planning itself, in place */
         for (int t = 0; t < T && rc == SA_OK; t++) {
             if (pthread_create(&th[t], NULL, plan_worker, &W[t]) == 0) started[t] = 1;
             else plan_worker(&W[t]); /* no thread to be had: do it here */
@@ -840,28 +935,14 @@ int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, co
             if (started[t]) pthread_join(th[t], NULL);
         PLAN_TRACE("sub-plans built");
         for (int t = 0; t < T && rc == SA_OK; t++) rc = W[t].rc; /* the first failing job in job order decides */
-        if (rc == SA_OK) {
-            pl = plan_new(m, p, flags, n_jobs);
-            if (!pl) rc = SA_ENOMEM;
-        }
+        /* round 3: the small arrays (jobs, regions, segments, checkpoints) are concatenated, offsets shifted */
         if (rc == SA_OK) {
             free(pl->jobs);
             pl->jobs = NULL;
             ALLOC_CAT(pl, jobs, n_jobs, sa_jobinfo_t);
             ALLOC_CAT(pl, regions, n_regions, sa_region_t);
-            ALLOC_CAT(pl, rows, n_rows, sa_row_t);
-            ALLOC_CAT(pl, pk, n_pk, int32_t);
-            ALLOC_CAT(pl, poff, n_poff, int32_t);
-            ALLOC_CAT(pl, pid, n_pid, int32_t);
-            ALLOC_CAT(pl, ev, n_ev, double);
             ALLOC_CAT(pl, segs, n_segs, sa_seg_t);
             ALLOC_CAT(pl, cks, n_cks, sa_ck_t);
-            {
-                int64_t tot = 0;
-                for (int t = 0; t < T; t++) tot += W[t].pl->n_pid;
-                pl->xc = malloc(sizeof(double) * 4 * (size_t) (tot > 0 ? tot : 1));
-                if (!pl->xc) rc = SA_ENOMEM;
-            }
         }
         if (rc == SA_OK) {
             merge_task_t *M = calloc((size_t) T, sizeof(*M));
