@@ -198,6 +198,12 @@ int sa_event_align_batch(const sa_model_t *m, const sa_ea_job_t *jobs, int64_t n
  * calls serialise on it); this returns the memory.  Safe to call at any time, also when nothing is held. */
 void sa_event_align_release(void);
 
+/* Batches take their device and pinned-host storage from a caching allocator: what a destroyed batch held is kept and
+ * handed to the next one (a pipeline that sees every read once creates and destroys a batch per few thousand reads;
+ * allocation and release of its 25 GB cost more than its kernels).  sa_pool_release() returns everything that is
+ * parked; SA_POOL=0 in the environment disables the cache, SA_POOL_LIMIT_GB bounds it (default 96 device / 8 pinned). */
+void sa_pool_release(void);
+
 /* ---- maximum-expected-accuracy path over a read's posteriors ----------------------------------
  * Replaces maximum_expected_accuracy_alignment + get_indexes_from_best_path (src/signalalign/mea_algorithm.py:25-197,
  * :248-264; called by mea_alignment_from_signal_align :323-341): the best monotone path through the sparse posterior

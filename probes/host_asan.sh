@@ -8,6 +8,7 @@ OUT=/tmp/sa_host_asan
 mkdir -p $OUT
 cat > $OUT/stubs.c <<'EOS'
 #include "signalalign_hip.h"
+#include "sa_internal.h"
 #include <stdlib.h>
 #define NODEV { return SA_ENODEVICE; }
 int sa_device_count(void) { return 0; }
@@ -25,6 +26,7 @@ int sa_event_align_batch(const sa_model_t *m, const sa_ea_job_t *j, int64_t n, i
 void sa_event_align_release(void) {}
 int sa_mea_batch(const sa_mea_job_t *j, int64_t n, int d, unsigned f, sa_mea_pair_t **p, int64_t *np, double *s, int32_t *st, int32_t *ne, double *k) NODEV
 void sa_mea_release(void) {}
+void sa_pool_release(void) { sa_plan_pool_release(); }
 int sa_batch_mea(sa_batch_t *b, unsigned f, sa_mea_pair_t **p, int64_t *np, double *s, int32_t *st, double *k) NODEV
 double sa_mea_printed_posterior(int64_t p) { return (double) p; }
 int sa_mea_printed_posterior_device(int64_t a, int64_t n, double *o, int d) NODEV

@@ -975,12 +975,19 @@ struct SaUploader {
     }
 };
 static SaUploader g_uploader;
+SaPool g_sa_pool;
+
+extern "C" void sa_pool_release(void) {
+    g_sa_pool.release(SaPool::DEVICE);
+    g_sa_pool.release(SaPool::PINNED);
+    sa_plan_pool_release();
+}
 
 template <typename T>
 static int upload(T **dst, const T *src, long long n, long long pad = 0) {
     // pad: extra zeroed elements behind the data (kernels that clamp an index may read one element past the end)
     size_t bytes = sizeof(T) * (size_t) (n + pad > 0 ? n + pad : 1);
-    HIPCHK(hipMalloc((void **) dst, bytes));
+    HIPCHK(g_sa_pool.get(SaPool::DEVICE, (void **) dst, bytes, g_uploader.device));
     if (pad > 0) HIPCHK(hipMemsetAsync((char *) *dst + sizeof(T) * (size_t) n, 0, sizeof(T) * (size_t) pad, g_uploader.stream));
     if (n > 0) return g_uploader.copy(*dst, src, sizeof(T) * (size_t) n);
     return SA_OK;
@@ -994,7 +1001,7 @@ void sa_batch_destroy(sa_batch_t *b) {
                     b->d_hdp_slot, b->d_hdp_y, b->d_hdp_slope, b->d_hdp_grid, b->d_hdp_tab, b->d_prob, b->d_seg_pass, b->d_seg_off,
                     b->d_out, b->d_ids, b->d_gsum, b->d_gmc};
     for (void *p : ptrs)
-        if (p) (void) hipFree(p);
+        if (p) g_sa_pool.put(SaPool::DEVICE, p);
     for (int i = 0; i < 8; i++)
         if (b->ev[i]) (void) hipEventDestroy(b->ev[i]);
     for (hipEvent_t e : b->gev) (void) hipEventDestroy(e);
@@ -1002,10 +1009,10 @@ void sa_batch_destroy(sa_batch_t *b) {
     for (int i = 0; i < 2; i++)
         if (b->cstream[i]) (void) hipStreamDestroy(b->cstream[i]);
     if (b->pair_stream) (void) hipStreamDestroy(b->pair_stream);
-    if (b->h_pairs) (void) hipHostFree(b->h_pairs);
-    if (b->d_pairs_up) (void) hipFree(b->d_pairs_up);
-    if (b->h_seg_off) (void) hipHostFree(b->h_seg_off);
-    if (b->h_overflow) (void) hipHostFree(b->h_overflow);
+    g_sa_pool.put(SaPool::PINNED, b->h_pairs);
+    g_sa_pool.put(SaPool::DEVICE, b->d_pairs_up);
+    g_sa_pool.put(SaPool::PINNED, b->h_seg_off);
+    g_sa_pool.put(SaPool::PINNED, b->h_overflow);
     sa_plan_free(b->plan);
     delete b;
 }
@@ -1159,7 +1166,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     if (trace_c) fprintf(stderr, "[trace] create: inputs uploaded at %.1f ms\n", now_ms_c() - tc0);
     // working buffers
     auto dalloc = [&](void **p_, long long bytes) -> int {
-        HIPCHK(hipMalloc(p_, (size_t) (bytes > 0 ? bytes : 8)));
+        HIPCHK(g_sa_pool.get(SaPool::DEVICE, p_, (size_t) (bytes > 0 ? bytes : 8), device));
         return SA_OK;
     };
     TRY(dalloc((void **) &b->d_F, 24 * pl->max_chunk_cellpaths));
@@ -1257,9 +1264,9 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
             if (hipEventCreate(&e) != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
         for (auto &e : b->cev)
             if (hipEventCreate(&e) != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
-        if (hipHostMalloc((void **) &b->h_seg_off, 8 * (size_t) (pl->n_segs + (long long) b->groups.size() + 1),
-                          hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc((void **) &b->h_overflow, 64, hipHostMallocDefault) != hipSuccess) {
+        if (g_sa_pool.get(SaPool::PINNED, (void **) &b->h_seg_off, 8 * (size_t) (pl->n_segs + (long long) b->groups.size() + 1),
+                          device) != hipSuccess ||
+            g_sa_pool.get(SaPool::PINNED, (void **) &b->h_overflow, 64, device) != hipSuccess) {
             sa_batch_destroy(b);
             return SA_ENOMEM;
         }
@@ -1396,17 +1403,17 @@ static int grow_after_overflow(sa_batch *b) {
     sa_plan_t *pl = b->plan;
     // a traceback segment produced more candidates than planned: enlarge and redo the pass
     sa_plan_grow_candidates(pl, 4);
-    HIPCHK(hipFree(b->d_cands));
-    HIPCHK(hipFree(b->d_prob));
+    g_sa_pool.put(SaPool::DEVICE, b->d_cands);
+    g_sa_pool.put(SaPool::DEVICE, b->d_prob);
     b->d_cands = nullptr;
     b->d_prob = nullptr;
-    HIPCHK(hipMalloc((void **) &b->d_cands, sizeof(sa_cand_t) * (size_t) pl->n_cand));
-    HIPCHK(hipMalloc((void **) &b->d_prob, 8 * (size_t) pl->n_cand));
+    HIPCHK(g_sa_pool.get(SaPool::DEVICE, (void **) &b->d_cands, sizeof(sa_cand_t) * (size_t) pl->n_cand, b->device));
+    HIPCHK(g_sa_pool.get(SaPool::DEVICE, (void **) &b->d_prob, 8 * (size_t) pl->n_cand, b->device));
     b->cand_alloc = pl->n_cand;
     if (b->d_out) {
-        HIPCHK(hipFree(b->d_out));
+        g_sa_pool.put(SaPool::DEVICE, b->d_out);
         b->d_out = nullptr;
-        HIPCHK(hipMalloc((void **) &b->d_out, sizeof(sa_pair_t) * (size_t) pl->n_cand));
+        HIPCHK(g_sa_pool.get(SaPool::DEVICE, (void **) &b->d_out, sizeof(sa_pair_t) * (size_t) pl->n_cand, b->device));
         b->out_alloc = pl->n_cand;
     }
     HIPCHK(hipMemcpy(b->d_segs, pl->segs, sizeof(sa_seg_t) * (size_t) pl->n_segs, hipMemcpyHostToDevice));
@@ -1439,14 +1446,21 @@ int sa_batch_run(sa_batch_t *b) {
     b->job_off.assign((size_t) pl->n_jobs + 1, 0);
     auto reserve_pairs = [&](long long total) -> int {
         if (total > b->h_pairs_cap) {
-            if (b->h_pairs) HIPCHK(hipHostFree(b->h_pairs));
+            g_sa_pool.put(SaPool::PINNED, b->h_pairs);
             b->h_pairs = nullptr;
             long long cap = total + total / 8 + 1024;
-            HIPCHK(hipHostMalloc((void **) &b->h_pairs, sizeof(sa_pair_t) * (size_t) cap, hipHostMallocDefault));
+            HIPCHK(g_sa_pool.get(SaPool::PINNED, (void **) &b->h_pairs, sizeof(sa_pair_t) * (size_t) cap, b->device));
             b->h_pairs_cap = cap;
         }
         return SA_OK;
     };
+    // A first estimate of the result size (measured: 0.9 pairs per event at the default threshold) lets even the FIRST run
+    // of a batch overlap its copies with the kernels; with the caching allocator the buffer is a reused block.  If the
+    // estimate is short the run falls back to copying afterwards, as before.
+    if (!(b->flags & SA_FLAG_EXACT) && b->h_pairs_cap == 0 && pl->params.threshold >= 0.005) {
+        int rce = reserve_pairs((long long) (1.5 * (double) pl->n_ev) + 4096);
+        if (rce) return rce;
+    }
     if (b->flags & SA_FLAG_EXACT) {
         int rcp0 = run_passes(b);
         if (rcp0) return rcp0;
@@ -1583,9 +1597,9 @@ int sa_batch_device_view(sa_batch_t *b, const sa_pair_t **pairs, std::vector<lon
         return SA_OK;
     }
     if (b->n_pairs_total > b->d_pairs_up_cap) {
-        if (b->d_pairs_up) HIPCHK(hipFree(b->d_pairs_up));
+        g_sa_pool.put(SaPool::DEVICE, b->d_pairs_up);
         b->d_pairs_up = nullptr; b->d_pairs_up_cap = 0;
-        HIPCHK(hipMalloc((void **) &b->d_pairs_up, sizeof(sa_pair_t) * (size_t) b->n_pairs_total));
+        HIPCHK(g_sa_pool.get(SaPool::DEVICE, (void **) &b->d_pairs_up, sizeof(sa_pair_t) * (size_t) b->n_pairs_total, b->device));
         b->d_pairs_up_cap = b->n_pairs_total;
     }
     if (b->n_pairs_total)

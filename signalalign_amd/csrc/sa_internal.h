@@ -147,6 +147,7 @@ typedef struct sa_plan {
     double cells_fwd, cells_bwd;
     int64_t n_fast_regions;
     int64_t max_span;
+    int32_t pooled;       /* rows, pk, poff, pid, xc, ev came from plan_big_alloc and go back to its cache */
     int32_t borrowed;     /* planner thread's sub-plan: rows, pk, poff, pid, xc, ev are slices of the final plan's arrays (sized
                            * exactly by a counting pass): never grown, never freed here */
 } sa_plan_t;
@@ -155,6 +156,7 @@ typedef struct sa_plan {
 int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs, int64_t n_jobs,
                   const char *const *ambig256, unsigned flags, int64_t chunk_budget_cellpaths);
 void sa_plan_free(sa_plan_t *pl);
+void sa_plan_pool_release(void); /* frees the host blocks the planner keeps between batches */
 /* grows every segment's candidate capacity by `factor` and re-lays out cand_off (overflow retry) */
 void sa_plan_grow_candidates(sa_plan_t *pl, int factor);
 /* after the device pass: turn candidates + totals into the reference's pair list for every job */

@@ -371,10 +371,78 @@ static int64_t expand_kmer(const sa_model_t *m, const char *s, const char *const
 }
 
 /* ---- plan -------------------------------------------------------------------------------------- */
+/* ---- host blocks kept between batches ---------------------------------------------------------------------------
+ * The big arrays of a plan (0.8 GB for 2000 reads) are fresh memory for every batch otherwise: first-touch page faults
+ * while the planner threads fill them and 80 ms of munmap when the batch is destroyed.  Freed blocks are parked here
+ * and handed out again when they fit (at most twice the request); SA_POOL=0 disables it, sa_pool_release() empties it. */
+#define PLAN_POOL_SLOTS 48
+static struct { void *p; size_t bytes; } plan_pool[PLAN_POOL_SLOTS];
+static size_t plan_pool_held = 0;
+static pthread_mutex_t plan_pool_mu = PTHREAD_MUTEX_INITIALIZER;
+static int plan_pool_on(void) {
+    const char *e = getenv("SA_POOL");
+    return !(e && atoi(e) == 0);
+}
+static void *plan_big_alloc(size_t bytes) {
+    if (bytes == 0) bytes = 8;
+    if (plan_pool_on()) {
+        pthread_mutex_lock(&plan_pool_mu);
+        int best = -1;
+        for (int i = 0; i < PLAN_POOL_SLOTS; i++)
+            if (plan_pool[i].p && plan_pool[i].bytes >= bytes && plan_pool[i].bytes / 2 <= bytes + (1 << 20) &&
+                (best < 0 || plan_pool[i].bytes < plan_pool[best].bytes))
+                best = i;
+        if (best >= 0) {
+            void *p = plan_pool[best].p;
+            plan_pool_held -= plan_pool[best].bytes;
+            plan_pool[best].p = NULL;
+            pthread_mutex_unlock(&plan_pool_mu);
+            return p;
+        }
+        pthread_mutex_unlock(&plan_pool_mu);
+    }
+    return malloc(bytes);
+}
+static void plan_big_free(void *p, size_t bytes) {
+    if (!p) return;
+    if (plan_pool_on() && bytes >= (1 << 20)) {
+        pthread_mutex_lock(&plan_pool_mu);
+        if (plan_pool_held + bytes <= ((size_t) 8 << 30))
+            for (int i = 0; i < PLAN_POOL_SLOTS; i++)
+                if (!plan_pool[i].p) {
+                    plan_pool[i].p = p;
+                    plan_pool[i].bytes = bytes;
+                    plan_pool_held += bytes;
+                    pthread_mutex_unlock(&plan_pool_mu);
+                    return;
+                }
+        pthread_mutex_unlock(&plan_pool_mu);
+    }
+    free(p);
+}
+void sa_plan_pool_release(void) {
+    pthread_mutex_lock(&plan_pool_mu);
+    for (int i = 0; i < PLAN_POOL_SLOTS; i++) {
+        free(plan_pool[i].p);
+        plan_pool[i].p = NULL;
+    }
+    plan_pool_held = 0;
+    pthread_mutex_unlock(&plan_pool_mu);
+}
+
 void sa_plan_free(sa_plan_t *pl) {
     if (!pl) return;
     free(pl->jobs); free(pl->regions);
-    if (!pl->borrowed) { free(pl->rows); free(pl->pk); free(pl->poff); free(pl->pid); free(pl->xc); free(pl->ev); }
+    if (pl->pooled) { /* sizes as allocated by sa_plan_build */
+        plan_big_free(pl->rows, sizeof(sa_row_t) * (size_t) (pl->cap_rows > 0 ? pl->cap_rows : 1));
+        plan_big_free(pl->pk, sizeof(int32_t) * (size_t) (pl->cap_pk > 0 ? pl->cap_pk : 1));
+        plan_big_free(pl->poff, sizeof(int32_t) * (size_t) (pl->cap_poff > 0 ? pl->cap_poff : 1));
+        plan_big_free(pl->pid, sizeof(int32_t) * (size_t) (pl->cap_pid > 0 ? pl->cap_pid : 1));
+        plan_big_free(pl->xc, sizeof(double) * 4 * (size_t) (pl->cap_pid > 0 ? pl->cap_pid : 1));
+        plan_big_free(pl->ev, sizeof(double) * (size_t) (pl->cap_ev > 0 ? pl->cap_ev : 1));
+    } else if (!pl->borrowed) {
+        free(pl->rows); free(pl->pk); free(pl->poff); free(pl->pid); free(pl->xc); free(pl->ev);
+    }
     free(pl->segs); free(pl->cks);
     free(pl);
 }
@@ -910,12 +978,14 @@ int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, co
             for (int t = 0; t < T; t++) {
                 tr += W[t].pl->cap_rows; tk += W[t].pl->cap_pk; to += W[t].pl->cap_poff; ti += W[t].pl->cap_pid; te += W[t].pl->cap_ev;
             }
-            pl->rows = malloc(sizeof(sa_row_t) * (size_t) (tr > 0 ? tr : 1));
-            pl->pk = malloc(sizeof(int32_t) * (size_t) (tk > 0 ? tk : 1));
-            pl->poff = malloc(sizeof(int32_t) * (size_t) (to > 0 ? to : 1));
-            pl->pid = malloc(sizeof(int32_t) * (size_t) (ti > 0 ? ti : 1));
-            pl->xc = malloc(sizeof(double) * 4 * (size_t) (ti > 0 ? ti : 1));
-            pl->ev = malloc(sizeof(double) * (size_t) (te > 0 ? te : 1));
+            pl->pooled = 1;
+            pl->cap_rows = tr; pl->cap_pk = tk; pl->cap_poff = to; pl->cap_pid = ti; pl->cap_ev = te;
+            pl->rows = plan_big_alloc(sizeof(sa_row_t) * (size_t) (tr > 0 ? tr : 1));
+            pl->pk = plan_big_alloc(sizeof(int32_t) * (size_t) (tk > 0 ? tk : 1));
+            pl->poff = plan_big_alloc(sizeof(int32_t) * (size_t) (to > 0 ? to : 1));
+            pl->pid = plan_big_alloc(sizeof(int32_t) * (size_t) (ti > 0 ? ti : 1));
+            pl->xc = plan_big_alloc(sizeof(double) * 4 * (size_t) (ti > 0 ? ti : 1));
+            pl->ev = plan_big_alloc(sizeof(double) * (size_t) (te > 0 ? te : 1));
             if (!pl->rows || !pl->pk || !pl->poff || !pl->pid || !pl->xc || !pl->ev) rc = SA_ENOMEM;
             tr = tk = to = ti = te = 0;
             for (int t = 0; t < T && rc == SA_OK; t++) {

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "sa_internal.h"
@@ -65,6 +66,106 @@ struct SaScratch {
         return SA_OK;
     }
 };
+// Caching allocators for a batch's working storage.  A pipeline that sees every read once creates and destroys a batch
+// per 2000 reads: hipMalloc / hipFree of its 25 GB (0.1 - 1 s per batch, measured), hipHostMalloc of the 200 MB pinned
+// result buffer (40 ms) and their release (130 ms) cost ten times the kernels.  Blocks handed back are kept (per device
+// and kind) and reused for requests they fit without wasting more than half of the block; sa_pool_release() returns
+// everything, SA_POOL=0 disables the cache, SA_POOL_LIMIT_GB (default 96 / 8) bounds what is held.
+struct SaPool {
+    enum Kind { DEVICE = 0, PINNED = 1 };
+    struct Blk {
+        void *p;
+        size_t bytes;
+        int dev;
+    };
+    std::mutex mu;
+    std::vector<Blk> idle[2];
+    std::unordered_map<void *, Blk> live[2];
+    size_t held[2] = {0, 0};
+    static bool enabled() {
+        static const bool on = !(getenv("SA_POOL") && atoi(getenv("SA_POOL")) == 0);
+        return on;
+    }
+    static size_t limit(int kind) {
+        const char *e = getenv("SA_POOL_LIMIT_GB");
+        const double gb = e ? atof(e) : (kind == DEVICE ? 96.0 : 8.0);
+        return (size_t) (gb * 1073741824.0);
+    }
+    static hipError_t raw_alloc(int kind, void **p, size_t bytes) {
+        return kind == DEVICE ? hipMalloc(p, bytes) : hipHostMalloc(p, bytes, hipHostMallocDefault);
+    }
+    static void raw_free(int kind, void *p) { (void) (kind == DEVICE ? hipFree(p) : hipHostFree(p)); }
+    // the current device must be `dev`
+    hipError_t get(int kind, void **out, size_t bytes, int dev) {
+        if (bytes == 0) bytes = 8;
+        if (enabled()) {
+            std::lock_guard<std::mutex> g(mu);
+            int best = -1;
+            for (size_t i = 0; i < idle[kind].size(); i++) {
+                const Blk &b = idle[kind][i];
+                if (b.dev != dev || b.bytes < bytes || b.bytes / 2 > bytes + (1 << 20)) continue;
+                if (best < 0 || b.bytes < idle[kind][(size_t) best].bytes) best = (int) i;
+            }
+            if (best >= 0) {
+                Blk b = idle[kind][(size_t) best];
+                idle[kind].erase(idle[kind].begin() + best);
+                held[kind] -= b.bytes;
+                live[kind][b.p] = b;
+                *out = b.p;
+                return hipSuccess;
+            }
+        }
+        hipError_t e = raw_alloc(kind, out, bytes);
+        if (e != hipSuccess && enabled()) {   // out of memory with blocks parked in the cache: give them back and retry
+            (void) hipGetLastError();
+            release(kind);
+            e = raw_alloc(kind, out, bytes);
+        }
+        if (e == hipSuccess && enabled()) {
+            std::lock_guard<std::mutex> g(mu);
+            live[kind][*out] = Blk{*out, bytes, dev};
+        }
+        return e;
+    }
+    void put(int kind, void *p) {
+        if (!p) return;
+        Blk b{nullptr, 0, 0};
+        bool known = false;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            auto it = live[kind].find(p);
+            if (it != live[kind].end()) {
+                b = it->second;
+                live[kind].erase(it);
+                known = true;
+                if (held[kind] + b.bytes <= limit(kind)) {
+                    idle[kind].push_back(b);
+                    held[kind] += b.bytes;
+                    return;
+                }
+            }
+        }
+        (void) known;
+        raw_free(kind, p);
+    }
+    void release(int kind) {
+        std::vector<Blk> v;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            v.swap(idle[kind]);
+            held[kind] = 0;
+        }
+        int cur = 0;
+        (void) hipGetDevice(&cur);
+        for (Blk &b : v) {
+            (void) hipSetDevice(b.dev);
+            raw_free(kind, b.p);
+        }
+        (void) hipSetDevice(cur);
+    }
+};
+extern SaPool g_sa_pool;
+
 // sa_hip.hip: device-side view of a finished batch for a downstream device step (per job: first pair in *pairs, number
 // of pairs, number of events)
 int sa_batch_device_view(sa_batch_t *b, const sa_pair_t **pairs, std::vector<long long> *first, std::vector<long long> *count,
