@@ -977,10 +977,68 @@ struct SaUploader {
 static SaUploader g_uploader;
 SaPool g_sa_pool;
 
+// Streams and events of destroyed batches, kept per device for the next batch (creating three streams and ~50 events is
+// 10 ms per batch).  Handles are only parked after the batch has drained them.
+struct SaHandles {
+    std::mutex mu;
+    struct S { hipStream_t s; int dev; int kind; };   // kind 0: compute, 1: high priority
+    struct E { hipEvent_t e; int dev; };
+    std::vector<S> streams;
+    std::vector<E> events;
+    hipError_t stream(hipStream_t *out, int dev, int kind) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (size_t i = 0; i < streams.size(); i++)
+                if (streams[i].dev == dev && streams[i].kind == kind) {
+                    *out = streams[i].s;
+                    streams.erase(streams.begin() + (long) i);
+                    return hipSuccess;
+                }
+        }
+        if (kind == 0) return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+        int lo = 0, hi = 0;
+        (void) hipDeviceGetStreamPriorityRange(&lo, &hi);
+        return hipStreamCreateWithPriority(out, hipStreamNonBlocking, hi);
+    }
+    hipError_t event(hipEvent_t *out, int dev) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (size_t i = events.size(); i-- > 0;)
+                if (events[i].dev == dev) {
+                    *out = events[i].e;
+                    events.erase(events.begin() + (long) i);
+                    return hipSuccess;
+                }
+        }
+        return hipEventCreate(out);
+    }
+    void park(hipStream_t s, int dev, int kind) {
+        if (!s) return;
+        if (!SaPool::enabled()) { (void) hipStreamDestroy(s); return; }
+        std::lock_guard<std::mutex> g(mu);
+        streams.push_back(S{s, dev, kind});
+    }
+    void park(hipEvent_t e, int dev) {
+        if (!e) return;
+        if (!SaPool::enabled() || events.size() > 4096) { (void) hipEventDestroy(e); return; }
+        std::lock_guard<std::mutex> g(mu);
+        events.push_back(E{e, dev});
+    }
+    void release() {
+        std::lock_guard<std::mutex> g(mu);
+        for (S &x : streams) (void) hipStreamDestroy(x.s);
+        for (E &x : events) (void) hipEventDestroy(x.e);
+        streams.clear();
+        events.clear();
+    }
+};
+static SaHandles g_handles;
+
 extern "C" void sa_pool_release(void) {
     g_sa_pool.release(SaPool::DEVICE);
     g_sa_pool.release(SaPool::PINNED);
     sa_plan_pool_release();
+    g_handles.release();
 }
 
 template <typename T>
@@ -996,6 +1054,11 @@ static int upload(T **dst, const T *src, long long n, long long pad = 0) {
 void sa_batch_destroy(sa_batch_t *b) {
     if (!b) return;
     if (b->device >= 0) (void) hipSetDevice(b->device);
+    // the storage goes back to the caching allocators without the implicit synchronisation of hipFree: nothing of this
+    // batch may still be in flight (only possible after an error inside a run)
+    for (int i = 0; i < 2; i++)
+        if (b->cstream[i]) (void) hipStreamSynchronize(b->cstream[i]);
+    if (b->pair_stream) (void) hipStreamSynchronize(b->pair_stream);
     void *ptrs[] = {b->d_regions, b->d_rows, b->d_pk, b->d_poff, b->d_pid, b->d_px, b->d_xc, b->d_ev, b->d_segs, b->d_cks, b->d_F,
                     b->d_vbuf, b->d_cands, b->d_cand_count, b->d_overflow, b->d_totals, b->d_bscratch, b->d_tab6,
                     b->d_hdp_slot, b->d_hdp_y, b->d_hdp_slope, b->d_hdp_grid, b->d_hdp_tab, b->d_prob, b->d_seg_pass, b->d_seg_off,
@@ -1003,12 +1066,12 @@ void sa_batch_destroy(sa_batch_t *b) {
     for (void *p : ptrs)
         if (p) g_sa_pool.put(SaPool::DEVICE, p);
     for (int i = 0; i < 8; i++)
-        if (b->ev[i]) (void) hipEventDestroy(b->ev[i]);
-    for (hipEvent_t e : b->gev) (void) hipEventDestroy(e);
-    for (hipEvent_t e : b->cev) (void) hipEventDestroy(e);
+        g_handles.park(b->ev[i], b->device);
+    for (hipEvent_t e : b->gev) g_handles.park(e, b->device);
+    for (hipEvent_t e : b->cev) g_handles.park(e, b->device);
     for (int i = 0; i < 2; i++)
-        if (b->cstream[i]) (void) hipStreamDestroy(b->cstream[i]);
-    if (b->pair_stream) (void) hipStreamDestroy(b->pair_stream);
+        g_handles.park(b->cstream[i], b->device, 0);
+    g_handles.park(b->pair_stream, b->device, 1);
     g_sa_pool.put(SaPool::PINNED, b->h_pairs);
     g_sa_pool.put(SaPool::DEVICE, b->d_pairs_up);
     g_sa_pool.put(SaPool::PINNED, b->h_seg_off);
@@ -1081,22 +1144,19 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     memset(&b->stats, 0, sizeof(b->stats));
     for (int i = 0; i < 8; i++) b->ev[i] = nullptr;
 #define TRY(x) do { int rc_ = (x); if (rc_) { sa_batch_destroy(b); return rc_; } } while (0)
-    if (hipStreamCreateWithFlags(&b->cstream[0], hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&b->cstream[1], hipStreamNonBlocking) != hipSuccess) {
+    if (g_handles.stream(&b->cstream[0], device, 0) != hipSuccess || g_handles.stream(&b->cstream[1], device, 0) != hipSuccess) {
         sa_batch_destroy(b);
         return SA_ENODEVICE;
     }
     b->stream = b->cstream[0];
     {   // the copy stream outranks the compute streams
-        int prio_lo = 0, prio_hi = 0;
-        (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        if (hipStreamCreateWithPriority(&b->pair_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
+        if (g_handles.stream(&b->pair_stream, device, 1) != hipSuccess) {
             sa_batch_destroy(b);
             return SA_ENODEVICE;
         }
     }
     for (int i = 0; i < 8; i++)
-        if (hipEventCreate(&b->ev[i]) != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
+        if (g_handles.event(&b->ev[i], device) != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
     std::unique_lock<std::mutex> up_lock(g_uploader.mu);
     TRY(g_uploader.bind(device));
     if (trace_c) fprintf(stderr, "[trace] create: upload ring ready at %.1f ms\n", now_ms_c() - tc0);
@@ -1261,9 +1321,9 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
         b->gev.resize(4 * b->groups.size(), nullptr);
         b->cev.resize(2 * b->chunks.size(), nullptr);
         for (auto &e : b->gev)
-            if (hipEventCreate(&e) != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
+            if (g_handles.event(&e, device) != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
         for (auto &e : b->cev)
-            if (hipEventCreate(&e) != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
+            if (g_handles.event(&e, device) != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
         if (g_sa_pool.get(SaPool::PINNED, (void **) &b->h_seg_off, 8 * (size_t) (pl->n_segs + (long long) b->groups.size() + 1),
                           device) != hipSuccess ||
             g_sa_pool.get(SaPool::PINNED, (void **) &b->h_overflow, 64, device) != hipSuccess) {
