@@ -949,6 +949,10 @@ struct SaUploader {
         }
         return SA_OK;
     }
+    int copy_pinned(void *dst, const void *src, size_t bytes) {   // the source is pinned: plain DMA
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+        return SA_OK;
+    }
     int copy(void *dst, const void *src, size_t bytes) {
         const char *s = (const char *) src;
         char *d = (char *) dst;
@@ -1034,6 +1038,16 @@ struct SaHandles {
 };
 static SaHandles g_handles;
 
+// the planner's big arrays as pinned memory of the caching allocator (the device then reads them by plain DMA)
+static void *plan_pinned_alloc(size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    void *p = nullptr;
+    if (g_sa_pool.get(SaPool::PINNED, &p, bytes, dev) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    return p;
+}
+static void plan_pinned_free(void *p, size_t bytes) { (void) bytes; g_sa_pool.put(SaPool::PINNED, p); }
+
 extern "C" void sa_pool_release(void) {
     g_sa_pool.release(SaPool::DEVICE);
     g_sa_pool.release(SaPool::PINNED);
@@ -1042,12 +1056,12 @@ extern "C" void sa_pool_release(void) {
 }
 
 template <typename T>
-static int upload(T **dst, const T *src, long long n, long long pad = 0) {
+static int upload(T **dst, const T *src, long long n, long long pad = 0, bool src_pinned = false) {
     // pad: extra zeroed elements behind the data (kernels that clamp an index may read one element past the end)
     size_t bytes = sizeof(T) * (size_t) (n + pad > 0 ? n + pad : 1);
     HIPCHK(g_sa_pool.get(SaPool::DEVICE, (void **) dst, bytes, g_uploader.device));
     if (pad > 0) HIPCHK(hipMemsetAsync((char *) *dst + sizeof(T) * (size_t) n, 0, sizeof(T) * (size_t) pad, g_uploader.stream));
-    if (n > 0) return g_uploader.copy(*dst, src, sizeof(T) * (size_t) n);
+    if (n > 0) return src_pinned ? g_uploader.copy_pinned(*dst, src, sizeof(T) * (size_t) n) : g_uploader.copy(*dst, src, sizeof(T) * (size_t) n);
     return SA_OK;
 }
 
@@ -1092,6 +1106,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     HIPCHK(hipSetDevice(device));
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    free_b += g_sa_pool.idle_bytes(SaPool::DEVICE, device);   // what destroyed batches left parked is available to this one
     // forward storage gets at most 60% of what is free; 24 B per cell-path
     long long budget = (long long) ((double) free_b * 0.60 / 24.0);
     const char *envb = getenv("SA_F_BUDGET_CELLPATHS");  // test hook: force several passes
@@ -1101,7 +1116,9 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     auto now_ms_c = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double tc0 = now_ms_c();
     sa_plan_t *pl = nullptr;
+    if (SaPool::enabled()) sa_plan_use_allocator(plan_pinned_alloc, plan_pinned_free);
     int rc = sa_plan_build(&pl, m, p, jobs, n_jobs, ambig, flags, budget);
+    sa_plan_use_allocator(nullptr, nullptr);
     if (rc) return rc;
     if (trace_c) fprintf(stderr, "[trace] create: planned at %.1f ms\n", now_ms_c() - tc0);
     sa_batch *b = new sa_batch();
@@ -1161,10 +1178,11 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     TRY(g_uploader.bind(device));
     if (trace_c) fprintf(stderr, "[trace] create: upload ring ready at %.1f ms\n", now_ms_c() - tc0);
     TRY(upload(&b->d_regions, pl->regions, pl->n_regions));
-    TRY(upload(&b->d_rows, pl->rows, pl->n_rows));
-    TRY(upload(&b->d_pk, pl->pk, pl->n_pk));
-    TRY(upload(&b->d_poff, pl->poff, pl->n_poff));
-    TRY(upload(&b->d_pid, pl->pid, pl->n_pid));
+    const bool big_pinned = pl->pooled && pl->big_free == plan_pinned_free;   // the big arrays are pinned: no staging
+    TRY(upload(&b->d_rows, pl->rows, pl->n_rows, 0, big_pinned));
+    TRY(upload(&b->d_pk, pl->pk, pl->n_pk, 0, big_pinned));
+    TRY(upload(&b->d_poff, pl->poff, pl->n_poff, 0, big_pinned));
+    TRY(upload(&b->d_pid, pl->pid, pl->n_pid, 0, big_pinned));
     std::vector<int> px;   // (alive until the uploader has drained)
     {   // cell-path -> reference position, for the memory-resident kernels (one lane per cell-path); register-kernel
         // regions never read it
@@ -1184,9 +1202,9 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
             TRY(upload(&b->d_px, (const int *) nullptr, 0));
         }
     }
-    TRY(upload(&b->d_xc, pl->xc, 4 * pl->n_pid));
+    TRY(upload(&b->d_xc, pl->xc, 4 * pl->n_pid, 0, big_pinned));
     // readable padding behind the events: the kernels clamp event indices to 0 even for reads without events
-    TRY(upload(&b->d_ev, pl->ev, pl->n_ev, 8));
+    TRY(upload(&b->d_ev, pl->ev, pl->n_ev, 8, big_pinned));
     TRY(upload(&b->d_segs, pl->segs, pl->n_segs));
     TRY(upload(&b->d_cks, pl->cks, pl->n_cks));
     {   // model tables

@@ -3,6 +3,7 @@
 #ifndef SA_INTERNAL_H_
 #define SA_INTERNAL_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #include "signalalign_hip.h"
@@ -148,6 +149,8 @@ typedef struct sa_plan {
     int64_t n_fast_regions;
     int64_t max_span;
     int32_t pooled;       /* rows, pk, poff, pid, xc, ev came from plan_big_alloc and go back to its cache */
+    void (*big_free)(void *p, size_t bytes); /* ... or from the caller's allocator (sa_plan_use_allocator): pinned host
+                                              * memory the device reads directly */
     int32_t borrowed;     /* planner thread's sub-plan: rows, pk, poff, pid, xc, ev are slices of the final plan's arrays (sized
                            * exactly by a counting pass): never grown, never freed here */
 } sa_plan_t;
@@ -157,6 +160,10 @@ int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, co
                   const char *const *ambig256, unsigned flags, int64_t chunk_budget_cellpaths);
 void sa_plan_free(sa_plan_t *pl);
 void sa_plan_pool_release(void); /* frees the host blocks the planner keeps between batches */
+/* The calling thread's next sa_plan_build takes the big arrays of a threaded plan from `alloc` and returns them with
+ * `release` (sa_batch_create: pinned memory from the caching allocator, so that the upload is a plain DMA); NULL, NULL
+ * restores the planner's own block cache. */
+void sa_plan_use_allocator(void *(*alloc)(size_t bytes), void (*release)(void *p, size_t bytes));
 /* grows every segment's candidate capacity by `factor` and re-lays out cand_off (overflow retry) */
 void sa_plan_grow_candidates(sa_plan_t *pl, int factor);
 /* after the device pass: turn candidates + totals into the reference's pair list for every job */

@@ -383,6 +383,13 @@ static int plan_pool_on(void) {
     const char *e = getenv("SA_POOL");
     return !(e && atoi(e) == 0);
 }
+static __thread void *(*plan_alloc_hook)(size_t) = NULL;
+static __thread void (*plan_free_hook)(void *, size_t) = NULL;
+void sa_plan_use_allocator(void *(*alloc)(size_t bytes), void (*release)(void *p, size_t bytes)) {
+    plan_alloc_hook = alloc;
+    plan_free_hook = release;
+}
+
 static void *plan_big_alloc(size_t bytes) {
     if (bytes == 0) bytes = 8;
     if (plan_pool_on()) {
@@ -433,7 +440,14 @@ void sa_plan_pool_release(void) {
 void sa_plan_free(sa_plan_t *pl) {
     if (!pl) return;
     free(pl->jobs); free(pl->regions);
-    if (pl->pooled) { /* sizes as allocated by sa_plan_build */
+    if (pl->pooled && pl->big_free) {
+        pl->big_free(pl->rows, sizeof(sa_row_t) * (size_t) (pl->cap_rows > 0 ? pl->cap_rows : 1));
+        pl->big_free(pl->pk, sizeof(int32_t) * (size_t) (pl->cap_pk > 0 ? pl->cap_pk : 1));
+        pl->big_free(pl->poff, sizeof(int32_t) * (size_t) (pl->cap_poff > 0 ? pl->cap_poff : 1));
+        pl->big_free(pl->pid, sizeof(int32_t) * (size_t) (pl->cap_pid > 0 ? pl->cap_pid : 1));
+        pl->big_free(pl->xc, sizeof(double) * 4 * (size_t) (pl->cap_pid > 0 ? pl->cap_pid : 1));
+        pl->big_free(pl->ev, sizeof(double) * (size_t) (pl->cap_ev > 0 ? pl->cap_ev : 1));
+    } else if (pl->pooled) { /* sizes as allocated by sa_plan_build */
         plan_big_free(pl->rows, sizeof(sa_row_t) * (size_t) (pl->cap_rows > 0 ? pl->cap_rows : 1));
         plan_big_free(pl->pk, sizeof(int32_t) * (size_t) (pl->cap_pk > 0 ? pl->cap_pk : 1));
         plan_big_free(pl->poff, sizeof(int32_t) * (size_t) (pl->cap_poff > 0 ? pl->cap_poff : 1));
@@ -980,12 +994,14 @@ int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, co
             }
             pl->pooled = 1;
             pl->cap_rows = tr; pl->cap_pk = tk; pl->cap_poff = to; pl->cap_pid = ti; pl->cap_ev = te;
-            pl->rows = plan_big_alloc(sizeof(sa_row_t) * (size_t) (tr > 0 ? tr : 1));
-            pl->pk = plan_big_alloc(sizeof(int32_t) * (size_t) (tk > 0 ? tk : 1));
-            pl->poff = plan_big_alloc(sizeof(int32_t) * (size_t) (to > 0 ? to : 1));
-            pl->pid = plan_big_alloc(sizeof(int32_t) * (size_t) (ti > 0 ? ti : 1));
-            pl->xc = plan_big_alloc(sizeof(double) * 4 * (size_t) (ti > 0 ? ti : 1));
-            pl->ev = plan_big_alloc(sizeof(double) * (size_t) (te > 0 ? te : 1));
+            void *(*get)(size_t) = plan_alloc_hook ? plan_alloc_hook : plan_big_alloc;
+            pl->big_free = plan_alloc_hook ? plan_free_hook : NULL;
+            pl->rows = get(sizeof(sa_row_t) * (size_t) (tr > 0 ? tr : 1));
+            pl->pk = get(sizeof(int32_t) * (size_t) (tk > 0 ? tk : 1));
+            pl->poff = get(sizeof(int32_t) * (size_t) (to > 0 ? to : 1));
+            pl->pid = get(sizeof(int32_t) * (size_t) (ti > 0 ? ti : 1));
+            pl->xc = get(sizeof(double) * 4 * (size_t) (ti > 0 ? ti : 1));
+            pl->ev = get(sizeof(double) * (size_t) (te > 0 ? te : 1));
             if (!pl->rows || !pl->pk || !pl->poff || !pl->pid || !pl->xc || !pl->ev) rc = SA_ENOMEM;
             tr = tk = to = ti = te = 0;
             for (int t = 0; t < T && rc == SA_OK; t++) {

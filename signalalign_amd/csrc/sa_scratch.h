@@ -148,6 +148,12 @@ struct SaPool {
         (void) known;
         raw_free(kind, p);
     }
+    size_t idle_bytes(int kind, int dev) {
+        std::lock_guard<std::mutex> g(mu);
+        size_t n = 0;
+        for (const Blk &b : idle[kind]) n += b.dev == dev ? b.bytes : 0;
+        return n;
+    }
     void release(int kind) {
         std::vector<Blk> v;
         {
