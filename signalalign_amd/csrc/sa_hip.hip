@@ -1116,7 +1116,10 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     auto now_ms_c = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double tc0 = now_ms_c();
     sa_plan_t *pl = nullptr;
-    if (SaPool::enabled()) sa_plan_use_allocator(plan_pinned_alloc, plan_pinned_free);
+    // pinning memory costs about 0.25 ms per MB: it pays for a process that streams batches (the blocks are reused), not
+    // for the one or two batches of a command-line run, which stage their plan through the uploader's ring instead
+    static std::atomic<int> batches_created(0);
+    if (SaPool::enabled() && batches_created.fetch_add(1) >= 2) sa_plan_use_allocator(plan_pinned_alloc, plan_pinned_free);
     int rc = sa_plan_build(&pl, m, p, jobs, n_jobs, ambig, flags, budget);
     sa_plan_use_allocator(nullptr, nullptr);
     if (rc) return rc;
