@@ -61,6 +61,7 @@ static void usage(void) {
     fprintf(stderr, "-g: traceBackDiagonals, how many backward diagonals to calculate during traceback\n");
     fprintf(stderr, "-r: boolean option if read is RNA\n");
     fprintf(stderr, "--batch <manifest>: align many reads in one process (one GPU batch per strand model)\n");
+    fprintf(stderr, "--batch-reads <n>: reads per GPU batch of a manifest (default 4096)\n");
     fprintf(stderr, "--device <n>: GPU to use\n");
     fprintf(stderr, "--mea: also write <posteriors file>.mea, the rows of the full output on the maximum expected accuracy path\n\n");
 }
@@ -623,10 +624,139 @@ static int outputs_distinct(const read_t *reads, const int64_t *who, int64_t n) 
     return ok;
 }
 
+/* One slice of the run's reads: host side of every read, one GPU batch per strand model, outputs.  Returns the number
+ * of reads that failed.  (The whole manifest used to be one batch: fine for thousands of reads, not for a flow cell.) */
+static int64_t run_slice(run_t *Rp, read_t *reads, int64_t n_reads, int batch_mode, int device) {
+#define R (*Rp)
+    /* ---- host side of every read ---- */
+    int64_t n_ok = 0;
+    {
+        prep_ctx_t pc = {&R, reads, !batch_mode};
+        parallel_for(n_reads, prep_one, &pc);
+        for (int64_t i = 0; i < n_reads; i++) n_ok += reads[i].failed ? 0 : 1;
+    }
+    const strand_model_t *sms[2] = {&R.smt, &R.smc};
+    const int n_strands = R.two_d ? 2 : 1;
+
+    /* ---- the pair-HMM on the GPU: one batch per strand model, all reads side by side ---- */
+    sa_job_t *bj = malloc(sizeof(sa_job_t) * (size_t) (n_ok > 0 ? n_ok : 1));
+    int64_t *who = malloc(sizeof(int64_t) * (size_t) (n_ok > 0 ? n_ok : 1));
+    int64_t k = 0;
+    for (int64_t i = 0; i < n_reads; i++)
+        if (!reads[i].failed) who[k++] = i;
+
+    if (R.expect_mode) { /* impl/signalMachine.c:772-848 */
+        if (n_ok > 0) fprintf(stderr, "Starting expectations routine\n");
+        for (int s = 0; s < n_strands && n_ok > 0; s++) {
+            fprintf(stderr, "signalAlign - getting expectations for %s\n", s == 0 ? "template" : "complement");
+            for (int64_t j = 0; j < n_ok; j++) bj[j] = reads[who[j]].jobs[s];
+            double *trans = malloc(sizeof(double) * 9 * (size_t) n_ok), *lik = calloc((size_t) n_ok, sizeof(double));
+            for (int64_t j = 0; j < 9 * n_ok; j++) trans[j] = 0.001; /* transitionsPseudocount, :785 */
+            sa_assignment_t **as = calloc((size_t) n_ok, sizeof(*as));
+            int64_t *n_as = calloc((size_t) n_ok, sizeof(int64_t));
+            int rc = sa_expect_batch(sms[s]->model, &R.p, bj, n_ok, R.ambig, device, 0, trans, lik, as, n_as);
+            if (rc != SA_OK) {
+                fprintf(stderr, "signalMachine: expectations failed: %s\n", sa_strerror(rc));
+                exit(1);
+            }
+            for (int64_t j = 0; j < n_ok; j++) {
+                read_t *rd = &reads[who[j]];
+                const char *path = s == 0 ? rd->t_expect : rd->c_expect;
+                if (R.hdp)
+                    fprintf(stderr, s == 0 ? "signalAlign - got %" PRId64 " template HDP assignments\n"
+                                           : "signalAlign - got %" PRId64 "complement HDP assignments\n", n_as[j]);
+                if (path != NULL) {
+                    fprintf(stderr, "signalAlign - writing expectations to file: %s\n", path);
+                    write_expectations(path, sms[s], s == 0 ? &rd->np->template_params : &rd->np->complement_params, R.hdp,
+                                       trans + 9 * j, lik[j], &rd->jobs[s], as[j], n_as[j]);
+                }
+                sa_free(as[j]);
+            }
+            free(trans); free(lik); free(as); free(n_as);
+        }
+        for (int64_t j = 0; j < n_ok; j++)
+            fprintf(stderr, "signalAlign - SUCCESS: finished alignment of query %s, exiting\n", reads[who[j]].label);
+        free(bj); free(who);
+        return n_reads - n_ok;
+    }
+
+    sa_pair_t **pairs_s[2] = {NULL, NULL};
+    int64_t *n_pairs_s[2] = {NULL, NULL};
+    sa_pair_t ***pairs = pairs_s;
+    int64_t **n_pairs = n_pairs_s;
+    sa_mea_pair_t **mea_s[2] = {NULL, NULL};
+    int64_t *n_mea_s[2] = {NULL, NULL};
+    sa_mea_pair_t ***mea = mea_s;
+    int64_t **n_mea = n_mea_s;
+    for (int s = 0; s < n_strands; s++) {
+        pairs[s] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(sa_pair_t *));
+        n_pairs[s] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(int64_t));
+        if (n_ok == 0) continue;
+        fprintf(stderr, s == 0 ? "signalAlign - starting template alignment\n" : "signalAlign - starting complement alignment\n");
+        for (int64_t j = 0; j < n_ok; j++) bj[j] = reads[who[j]].jobs[s];
+        int rc;
+        if (!R.mea) {
+            rc = sa_align_batch(sms[s]->model, &R.p, bj, n_ok, R.ambig, device, 0, pairs[s], n_pairs[s]);
+        } else { /* the same batch, kept alive for the path step: its pairs are still on the device */
+            sa_batch_t *b = NULL;
+            mea[s] = calloc((size_t) n_ok, sizeof(sa_mea_pair_t *));
+            n_mea[s] = calloc((size_t) n_ok, sizeof(int64_t));
+            rc = sa_batch_create(&b, sms[s]->model, &R.p, bj, n_ok, R.ambig, device, 0);
+            if (rc == SA_OK) rc = sa_batch_run(b);
+            for (int64_t j = 0; j < n_ok && rc == SA_OK; j++) {
+                sa_batch_n_pairs(b, j, &n_pairs[s][j]);
+                pairs[s][j] = malloc(sizeof(sa_pair_t) * (size_t) (n_pairs[s][j] > 0 ? n_pairs[s][j] : 1));
+                rc = sa_batch_pairs(b, j, pairs[s][j], n_pairs[s][j]);
+            }
+            if (rc == SA_OK) rc = sa_batch_mea(b, 0, mea[s], n_mea[s], NULL, NULL, NULL);
+            sa_batch_destroy(b);
+        }
+        if (rc != SA_OK) {
+            fprintf(stderr, "signalMachine: alignment failed: %s\n", sa_strerror(rc));
+            exit(1);
+        }
+    }
+
+    /* ---- outputs: rendered in parallel (one file per read), summary lines in read order ---- */
+    double (*score)[2] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(*score));
+    {
+        out_job_t oc = {&R, reads, who, pairs, n_pairs, score, mea, n_mea};
+        if (outputs_distinct(reads, who, n_ok)) parallel_for(n_ok, output_one, &oc);
+        else for (int64_t j = 0; j < n_ok; j++) output_one(j, &oc);
+    }
+    for (int64_t j = 0; j < n_ok; j++) {
+        read_t *rd = &reads[who[j]];
+        if (rd->failed) continue;
+        fprintf(stdout, "%s %" PRId64 "\t%" PRId64 "(%f)\t", rd->label, rd->n_guide, n_pairs[0][j], score[j][0]);
+        if (R.two_d) fprintf(stdout, "%" PRId64 "(%f)\n", n_pairs[1][j], score[j][1]);
+        else fprintf(stdout, "\n");
+        fprintf(stderr, "signalAlign - SUCCESS: finished alignment of query %s, exiting\n", rd->label);
+        for (int s = 0; s < n_strands; s++) {
+            sa_free(pairs[s][j]);
+            if (R.mea) sa_free(mea[s][j]);
+        }
+    }
+    int64_t n_failed = 0;
+    for (int64_t i = 0; i < n_reads; i++) n_failed += reads[i].failed ? 1 : 0;
+    for (int s = 0; s < n_strands; s++) { free(pairs[s]); free(n_pairs[s]); if (R.mea) { free(mea[s]); free(n_mea[s]); } }
+    free(score); free(bj); free(who);
+    return n_failed;
+#undef R
+}
+
+/* what a read holds once its outputs are written */
+static void release_read(read_t *rd) {
+    if (rd->pA) sa_cigar_free(rd->pA);
+    if (rd->np) sa_npread_free(rd->np);
+    free(rd->forward_seq); free(rd->backward_seq);
+    for (int s = 0; s < 2; s++) { free(rd->ax[s]); free(rd->ay[s]); rd->ax[s] = rd->ay[s] = NULL; }
+    rd->pA = NULL; rd->np = NULL; rd->forward_seq = rd->backward_seq = NULL;
+}
+
 int main(int argc, char **argv) {
     run_t R;
     memset(&R, 0, sizeof(R));
-    int64_t diag_expansion = 50, trace_back = 50;
+    int64_t diag_expansion = 50, trace_back = 50, batch_reads = 4096;
     double threshold = 0.01;
     int device = 0; /* --device: which GPU of the node (one process per GPU; reads shard across processes) */
     R.constraint_trim = 14;
@@ -660,6 +790,7 @@ int main(int argc, char **argv) {
                                            {"batch", required_argument, 0, 1000},
                                            {"device", required_argument, 0, 1001},
                                            {"mea", no_argument, 0, 1002},
+                                           {"batch-reads", required_argument, 0, 1003},
                                            {0, 0, 0, 0}};
     for (;;) {
         int idx = 0;
@@ -693,6 +824,7 @@ int main(int argc, char **argv) {
             case 1000: manifest = strdup(optarg); break;
             case 1001: device = atoi(optarg); break;
             case 1002: R.mea = 1; break;
+            case 1003: batch_reads = atoll(optarg) > 0 ? atoll(optarg) : batch_reads; break;
             default: usage(); return 1;
         }
     }
@@ -765,119 +897,17 @@ int main(int argc, char **argv) {
         sa_default_ambig(R.ambig);
     }
 
-    /* ---- host side of every read ---- */
-    int64_t n_ok = 0;
-    {
-        prep_ctx_t pc = {&R, reads, !batch_mode};
-        parallel_for(n_reads, prep_one, &pc);
-        for (int64_t i = 0; i < n_reads; i++) n_ok += reads[i].failed ? 0 : 1;
-    }
     if (R.hdp && !R.expect_mode) { /* the alignment branch sets the HDP expected values (impl/signalMachine.c:861-863), the expectation branch does not */
         set_hdp_expected(&R.smt);
         if (R.two_d) set_hdp_expected(&R.smc);
     }
-    const strand_model_t *sms[2] = {&R.smt, &R.smc};
-    const int n_strands = R.two_d ? 2 : 1;
-
-    /* ---- the pair-HMM on the GPU: one batch per strand model, all reads side by side ---- */
-    sa_job_t *bj = malloc(sizeof(sa_job_t) * (size_t) (n_ok > 0 ? n_ok : 1));
-    int64_t *who = malloc(sizeof(int64_t) * (size_t) (n_ok > 0 ? n_ok : 1));
-    int64_t k = 0;
-    for (int64_t i = 0; i < n_reads; i++)
-        if (!reads[i].failed) who[k++] = i;
-
-    if (R.expect_mode) { /* impl/signalMachine.c:772-848 */
-        if (n_ok > 0) fprintf(stderr, "Starting expectations routine\n");
-        for (int s = 0; s < n_strands && n_ok > 0; s++) {
-            fprintf(stderr, "signalAlign - getting expectations for %s\n", s == 0 ? "template" : "complement");
-            for (int64_t j = 0; j < n_ok; j++) bj[j] = reads[who[j]].jobs[s];
-            double *trans = malloc(sizeof(double) * 9 * (size_t) n_ok), *lik = calloc((size_t) n_ok, sizeof(double));
-            for (int64_t j = 0; j < 9 * n_ok; j++) trans[j] = 0.001; /* transitionsPseudocount, :785 */
-            sa_assignment_t **as = calloc((size_t) n_ok, sizeof(*as));
-            int64_t *n_as = calloc((size_t) n_ok, sizeof(int64_t));
-            int rc = sa_expect_batch(sms[s]->model, &R.p, bj, n_ok, R.ambig, device, 0, trans, lik, as, n_as);
-            if (rc != SA_OK) {
-                fprintf(stderr, "signalMachine: expectations failed: %s\n", sa_strerror(rc));
-                return 1;
-            }
-            for (int64_t j = 0; j < n_ok; j++) {
-                read_t *rd = &reads[who[j]];
-                const char *path = s == 0 ? rd->t_expect : rd->c_expect;
-                if (R.hdp)
-                    fprintf(stderr, s == 0 ? "signalAlign - got %" PRId64 " template HDP assignments\n"
-                                           : "signalAlign - got %" PRId64 "complement HDP assignments\n", n_as[j]);
-                if (path != NULL) {
-                    fprintf(stderr, "signalAlign - writing expectations to file: %s\n", path);
-                    write_expectations(path, sms[s], s == 0 ? &rd->np->template_params : &rd->np->complement_params, R.hdp,
-                                       trans + 9 * j, lik[j], &rd->jobs[s], as[j], n_as[j]);
-                }
-                sa_free(as[j]);
-            }
-            free(trans); free(lik); free(as); free(n_as);
-        }
-        for (int64_t j = 0; j < n_ok; j++)
-            fprintf(stderr, "signalAlign - SUCCESS: finished alignment of query %s, exiting\n", reads[who[j]].label);
-        return n_ok == n_reads ? 0 : 1;
-    }
-
-    sa_pair_t **pairs_s[2] = {NULL, NULL};
-    int64_t *n_pairs_s[2] = {NULL, NULL};
-    sa_pair_t ***pairs = pairs_s;
-    int64_t **n_pairs = n_pairs_s;
-    sa_mea_pair_t **mea_s[2] = {NULL, NULL};
-    int64_t *n_mea_s[2] = {NULL, NULL};
-    sa_mea_pair_t ***mea = mea_s;
-    int64_t **n_mea = n_mea_s;
-    for (int s = 0; s < n_strands; s++) {
-        pairs[s] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(sa_pair_t *));
-        n_pairs[s] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(int64_t));
-        if (n_ok == 0) continue;
-        fprintf(stderr, s == 0 ? "signalAlign - starting template alignment\n" : "signalAlign - starting complement alignment\n");
-        for (int64_t j = 0; j < n_ok; j++) bj[j] = reads[who[j]].jobs[s];
-        int rc;
-        if (!R.mea) {
-            rc = sa_align_batch(sms[s]->model, &R.p, bj, n_ok, R.ambig, device, 0, pairs[s], n_pairs[s]);
-        } else { /* the same batch, kept alive for the path step: its pairs are still on the device */
-            sa_batch_t *b = NULL;
-            mea[s] = calloc((size_t) n_ok, sizeof(sa_mea_pair_t *));
-            n_mea[s] = calloc((size_t) n_ok, sizeof(int64_t));
-            rc = sa_batch_create(&b, sms[s]->model, &R.p, bj, n_ok, R.ambig, device, 0);
-            if (rc == SA_OK) rc = sa_batch_run(b);
-            for (int64_t j = 0; j < n_ok && rc == SA_OK; j++) {
-                sa_batch_n_pairs(b, j, &n_pairs[s][j]);
-                pairs[s][j] = malloc(sizeof(sa_pair_t) * (size_t) (n_pairs[s][j] > 0 ? n_pairs[s][j] : 1));
-                rc = sa_batch_pairs(b, j, pairs[s][j], n_pairs[s][j]);
-            }
-            if (rc == SA_OK) rc = sa_batch_mea(b, 0, mea[s], n_mea[s], NULL, NULL, NULL);
-            sa_batch_destroy(b);
-        }
-        if (rc != SA_OK) {
-            fprintf(stderr, "signalMachine: alignment failed: %s\n", sa_strerror(rc));
-            return 1;
-        }
-    }
-
-    /* ---- outputs: rendered in parallel (one file per read), summary lines in read order ---- */
-    double (*score)[2] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(*score));
-    {
-        out_job_t oc = {&R, reads, who, pairs, n_pairs, score, mea, n_mea};
-        if (outputs_distinct(reads, who, n_ok)) parallel_for(n_ok, output_one, &oc);
-        else for (int64_t j = 0; j < n_ok; j++) output_one(j, &oc);
-    }
-    for (int64_t j = 0; j < n_ok; j++) {
-        read_t *rd = &reads[who[j]];
-        if (rd->failed) continue;
-        fprintf(stdout, "%s %" PRId64 "\t%" PRId64 "(%f)\t", rd->label, rd->n_guide, n_pairs[0][j], score[j][0]);
-        if (R.two_d) fprintf(stdout, "%" PRId64 "(%f)\n", n_pairs[1][j], score[j][1]);
-        else fprintf(stdout, "\n");
-        fprintf(stderr, "signalAlign - SUCCESS: finished alignment of query %s, exiting\n", rd->label);
-        for (int s = 0; s < n_strands; s++) {
-            sa_free(pairs[s][j]);
-            if (R.mea) sa_free(mea[s][j]);
-        }
-    }
+    /* the reads go through in slices of --batch-reads (default 4096): bounded host and device memory for any manifest */
     int64_t n_failed = 0;
-    for (int64_t i = 0; i < n_reads; i++) n_failed += reads[i].failed ? 1 : 0;
+    for (int64_t off = 0; off < n_reads; off += batch_reads) {
+        const int64_t n = n_reads - off < batch_reads ? n_reads - off : batch_reads;
+        n_failed += run_slice(&R, reads + off, n, batch_mode, device);
+        for (int64_t i = 0; i < n; i++) release_read(&reads[off + i]);
+    }
     if (batch_mode)
         fprintf(stderr, "[signalMachine] batch: %" PRId64 " of %" PRId64 " reads aligned\n", n_reads - n_failed, n_reads);
     return n_failed == 0 ? 0 : 1;

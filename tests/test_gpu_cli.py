@@ -226,6 +226,19 @@ def test_signalmachine_batch_front_door(oracle, tmp_path):
         assert single_out[name][1] in pr.stdout
         assert "signalAlign - SUCCESS: finished alignment of query %s, exiting" % name in pr.stderr
     assert not os.path.exists(str(tmp_path / "broken.tsv"))
+    # the same manifest in slices of two reads (--batch-reads): several GPU batches in one process, the storage of one
+    # reused by the next, identical files (appended a second time) and the same summary
+    pr = subprocess.run([BIN] + common + ["--batch", manifest, "--batch-reads", "2", "--mea"], capture_output=True, text=True,
+                        timeout=600)
+    assert pr.returncode == 1 and "3 of 4 reads aligned" in pr.stderr
+    for name, _, _ in specs:
+        assert open(str(tmp_path / (name + ".batch.tsv"))).read() == 2 * single_out[name][0], name
+        assert single_out[name][1] in pr.stdout
+        mea_rows = open(str(tmp_path / (name + ".batch.tsv.mea"))).readlines()
+        full_rows = set(single_out[name][0].splitlines(True))
+        assert len(mea_rows) > 0 and all(row in full_rows for row in mea_rows)
+        events = [int(row.split("\t")[5]) for row in mea_rows]
+        assert events == sorted(set(events))               # one row per event, ascending
 
 
 def _revcomp(s):
