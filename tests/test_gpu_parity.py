@@ -286,3 +286,25 @@ def test_against_committed_expected_outputs(name, npread, model, nhdp):
     assert st.n_fast_regions == st.n_regions
     cases.compare_pairs(got[0], exp, TOL_E7, p.threshold)
     assert cases.same_order(got[0], exp)
+
+
+def test_storage_reuse_across_batches_and_release(oracle):
+    """Batches take their storage from caching allocators: a second, DIFFERENT batch built from the blocks of a destroyed
+    one (stale bytes in every buffer) gives the same pairs as in a fresh process state, and sa_pool_release() leaves the
+    library usable."""
+    import ctypes as C
+    pm, om = _models(oracle, cases.MODEL_6MER)
+    p = sa.default_params()
+    jobs_a = cases.synthetic_jobs(cases.MODEL_6MER, 6, 1100, 50)
+    jobs_b = cases.synthetic_jobs(cases.MODEL_6MER, 5, 1300, 900)
+    sa.lib().sa_pool_release()
+    fresh_b, _ = _run(pm, p, jobs_b)
+    sa.lib().sa_pool_release()
+    _run(pm, p, jobs_a)                       # its blocks are parked when it is destroyed ...
+    reused_b, _ = _run(pm, p, jobs_b)         # ... and serve this one
+    for x, y in zip(fresh_b, reused_b):
+        assert np.array_equal(x, y)
+    sa.lib().sa_pool_release()
+    again_b, _ = _run(pm, p, jobs_b)
+    for x, y in zip(fresh_b, again_b):
+        assert np.array_equal(x, y)
