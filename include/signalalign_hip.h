@@ -130,6 +130,10 @@ int sa_load_ambig(const char *path, const char **map256);
 int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs,
                     int64_t n_jobs, const char *const *ambig256, int device, unsigned flags);
 int sa_batch_run(sa_batch_t *b);
+/* The same on a thread of the library's own: sa_batch_start returns at once, sa_batch_wait returns sa_batch_run's code.
+ * Lets one caller thread plan the next batch (sa_batch_create is host work) while this one is on the GPU. */
+int sa_batch_start(sa_batch_t *b);
+int sa_batch_wait(sa_batch_t *b);
 int sa_batch_n_pairs(const sa_batch_t *b, int64_t job, int64_t *n);
 int sa_batch_pairs(const sa_batch_t *b, int64_t job, sa_pair_t *out, int64_t cap);
 int sa_batch_stats(const sa_batch_t *b, sa_batch_stats_t *out);

@@ -26,6 +26,8 @@
 
 #include <algorithm>
 #include <mutex>
+#include <new>
+#include <thread>
 #include <time.h>
 #include <vector>
 
@@ -882,6 +884,8 @@ struct sa_batch {
     sa_pair_t *d_pairs_up;                // host-finalised pairs uploaded for a downstream device step (sa_batch_mea)
     long long d_pairs_up_cap;
     bool ran;
+    std::thread *runner;   // sa_batch_start .. sa_batch_wait
+    int runner_rc;
     sa_batch_stats_t stats;
     hipEvent_t ev[8];
 };
@@ -1067,6 +1071,7 @@ static int upload(T **dst, const T *src, long long n, long long pad = 0, bool sr
 
 void sa_batch_destroy(sa_batch_t *b) {
     if (!b) return;
+    if (b->runner) { b->runner->join(); delete b->runner; b->runner = nullptr; }
     if (b->device >= 0) (void) hipSetDevice(b->device);
     // the storage goes back to the caching allocators without the implicit synchronisation of hipFree: nothing of this
     // batch may still be in flight (only possible after an error inside a run)
@@ -1134,6 +1139,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     b->h_seg_off = nullptr;
     b->h_overflow = nullptr;
     b->ran = false;
+    b->runner = nullptr; b->runner_rc = SA_OK;
     b->d_regions = nullptr; b->d_rows = nullptr; b->d_pk = nullptr; b->d_poff = nullptr; b->d_pid = nullptr; b->d_px = nullptr; b->d_xc = nullptr;
     b->d_ev = nullptr; b->d_segs = nullptr; b->d_cks = nullptr; b->d_F = nullptr; b->d_vbuf = nullptr;
     b->d_cands = nullptr; b->d_cand_count = nullptr; b->d_overflow = nullptr; b->d_totals = nullptr;
@@ -1688,6 +1694,24 @@ int sa_batch_device_view(sa_batch_t *b, const sa_pair_t **pairs, std::vector<lon
     *pairs = b->d_pairs_up;
     for (size_t j = 0; j < nj; j++) (*first)[j] = b->job_off[j];
     return SA_OK;
+}
+
+// sa_batch_run on a thread of the library's own, so that the caller can plan the next batch (sa_batch_create is host
+// work) while this one is on the GPU; sa_batch_wait joins it and returns sa_batch_run's code.
+int sa_batch_start(sa_batch_t *b) {
+    if (!b) return SA_EINVAL;
+    if (b->runner) return SA_ESTATE;
+    b->runner_rc = SA_OK;
+    b->runner = new (std::nothrow) std::thread([b]() { b->runner_rc = sa_batch_run(b); });
+    return b->runner ? SA_OK : SA_ENOMEM;
+}
+int sa_batch_wait(sa_batch_t *b) {
+    if (!b) return SA_EINVAL;
+    if (!b->runner) return SA_ESTATE;
+    b->runner->join();
+    delete b->runner;
+    b->runner = nullptr;
+    return b->runner_rc;
 }
 
 int sa_batch_n_pairs(const sa_batch_t *b, int64_t job, int64_t *n) {

@@ -308,3 +308,33 @@ def test_storage_reuse_across_batches_and_release(oracle):
     again_b, _ = _run(pm, p, jobs_b)
     for x, y in zip(fresh_b, again_b):
         assert np.array_equal(x, y)
+
+
+def test_start_wait_overlaps_batches(oracle):
+    """sa_batch_start / sa_batch_wait: two batches in flight (the second planned while the first is on the GPU) give what
+    two serial runs give; waiting twice or starting twice is a state error."""
+    pm, om = _models(oracle, cases.MODEL_6MER)
+    p = sa.default_params()
+    jobs_a = cases.synthetic_jobs(cases.MODEL_6MER, 5, 1200, 10)
+    jobs_b = cases.synthetic_jobs(cases.MODEL_6MER, 4, 900, 700)
+    want_a, _ = _run(pm, p, jobs_a)
+    want_b, _ = _run(pm, p, jobs_b)
+    a = sa.Batch(pm, p, jobs_a)
+    a.start()
+    with pytest.raises(sa.SaError):
+        a.start()
+    b = sa.Batch(pm, p, jobs_b)
+    b.start()
+    a.wait()
+    b.wait()
+    with pytest.raises(sa.SaError):
+        a.wait()
+    for j in range(len(jobs_a)):
+        assert np.array_equal(a.pairs(j), want_a[j])
+    for j in range(len(jobs_b)):
+        assert np.array_equal(b.pairs(j), want_b[j])
+    a.close()
+    c = sa.Batch(pm, p, jobs_a)
+    c.start()
+    c.close()                                  # destroying a started batch joins it first
+    b.close()
