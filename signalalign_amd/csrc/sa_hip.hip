@@ -821,6 +821,44 @@ __global__ __launch_bounds__(64) void k_gather(DevPlan P, int seg0, int n_segs, 
 }
 
 
+// Emission constants per (reference position, path) with the read's scale / shift / var folded in -- what fill_xc of the
+// planner computes (sa_plan.c), here on the device: 32 bytes per path that the host neither has to write nor to upload.
+// One block per region.  The per-k-mer logarithms come from tab6 (computed once per batch on the host with the C
+// library's log), so the values are bit-identical to the host's.
+__global__ __launch_bounds__(256) void k_fill_xc(const sa_region_t *__restrict__ regions, const int *__restrict__ poff_all,
+                                                 const int *__restrict__ pid_all, const double *__restrict__ tab6,
+                                                 const int *__restrict__ hdp_slot, long long hdp_grid_length, double4 *xc) {
+    const sa_region_t *R = &regions[blockIdx.x];
+    const int *poff = poff_all + R->poff_off;
+    const int *pid = pid_all + R->pid_off;
+    const long long n = poff[R->lX + 1];
+    double4 *o = xc + R->pid_off;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+        const int id = pid[i];
+        double4 v;
+        if (hdp_slot) {   // e' = e/var - v.x; v.y = byte offset of the k-mer's {y, slope} row (or past the table: no density)
+            const double mu = id >= 0 ? tab6[6ll * id] : 0.0;
+            const int slot = id >= 0 ? hdp_slot[id] : -1;
+            v.x = ((R->scale - R->var) * mu + R->shift) / R->var;
+            v.y = slot >= 0 ? (double) ((long long) slot * hdp_grid_length * 16) : (double) SA_HDP_FAST_MAX_BYTES;
+            v.z = 0.0; v.w = 0.0;
+        } else if (id < 0) {   // NULL k-mer: both emissions are log(0); inv_s = 1 keeps (e - m) * inv_s finite
+            v.x = 0.0; v.y = 1.0; v.z = NEG_INF; v.w = NEG_INF;
+        } else {
+            const double mu = tab6[6ll * id], sd = tab6[6ll * id + 1], c = tab6[6ll * id + 2], cy = tab6[6ll * id + 4];
+            v.x = R->scale * mu + R->shift;
+            if (c == NEG_INF) {   // sd == 0: emissions_signal_logGaussPdf returns LOG_ZERO
+                v.y = 1.0; v.z = NEG_INF; v.w = NEG_INF;
+            } else {
+                v.y = 1.0 / (R->var * sd);
+                v.z = R->lvar + c;
+                v.w = R->lvar + cy;
+            }
+        }
+        o[i] = v;
+    }
+}
+
 // ===================================================================================================
 // host runtime
 // ===================================================================================================
@@ -1125,7 +1163,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     // for the one or two batches of a command-line run, which stage their plan through the uploader's ring instead
     static std::atomic<int> batches_created(0);
     if (SaPool::enabled() && batches_created.fetch_add(1) >= 2) sa_plan_use_allocator(plan_pinned_alloc, plan_pinned_free);
-    int rc = sa_plan_build(&pl, m, p, jobs, n_jobs, ambig, flags, budget);
+    int rc = sa_plan_build(&pl, m, p, jobs, n_jobs, ambig, flags | SA_FLAG_DEVICE_XC_INTERNAL, budget);
     sa_plan_use_allocator(nullptr, nullptr);
     if (rc) return rc;
     if (trace_c) fprintf(stderr, "[trace] create: planned at %.1f ms\n", now_ms_c() - tc0);
@@ -1211,7 +1249,6 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
             TRY(upload(&b->d_px, (const int *) nullptr, 0));
         }
     }
-    TRY(upload(&b->d_xc, pl->xc, 4 * pl->n_pid, 0, big_pinned));
     // readable padding behind the events: the kernels clamp event indices to 0 even for reads without events
     TRY(upload(&b->d_ev, pl->ev, pl->n_ev, 8, big_pinned));
     TRY(upload(&b->d_segs, pl->segs, pl->n_segs));
@@ -1247,6 +1284,18 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
             }
             TRY(upload(&b->d_hdp_tab, tab.data(), (long long) tab.size()));
         }
+    }
+    {   // emission constants, on the device (same stream as the uploads they read)
+        if (g_sa_pool.get(SaPool::DEVICE, (void **) &b->d_xc, sizeof(double) * 4 * (size_t) (pl->n_pid > 0 ? pl->n_pid : 1), device) !=
+            hipSuccess) {
+            sa_batch_destroy(b);
+            return SA_ENOMEM;
+        }
+        if (pl->n_regions > 0)
+            hipLaunchKernelGGL(k_fill_xc, dim3((unsigned) pl->n_regions), dim3(256), 0, g_uploader.stream, b->d_regions, b->d_poff,
+                               b->d_pid, b->d_tab6, m->hdp ? b->d_hdp_slot : (const int *) nullptr,
+                               m->hdp ? (long long) m->hdp->grid_length : 0ll, reinterpret_cast<double4 *>(b->d_xc));
+        if (hipGetLastError() != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
     }
     TRY(g_uploader.drain());
     up_lock.unlock();

@@ -18,6 +18,8 @@ extern "C" {
 #define SA_LOG_GAPX (-2.3025850929940455) /* log(0.1): impl/stateMachine.c:1584-1586, :1394 */
 #define SA_GAPY_SD_MULT 1.75          /* EXTRA_EVENT_NOISE_MULTIPLIER, inc/stateMachine.h:34 */
 #define SA_FLAG_EXPECT_INTERNAL 0x10000u /* sa_expect_batch: expectation pass instead of posteriors */
+#define SA_FLAG_DEVICE_XC_INTERNAL 0x20000u /* sa_batch_create: the emission constants (xc) are filled on the device; the
+                                             * planner leaves pl->xc NULL */
 #define SA_CAND_EPS 1e-6              /* slack of the on-device candidate filter (see sa_hip.hip) */
 
 /* ---- model (host) ---------------------------------------------------------------------------- */

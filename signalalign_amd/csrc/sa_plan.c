@@ -445,7 +445,7 @@ void sa_plan_free(sa_plan_t *pl) {
         pl->big_free(pl->pk, sizeof(int32_t) * (size_t) (pl->cap_pk > 0 ? pl->cap_pk : 1));
         pl->big_free(pl->poff, sizeof(int32_t) * (size_t) (pl->cap_poff > 0 ? pl->cap_poff : 1));
         pl->big_free(pl->pid, sizeof(int32_t) * (size_t) (pl->cap_pid > 0 ? pl->cap_pid : 1));
-        pl->big_free(pl->xc, sizeof(double) * 4 * (size_t) (pl->cap_pid > 0 ? pl->cap_pid : 1));
+        if (pl->xc) pl->big_free(pl->xc, sizeof(double) * 4 * (size_t) (pl->cap_pid > 0 ? pl->cap_pid : 1));
         pl->big_free(pl->ev, sizeof(double) * (size_t) (pl->cap_ev > 0 ? pl->cap_ev : 1));
     } else if (pl->pooled) { /* sizes as allocated by sa_plan_build */
         plan_big_free(pl->rows, sizeof(sa_row_t) * (size_t) (pl->cap_rows > 0 ? pl->cap_rows : 1));
@@ -801,7 +801,7 @@ static void *plan_worker(void *arg) {
     plan_worker_t *w = arg;
     w->rc = SA_OK;
     for (int64_t j = 0; j < w->n && w->rc == SA_OK; j++) w->rc = plan_job(w->pl, j, &w->jobs[j], w->ambig);
-    if (w->rc == SA_OK) w->rc = fill_xc(w->pl);
+    if (w->rc == SA_OK && !(w->pl->flags & SA_FLAG_DEVICE_XC_INTERNAL)) w->rc = fill_xc(w->pl);
     if (w->rc == SA_OK && w->pl->borrowed &&
         (w->pl->n_rows != w->pl->cap_rows || w->pl->n_pk != w->pl->cap_pk || w->pl->n_poff != w->pl->cap_poff ||
          w->pl->n_pid != w->pl->cap_pid || w->pl->n_ev != w->pl->cap_ev))
@@ -1000,15 +1000,16 @@ int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, co
             pl->pk = get(sizeof(int32_t) * (size_t) (tk > 0 ? tk : 1));
             pl->poff = get(sizeof(int32_t) * (size_t) (to > 0 ? to : 1));
             pl->pid = get(sizeof(int32_t) * (size_t) (ti > 0 ? ti : 1));
-            pl->xc = get(sizeof(double) * 4 * (size_t) (ti > 0 ? ti : 1));
+            pl->xc = (flags & SA_FLAG_DEVICE_XC_INTERNAL) ? NULL : get(sizeof(double) * 4 * (size_t) (ti > 0 ? ti : 1));
             pl->ev = get(sizeof(double) * (size_t) (te > 0 ? te : 1));
-            if (!pl->rows || !pl->pk || !pl->poff || !pl->pid || !pl->xc || !pl->ev) rc = SA_ENOMEM;
+            if (!pl->rows || !pl->pk || !pl->poff || !pl->pid || (!pl->xc && !(flags & SA_FLAG_DEVICE_XC_INTERNAL)) || !pl->ev)
+                rc = SA_ENOMEM;
             tr = tk = to = ti = te = 0;
             for (int t = 0; t < T && rc == SA_OK; t++) {
                 sa_plan_t *s = W[t].pl;
                 s->borrowed = 1;
                 s->rows = pl->rows + tr; s->pk = pl->pk + tk; s->poff = pl->poff + to; s->pid = pl->pid + ti;
-                s->xc = pl->xc + 4 * ti; s->ev = pl->ev + te;
+                s->xc = pl->xc ? pl->xc + 4 * ti : NULL; s->ev = pl->ev + te;
                 tr += s->cap_rows; tk += s->cap_pk; to += s->cap_poff; ti += s->cap_pid; te += s->cap_ev;
             }
         }
