@@ -311,7 +311,7 @@ __global__ __launch_bounds__(128) void k_fwd_generic(DevPlan P, const int *regio
     __syncthreads();
     for (long long d = 1; d <= N; d++) {
         sa_row_t rd = rows[d], r1 = rows[d - 1];
-        sa_row_t r2 = {0, 0, 0, 0, 0};
+        sa_row_t r2 = {0, 0, 0};
         if (d >= 2) r2 = rows[d - 2];
         long long x0 = (d + rd.xmyL) >> 1;
         long long x01 = (d - 1 + r1.xmyL) >> 1;
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(128) void k_bwd_generic(DevPlan P, const int *seg_i
             return in_lds ? lring + (row % 3) * (long long) ring_cap * 3 : gring + (row % 3) * grow * 3;
         };
         double *Be = row_ptr(e, x0, re.width);
-        sa_row_t r1 = {0, 0, 0, 0, 0}, r2 = {0, 0, 0, 0, 0};
+        sa_row_t r1 = {0, 0, 0}, r2 = {0, 0, 0};
         long long x01 = 0, x02 = 0;
         const double *B1 = nullptr, *B2 = nullptr;
         if (e + 1 <= start) {
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(128) void k_bwd_generic(DevPlan P, const int *seg_i
         {
             const sa_row_t rm1 = rows[e - 1];
             const bool have2 = e - 2 >= to && e - 2 >= 0;
-            sa_row_t rm2 = {0, 0, 0, 0, 0};
+            sa_row_t rm2 = {0, 0, 0};
             if (have2) rm2 = rows[e - 2];
             const long long x0m1 = (e - 1 + rm1.xmyL) >> 1, x0m2 = have2 ? (e - 2 + rm2.xmyL) >> 1 : 0;
             const double lim = Mc + P.log_thr - SA_CAND_EPS;

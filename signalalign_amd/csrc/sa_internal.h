@@ -54,9 +54,7 @@ typedef struct sa_row {
     int32_t xmyL;  /* smallest x-y on this anti-diagonal */
     int32_t width; /* cells                               */
     int64_t foff;  /* offset (cell-paths) of the row inside the region's forward storage */
-    int32_t span3; /* lanes needed to hold this diagonal, the two before it and one neighbour each side */
-    int32_t pad;
-} sa_row_t;
+} sa_row_t;        /* 16 bytes per anti-diagonal: with 9000 diagonals per read the largest array of a plan */
 
 enum { SA_KIND_GENERIC = 0, SA_KIND_FAST = 1 };
 

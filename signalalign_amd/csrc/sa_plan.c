@@ -506,25 +506,26 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
 
     /* band */
     int64_t *lo = malloc(sizeof(int64_t) * (N + 1)), *hi = malloc(sizeof(int64_t) * (N + 1));
-    if (!lo || !hi) {
-        free(lo); free(hi);
+    int32_t *span3 = malloc(sizeof(int32_t) * (N + 1));
+    if (!lo || !hi || !span3) {
+        free(lo); free(hi); free(span3);
         return SA_ENOMEM;
     }
     int rcode = sa_band_rows(ax, ay, na, lX, lY, p->diagonal_expansion, lo, hi);
     if (rcode) {
-        free(lo); free(hi);
+        free(lo); free(hi); free(span3);
         return rcode;
     }
     if (pl->n_rows + N + 1 > pl->cap_rows) {
         if (pl->borrowed) {
-            free(lo); free(hi);
+            free(lo); free(hi); free(span3);
             return SA_EINVAL; /* the counting pass undercounted */
         }
         int64_t nc = pl->cap_rows ? pl->cap_rows * 2 : 4096;
         while (nc < pl->n_rows + N + 1) nc *= 2;
         void *np_ = realloc(pl->rows, sizeof(sa_row_t) * (size_t) nc);
         if (!np_) {
-            free(lo); free(hi);
+            free(lo); free(hi); free(span3);
             return SA_ENOMEM;
         }
         pl->rows = np_;
@@ -563,8 +564,7 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
             if (l2 < wl) wl = l2;
             if (r2 > wr) wr = r2;
         }
-        rows[d].span3 = (int32_t) (wr - wl + 1);
-        rows[d].pad = 0;
+        span3[d] = (int32_t) (wr - wl + 1); /* lanes needed to hold this diagonal, the two before it and one neighbour each side */
         if (wr - wl + 1 > span) span = wr - wl + 1;
     }
     /* packed band words for the register kernels */
@@ -578,8 +578,8 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
             int64_t uL = ((int64_t) rows[d].xmyL + K) >> 1;
             int64_t w = rows[d].width;
             int32_t word = (int32_t) ((w > SA_PK_WIDTH_MASK ? SA_PK_WIDTH_MASK : w) | ((uint32_t) uL << SA_PK_SHIFT));
-            if (rows[d].span3 <= 64) word |= SA_PK_FWD;
-            if (rows[d + 2 <= N ? d + 2 : N].span3 <= 64) word |= SA_PK_BWD;
+            if (span3[d] <= 64) word |= SA_PK_FWD;
+            if (span3[d + 2 <= N ? d + 2 : N] <= 64) word |= SA_PK_BWD;
             pk[SA_PK_PAD + d] = word;
         }
         pl->n_pk += N + 1 + SA_PK_PAD + 160;
@@ -609,7 +609,7 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
         S->from = d - (at_end ? 0 : p->trace_back_diagonals + 1);
         S->to = traced_to;
         if (S->from <= S->to) { /* would violate traceBackDiagonals+1 < minDiagsBetweenTraceBack */
-            free(lo); free(hi);
+            free(lo); free(hi); free(span3);
             return SA_EINVAL;
         }
         for (int64_t e = S->to + 2; e <= S->start; e++) {
@@ -658,6 +658,7 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
     }
     free(lo);
     free(hi);
+    free(span3);
     pl->jobs[job].cells_fwd += cf;
     pl->jobs[job].cells_bwd += cb;
     pl->cells_fwd += cf;
