@@ -202,6 +202,12 @@ int sa_event_align_batch(const sa_model_t *m, const sa_ea_job_t *jobs, int64_t n
  * calls serialise on it); this returns the memory.  Safe to call at any time, also when nothing is held. */
 void sa_event_align_release(void);
 
+/* fastaHandler_getSubSequence (impl/fasta_handler.c:15-44, htslib faidx underneath): bases [start, end) of the record
+ * `name` (the header's first word) of a FASTA file; strand == 0 asks htslib for [end, start - 1] as the reference does.
+ * Uses <path>.fai when it exists, otherwise scans the file (nothing is written).  *out is freed with sa_free.
+ * SA_EIO: file unreadable; SA_EINVAL: no such record. */
+int sa_fasta_subsequence(const char *fasta_path, const char *name, int64_t start, int64_t end, int strand, char **out);
+
 /* Batches take their device and pinned-host storage from a caching allocator: what a destroyed batch held is kept and
  * handed to the next one (a pipeline that sees every read once creates and destroys a batch per few thousand reads;
  * allocation and release of its 25 GB cost more than its kernels).  sa_pool_release() returns everything that is

@@ -77,7 +77,7 @@ EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alp
            "sa_model_set_to_hdp_expected_values", "sa_kmer_id", "sa_default_ambig", "sa_load_ambig",
            "sa_batch_create", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_stats",
            "sa_batch_job_cells", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_plan_describe", "sa_plan_digest",
-           "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_strerror",
+           "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_fasta_subsequence", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_strerror",
            "sa_version", "sa_free"]
 
 
@@ -129,6 +129,7 @@ def lib():
     L.sa_batch_stats.argtypes = [C.c_void_p, C.POINTER(BatchStats)]
     L.sa_batch_job_cells.argtypes = [C.c_void_p, C.c_int64, dp, dp]
     L.sa_batch_destroy.argtypes = [C.c_void_p]
+    L.sa_fasta_subsequence.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
     L.sa_batch_start.argtypes = [C.c_void_p]
     L.sa_batch_wait.argtypes = [C.c_void_p]
     L.sa_plan_describe.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Job), C.POINTER(C.c_char_p), C.c_uint,

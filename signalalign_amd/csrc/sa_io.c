@@ -330,6 +330,16 @@ int sa_cigar_load(const char *path, sa_cigar_t **out) {
 }
 
 /* ---- FASTA through its .fai index ---------------------------------------------------------------- */
+/* fastaHandler_getSubSequence (impl/fasta_handler.c:15-44): [start, end) of the named record on the forward strand, the
+ * htslib interval [end, start - 1] (what the reference asks for) otherwise */
+int sa_fasta_subsequence(const char *fasta_path, const char *name, int64_t start, int64_t end, int strand, char **out) {
+    if (!fasta_path || !name || !out) return SA_EINVAL;
+    int err = 0;
+    *out = strand ? sa_fasta_fetch(fasta_path, name, start, end - 1, &err) : sa_fasta_fetch(fasta_path, name, end, start - 1, &err);
+    if (*out == NULL) return err == -2 ? SA_EINVAL : SA_EIO;
+    return SA_OK;
+}
+
 char *sa_fasta_fetch(const char *fasta_path, const char *name, int64_t start, int64_t end_incl, int *err) {
     if (err) *err = 0;
     size_t pl = strlen(fasta_path);
@@ -338,8 +348,54 @@ char *sa_fasta_fetch(const char *fasta_path, const char *name, int64_t start, in
     memcpy(fai + pl, ".fai", 5);
     FILE *fi = fopen(fai, "r");
     free(fai);
-    if (!fi) { if (err) *err = -1; return NULL; }
     long long len = -1, off = 0, bases = 0, width = 0;
+    if (!fi) {
+        /* no index next to the FASTA: htslib's fai_load (impl/fasta_handler.c:19) would build one; here the record is
+         * located by scanning, nothing is written */
+        FILE *fs = fopen(fasta_path, "r");
+        if (!fs) { if (err) *err = -1; return NULL; }
+        const size_t name_len = strlen(name);
+        long long pos = 0, rec_len = 0, rec_off = 0, rec_bases = 0, rec_width = 0, line_start = 0, line_bases = 0;
+        int in_header = 0, match = 0, hdr_i = 0, hdr_ok = 1, first_line = 0, ch;
+        char hdr[256];
+        while (1) {
+            ch = fgetc(fs);
+            if (ch == EOF || (ch == '>' && pos == line_start)) {
+                if (match) { len = rec_len; off = rec_off; bases = rec_bases; width = rec_width; break; }
+                if (ch == EOF) break;
+                in_header = 1; hdr_i = 0; hdr_ok = 1;
+                pos++;
+                continue;
+            }
+            pos++;
+            if (in_header) {
+                if (ch == '\n') {
+                    hdr[hdr_i < 255 ? hdr_i : 255] = 0;
+                    match = hdr_ok && strlen(hdr) == name_len && strcmp(hdr, name) == 0;
+                    in_header = 0;
+                    rec_len = 0; rec_off = pos; rec_bases = 0; rec_width = 0; first_line = 1;
+                    line_start = pos; line_bases = 0;
+                } else if (ch == ' ' || ch == '\t' || ch == '\r') {
+                    hdr_ok = hdr_ok && 1;
+                    if (hdr_i < 255) hdr[hdr_i] = 0;
+                    hdr_i = 256; /* the name ends at the first white space */
+                } else if (hdr_i < 255) {
+                    hdr[hdr_i++] = (char) ch;
+                    hdr[hdr_i] = 0;
+                }
+                continue;
+            }
+            if (ch == '\n') {
+                if (first_line && line_bases > 0) { rec_bases = line_bases; rec_width = pos - line_start; first_line = 0; }
+                line_start = pos; line_bases = 0;
+            } else if (ch != '\r') {
+                line_bases++;
+                rec_len++;
+            }
+        }
+        if (match && rec_bases == 0) { len = rec_len; off = rec_off; bases = rec_len > 0 ? rec_len : 1; width = bases + 1; }
+        fclose(fs);
+    } else {
     char *line;
     while ((line = sa_read_line(fi)) != NULL) {
         char **t;
@@ -354,6 +410,7 @@ char *sa_fasta_fetch(const char *fasta_path, const char *name, int64_t start, in
         free(line);
     }
     fclose(fi);
+    }
     if (len < 0) { if (err) *err = -2; return NULL; }
     if (start < 0) start = 0;
     if (end_incl >= len) end_incl = len - 1;

@@ -266,3 +266,59 @@ def test_plan_geometry_random_anchor_sets(oracle):
         _, st = oracle.align(om, job["ref"], job["events"], ax, ay, op, want_stats=True)
         assert info.cells_forward == st.cells_forward and info.cells_backward == st.cells_backward, it
         assert info.n_segments == st.n_tracebacks, it
+
+
+def test_fasta_subsequence_reference_known_answer(tmp_path):
+    """tests/fastaHandlerTests.c:15-32 (test_fastaHandler_getSubSequence): bases [0, 10) of record ZYMO of the reference's
+    own fixture are AGAATTGGTT -- with an index file next to the FASTA and, as htslib would build one, without."""
+    import ctypes as C
+    import shutil
+    L = sa.lib()
+
+    def fetch(path, name, start, end, strand=1):
+        out = C.c_void_p()
+        rc = L.sa_fasta_subsequence(path.encode(), name.encode(), start, end, strand, C.byref(out))
+        if rc:
+            return rc
+        s = C.string_at(out).decode()
+        L.sa_free(out)
+        return s
+
+    src = os.path.join(cases.GOLDEN, "sequences", "pUC19_SspI_Zymo.fa")
+    fa = str(tmp_path / "ref.fa")
+    shutil.copy(src, fa)
+    text = open(fa).read()
+    records, name, seq = {}, None, []
+    for line in text.splitlines():
+        if line.startswith(">"):
+            if name is not None:
+                records[name] = "".join(seq)
+            name, seq = line[1:].split()[0], []
+        else:
+            seq.append(line.strip())
+    records[name] = "".join(seq)
+    assert fetch(fa, "ZYMO", 0, 10) == "AGAATTGGTT"                      # the reference's assertion, no .fai present
+    for rec, s in records.items():
+        for a, b in ((0, 10), (5, 77), (len(s) - 9, len(s)), (61, 200), (0, len(s))):
+            assert fetch(fa, rec, a, b) == s[a:b], (rec, a, b)
+    assert fetch(fa, "nope", 0, 10) != 0 and not isinstance(fetch(fa, "nope", 0, 10), str)
+    # the same through a faidx index (name, length, offset, bases per line, bytes per line)
+    with open(fa + ".fai", "w") as f:
+        off = 0
+        lines = text.splitlines(True)
+        i = 0
+        while i < len(lines):
+            if lines[i].startswith(">"):
+                nm = lines[i][1:].split()[0]
+                off += len(lines[i])
+                first = lines[i + 1]
+                f.write("%s\t%d\t%d\t%d\t%d\n" % (nm, len(records[nm]), off, len(first.rstrip("\n")), len(first)))
+                i += 1
+                while i < len(lines) and not lines[i].startswith(">"):
+                    off += len(lines[i])
+                    i += 1
+            else:
+                i += 1
+    assert fetch(fa, "ZYMO", 0, 10) == "AGAATTGGTT"
+    for rec, s in records.items():
+        assert fetch(fa, rec, 61, 200) == s[61:200]
