@@ -127,6 +127,8 @@ def test_anchor_helpers_match_oracle(oracle):
         c = sa.remap_anchors(a[0], a[1], emap, start2)
         d = oracle.remap_anchors(a[0], a[1], emap, start2)
         assert np.array_equal(c[0], d[0]) and np.array_equal(c[1], d[1])
+        # filterToRemoveOverlap (impl/pairwiseAligner.c:1755-1796): what is left rises strictly in both coordinates
+        assert np.all(np.diff(c[0]) > 0) and np.all(np.diff(c[1]) > 0)
 
 
 @pytest.mark.parametrize("name,model", [("r9p4_oneD.npRead", cases.MODEL_6MER),
