@@ -324,3 +324,43 @@ def test_fasta_subsequence_reference_known_answer(tmp_path):
     assert fetch(fa, "ZYMO", 0, 10) == "AGAATTGGTT"
     for rec, s in records.items():
         assert fetch(fa, rec, 61, 200) == s[61:200]
+
+
+def test_cigar_loader_on_the_reference_guide_alignment(oracle):
+    """The exonerate cigar line the reference's own test expects from its bwa wrapper for a reverse-strand E. coli read
+    (src/signalalign/tests/test_bwaWrapper.py:42-47, kept as tests/golden/cigars/ecoli_minus_strand.cigar): the
+    product's loader reads it as sonLib's cigarRead would (coordinates, strands, 1261 operations) and the anchors
+    derived from it equal the oracle's."""
+    import ctypes as C
+
+    class Cigar(C.Structure):
+        _fields_ = [("contig1", C.c_char_p), ("contig2", C.c_char_p), ("start1", C.c_int64), ("end1", C.c_int64),
+                    ("start2", C.c_int64), ("end2", C.c_int64), ("strand1", C.c_int), ("strand2", C.c_int),
+                    ("score", C.c_double), ("n_ops", C.c_int64), ("op_type", C.POINTER(C.c_int32)),
+                    ("op_len", C.POINTER(C.c_int64))]
+    L = sa.lib()
+    path = os.path.join(cases.GOLDEN, "cigars", "ecoli_minus_strand.cigar")
+    pc = C.POINTER(Cigar)()
+    L.sa_cigar_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(Cigar))]
+    L.sa_cigar_free.argtypes = [C.POINTER(Cigar)]
+    assert L.sa_cigar_load(path.encode(), C.byref(pc)) == 0
+    c = pc.contents
+    toks = open(path).read().split()
+    assert c.contig2 == toks[1].encode() and c.contig1 == b"gi_ecoli"
+    assert (c.start2, c.end2, c.strand2) == (1, 11458, 1) and (c.start1, c.end1, c.strand1) == (1845113, 1832930, 0)
+    assert c.score == 1.0 and c.n_ops == (len(toks) - 10) // 2 == 1261
+    ops = [(int(c.op_type[i]), int(c.op_len[i])) for i in range(c.n_ops)]
+    letters = {"M": 0, "D": 1, "I": 2}
+    assert ops == [(letters[toks[10 + 2 * i]], int(toks[11 + 2 * i])) for i in range(c.n_ops)]
+    m = sum(n for t, n in ops if t == 0)
+    d = sum(n for t, n in ops if t == 1)
+    ins = sum(n for t, n in ops if t == 2)
+    assert m + ins == c.end2 - c.start2 and m + d == c.start1 - c.end1      # both spans add up: 11457 read, 12183 reference bases
+    for trim in (0, 14):
+        a = sa.guide_to_anchors(c.start1, c.end1, c.strand1, c.start2, ops, trim)
+        b = oracle.guide_to_anchors(c.start1, c.end1, c.strand1, c.start2, ops, trim)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        # untrimmed, every matched base is an anchor; the default trim of 14 at both ends of every match run leaves a
+        # sixth of them (a real alignment has an indel every ten to fifty bases)
+        assert len(a[0]) == (m if trim == 0 else 1801)
+    L.sa_cigar_free(pc)
