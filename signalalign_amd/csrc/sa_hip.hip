@@ -898,6 +898,7 @@ struct sa_batch {
     bool expect;
     bool relax;              // memory-resident kernels in their RELAX flavour
     int ring_cap;            // cell-paths per diagonal of their LDS ring (0: rows stay in global memory)
+    int wide_cap;            // cells per row of the register kernels' LDS ring for wide diagonals (0: every diagonal fits)
     int gen_threads;         // 64, or 128 when a diagonal of a memory-resident region holds more than 64 cell-paths
     double *d_tab6; int *d_hdp_slot; double *d_hdp_y, *d_hdp_slope, *d_hdp_grid, *d_hdp_tab;
     long long *d_prob; int *d_seg_pass; long long *d_seg_off; sa_pair_t *d_out;
@@ -1188,6 +1189,15 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     b->relax = !(flags & SA_FLAG_EXACT) && !b->expect && m->hdp == nullptr;
     b->ring_cap = 0;
     b->gen_threads = 64;
+    b->wide_cap = 0;
+    {   // register-kernel regions with diagonals too wide for the registers: an LDS ring of up to 256 cells per row
+        long long widest = 0;
+        for (long long r = 0; r < pl->n_regions; r++)
+            if (pl->regions[r].kind == SA_KIND_FAST && pl->regions[r].slots > 1 && pl->regions[r].max_rowpaths > widest)
+                widest = pl->regions[r].max_rowpaths;
+        if (widest > 0) b->wide_cap = (int) (widest < 256 ? (widest + 31) / 32 * 32 : 256);
+        if (const char *envw = getenv("SA_WIDE_CAP")) b->wide_cap = atoi(envw) < 0 ? 0 : atoi(envw);  // tuning / test hook
+    }
     for (long long r = 0; r < pl->n_regions; r++)
         if (pl->regions[r].kind == SA_KIND_GENERIC && pl->regions[r].max_rowpaths > 64) b->gen_threads = 128;
     if (const char *envt = getenv("SA_GENERIC_THREADS")) b->gen_threads = atoi(envt) == 128 ? 128 : 64;  // test hook
@@ -1488,7 +1498,7 @@ static int enqueue_pass(sa_batch *b, bool finalize, AfterGroup after_group) {
                                s0, P, b->d_ids + C.ids_gr, C.ngr, b->ring_cap);
         else if (C.ngr)
             hipLaunchKernelGGL(k_fwd_generic<false>, dim3(C.ngr), dim3(b->gen_threads), 0, s0, P, b->d_ids + C.ids_gr, C.ngr, 0);
-        if (C.nfr) launch_fwd_fast(P, b->d_ids + C.ids_fr, C.nfr, s0);
+        if (C.nfr) launch_fwd_fast(P, b->d_ids + C.ids_fr, C.nfr, s0, b->wide_cap);
         HIPCHK(hipEventRecord(b->cev[2 * c + 1], s0));
         if (C.g1 - C.g0 > 1) HIPCHK(hipStreamWaitEvent(s1, b->cev[2 * c + 1], 0));
         int submitted = C.g0, completed = C.g0;
