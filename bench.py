@@ -182,9 +182,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=2000, help="reads per GPU (BASELINE configs[1]: 2000)")
     ap.add_argument("--events", type=int, default=5000, help="events per read (BASELINE configs[1]: 5000)")
-    ap.add_argument("--workload", choices=["gaussian", "cpg", "hdp", "event_align", "mea"], default="gaussian",
+    ap.add_argument("--workload", choices=["gaussian", "cpg", "hdp", "realistic", "event_align", "mea"], default="gaussian",
                     help="gaussian = BASELINE configs[1] (the headline); cpg = configs[2] (ACEGT model, every CpG cytosine "
-                         "ambiguous C/E); hdp = configs[3] (HDP emissions).  The last two run on the memory-resident kernels.")
+                         "ambiguous C/E); hdp = configs[3] (HDP emissions); realistic = configs[1] reads with the sparse anchors "
+                         "of a real guide alignment; event_align, mea = the steps either side of the pair-HMM.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reads-per-thread", type=int, default=30)
     args = ap.parse_args()
@@ -234,6 +235,26 @@ def main():
     from signalalign_amd import shard
     mine = shard.shard_indices([args.events] * (world * args.reads), rank, world)
     jobs = [synth.make_read(int(i), args.events, alpha, k, tab, **read_kw) for i in mine]
+    if args.workload == "realistic":
+        # the anchors a real guide alignment leaves: the run structure of the reference's own example cigar (an indel
+        # every 10-50 bases), 14 bases trimmed off both ends of every match run as signalMachine -m 14 does
+        toks = open(os.path.join(ROOT, "tests", "golden", "cigars", "ecoli_minus_strand.cigar")).read().split()[10:]
+        runs = [(toks[i], int(toks[i + 1])) for i in range(0, len(toks), 2)]
+        for idx, job in zip(mine, jobs):
+            keep = np.zeros(len(job["ax"]), dtype=bool)
+            pos, r = 0, (7 * int(idx)) % len(runs)
+            while pos < len(keep):
+                op, ln = runs[r % len(runs)]
+                r += 1
+                if op == "M":
+                    if ln > 28:
+                        keep[pos + 14: min(pos + ln - 14, len(keep))] = True
+                    pos += ln
+                elif op == "D":
+                    pos += ln
+            job["ax"], job["ay"] = job["ax"][keep], job["ay"][keep]
+        wl_name = ("BASELINE configs[1] reads with the anchor density of a real guide alignment "
+                   "(tests/golden/cigars/ecoli_minus_strand.cigar, -m 14: a sixth of the bases)")
     n_events_total = sum(len(j["events"]) for j in jobs)
     t_create = time.perf_counter()
     batch = sa.Batch(pm, params, jobs, ambig=ambig, device=device)  # planning + upload to HBM
