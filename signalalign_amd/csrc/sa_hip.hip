@@ -875,6 +875,8 @@ __global__ __launch_bounds__(256) void k_fill_xc(const sa_region_t *__restrict__
 struct sa_launch_chunk {
     long long ids_gr, ids_fr;  // offsets into d_ids: memory-resident / register-kernel regions
     int ngr, nfr;
+    long long ids_fw[7];       // register-kernel regions whose band needs 2..6 x 64 lanes (k_fwd_wide<S>), by S
+    int nfw[7];
     int g0, g1;                // groups [g0, g1)
 };
 struct sa_launch_group {
@@ -1344,11 +1346,19 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
             while (r < pl->n_regions && pl->regions[r].chunk == c) r++;
             long long rb = r;
             sa_launch_chunk C;
-            std::vector<int> gr, fr;
+            std::vector<int> gr, fr, fw[7];
             double work = 0;
+            // SA_WIDE_KERNEL=1 sends regions whose band needs 2..5 x 64 lanes to k_fwd_wide (band in registers, S cells
+            // per lane).  Off by default: bit-identical, but slower than k_fwd_fast's memory-resident path -- 32.7 ms
+            // against 20.9 ms forward on 2000 reads with realistic anchors (the path is bound by the fp64 logAdd
+            // arithmetic, not by re-reading the band, and slot granularity adds idle lanes); DESIGN.md section 8.
+            const bool wide_on = getenv("SA_WIDE_KERNEL") && atoi(getenv("SA_WIDE_KERNEL")) == 1 && m->hdp == nullptr;
             for (long long q = ra; q < rb; q++) {
-                (pl->regions[q].kind == SA_KIND_FAST ? fr : gr).push_back((int) q);
-                work += (double) pl->regions[q].N;
+                const sa_region_t &Rq = pl->regions[q];
+                if (Rq.kind != SA_KIND_FAST) gr.push_back((int) q);
+                else if (wide_on && Rq.slots >= 2 && Rq.slots <= SA_WIDE_SLOTS_MAX) fw[2].push_back((int) q);
+                else fr.push_back((int) q);
+                work += (double) Rq.N;
             }
             auto by_len_r = [&](int a, int d) { return pl->regions[a].N > pl->regions[d].N; };
             // longest first inside each launch: the tail of a launch is then made of short waves
@@ -1358,6 +1368,14 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
             b->ids_flat.insert(b->ids_flat.end(), gr.begin(), gr.end());
             C.ids_fr = (long long) b->ids_flat.size(); C.nfr = (int) fr.size();
             b->ids_flat.insert(b->ids_flat.end(), fr.begin(), fr.end());
+            auto by_work_r = [&](int a, int d) {
+                return pl->regions[a].N * pl->regions[a].slots > pl->regions[d].N * pl->regions[d].slots;
+            };
+            for (int sl = 0; sl < 7; sl++) {
+                std::stable_sort(fw[sl].begin(), fw[sl].end(), by_work_r);
+                C.ids_fw[sl] = (long long) b->ids_flat.size(); C.nfw[sl] = (int) fw[sl].size();
+                b->ids_flat.insert(b->ids_flat.end(), fw[sl].begin(), fw[sl].end());
+            }
             C.g0 = (int) b->groups.size();
             // a group should still be a sizeable launch: at least 2048 segments each (measured optimum 6-8 groups
             // for 18000 segments; 16 and more lose to launch gaps)
@@ -1499,6 +1517,7 @@ static int enqueue_pass(sa_batch *b, bool finalize, AfterGroup after_group) {
         else if (C.ngr)
             hipLaunchKernelGGL(k_fwd_generic<false>, dim3(C.ngr), dim3(b->gen_threads), 0, s0, P, b->d_ids + C.ids_gr, C.ngr, 0);
         if (C.nfr) launch_fwd_fast(P, b->d_ids + C.ids_fr, C.nfr, s0, b->wide_cap);
+        if (C.nfw[2]) launch_fwd_wide(P, b->d_ids + C.ids_fw[2], C.nfw[2], s0);
         HIPCHK(hipEventRecord(b->cev[2 * c + 1], s0));
         if (C.g1 - C.g0 > 1) HIPCHK(hipStreamWaitEvent(s1, b->cev[2 * c + 1], 0));
         int submitted = C.g0, completed = C.g0;

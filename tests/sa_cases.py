@@ -18,6 +18,32 @@ def synthetic_jobs(model_path, n_reads, n_events, first_index=0, **kw):
     return synth.make_jobs(n_reads, n_events, alpha, k, tab, first_index=first_index, **kw)
 
 
+def realistic_anchor_jobs(model_path, n_reads, n_events, first_index=0, trim=14):
+    """Synthetic reads whose anchors are thinned the way a real guide alignment thins them: match runs taken from
+    the bundled minus-strand cigar (tests/golden/cigars), `trim` anchors dropped at both ends of each run, nothing
+    kept inside deletions.  About one base in six stays an anchor and most diagonals are wider than 64 lanes."""
+    toks = open(os.path.join(GOLDEN, "cigars", "ecoli_minus_strand.cigar")).read().split()[10:]
+    runs = [(toks[i], int(toks[i + 1])) for i in range(0, len(toks), 2)]
+    jobs = []
+    for j, job in enumerate(synthetic_jobs(model_path, n_reads, n_events, first_index)):
+        ax, ay = job["ax"], job["ay"]
+        keep = np.zeros(len(ax), dtype=bool)
+        pos, r = 0, (7 * j) % len(runs)
+        while pos < len(ax):
+            op, ln = runs[r % len(runs)]
+            r += 1
+            if op == "M":
+                if ln > 2 * trim:
+                    keep[pos + trim: min(pos + ln - trim, len(ax))] = True
+                pos += ln
+            elif op == "D":
+                pos += ln
+        q = dict(job)
+        q["ax"], q["ay"] = ax[keep], ay[keep]
+        jobs.append(q)
+    return jobs
+
+
 def oracle_pairs(oracle, omodel, job, params, ambig=None):
     omodel.set_read_params(job["scale"], job["shift"], job["var"])
     return oracle.align(omodel, job["ref"], job["events"], job["ax"], job["ay"], params, ambig=ambig)

@@ -193,6 +193,21 @@ def test_sparse_anchors_wide_bands(oracle):
         assert cases.same_order(got[j], exp)
 
 
+def test_wide_register_kernel_opt_in_is_bit_identical(oracle, monkeypatch):
+    # SA_WIDE_KERNEL=1 routes regions whose band needs 2..5 x 64 lanes to k_fwd_wide (band in registers at any
+    # width); it must reproduce the default path's forward values exactly, hence identical output pairs
+    pm, _ = _models(oracle, cases.MODEL_6MER)
+    p = sa.default_params()
+    jobs = cases.realistic_anchor_jobs(cases.MODEL_6MER, 8, 2500, 600)
+    jobs += cases.synthetic_jobs(cases.MODEL_6MER, 4, 900, 300)  # narrow regions stay on k_fwd_fast
+    want, _st = _run(pm, p, jobs)
+    monkeypatch.setenv("SA_WIDE_KERNEL", "1")
+    got, _st = _run(pm, p, jobs)
+    assert sum(len(w) for w in want) > 0
+    for j in range(len(jobs)):
+        assert np.array_equal(got[j], want[j]), j
+
+
 def test_split_regions_and_chunked_forward_storage(oracle, monkeypatch):
     pm, om = _models(oracle, cases.MODEL_6MER)
     p = sa.default_params()
