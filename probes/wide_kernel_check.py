@@ -5,12 +5,13 @@ pm = sa.Model.load(cases.MODEL_6MER); p = sa.default_params()
 NR = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 NE = int(sys.argv[2]) if len(sys.argv) > 2 else 2500
 jobs = cases.realistic_anchor_jobs(cases.MODEL_6MER, NR, NE)
+VAR = sys.argv[3] if len(sys.argv) > 3 else "SA_WIDE_KERNEL"   # or SA_WIDE_BWD
 res = {}
 for v in ("0", "1"):
-    os.environ["SA_WIDE_KERNEL"] = v
+    os.environ[VAR] = v
     b = sa.Batch(pm, p, jobs); b.run(); b.run()
     res[v] = [b.pairs(j) for j in range(len(jobs))]
-    print("SA_WIDE_KERNEL", v, "pairs", sum(len(x) for x in res[v]), "fwd ms %.3f bwd ms %.3f" % (b.stats().ms_forward, b.stats().ms_backward))
+    print(VAR, v, "pairs", sum(len(x) for x in res[v]), "fwd ms %.3f bwd ms %.3f" % (b.stats().ms_forward, b.stats().ms_backward))
     b.close()
 same = all(np.array_equal(a, c) for a, c in zip(res["0"], res["1"]))
 print("identical:", same)

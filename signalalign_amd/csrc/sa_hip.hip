@@ -881,8 +881,8 @@ struct sa_launch_chunk {
 };
 struct sa_launch_group {
     long long seg0, seg1, ck0, ck1;
-    long long ids_gs, ids_fs;
-    int ngs, nfs;
+    long long ids_gs, ids_fs, ids_ws;   // segments of memory-resident / register / register, wide-band regions
+    int ngs, nfs, nws;
 };
 
 struct sa_batch {
@@ -1395,12 +1395,14 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
                 while (q < rb && pl->regions[q].job == pl->regions[q - 1].job) { acc += (double) pl->regions[q].N; q++; }
                 sa_launch_group G;
                 G.seg0 = G.seg1 = G.ck0 = G.ck1 = 0;
-                std::vector<int> gs, fs;
+                std::vector<int> gs, fs, ws;
                 bool any = false;
+                // SA_WIDE_BWD=0 keeps the segments of wide-band regions on k_bwd_fast (comparison hook)
+                const bool wide_bwd = !(getenv("SA_WIDE_BWD") && atoi(getenv("SA_WIDE_BWD")) == 0) && m->hdp == nullptr;
                 for (long long t = qa; t < q; t++) {
                     const sa_region_t *R = &pl->regions[t];
                     for (long long sg = R->seg_off; sg < R->seg_off + R->n_seg; sg++) {
-                        (R->kind == SA_KIND_FAST ? fs : gs).push_back((int) sg);
+                        (R->kind != SA_KIND_FAST ? gs : (wide_bwd && R->slots >= 2 ? ws : fs)).push_back((int) sg);
                         const sa_seg_t *S = &pl->segs[sg];
                         if (!any) { G.seg0 = sg; G.ck0 = S->ck_base; any = true; }
                         G.seg1 = sg + 1;
@@ -1417,6 +1419,9 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
                 b->ids_flat.insert(b->ids_flat.end(), gs.begin(), gs.end());
                 G.ids_fs = (long long) b->ids_flat.size(); G.nfs = (int) fs.size();
                 b->ids_flat.insert(b->ids_flat.end(), fs.begin(), fs.end());
+                std::stable_sort(ws.begin(), ws.end(), by_len_s);
+                G.ids_ws = (long long) b->ids_flat.size(); G.nws = (int) ws.size();
+                b->ids_flat.insert(b->ids_flat.end(), ws.begin(), ws.end());
                 b->groups.push_back(G);
             }
             C.g1 = (int) b->groups.size();
@@ -1482,6 +1487,7 @@ static int submit_group(sa_batch *b, const DevPlan &P, int g, int which_stream, 
                            b->ring_cap);
     else if (G.ngs)
         hipLaunchKernelGGL((k_bwd_generic<false, false>), dim3(G.ngs), dim3(b->gen_threads), 0, st, P, b->d_ids + G.ids_gs, G.ngs, 0);
+    if (G.nws) launch_bwd_fast(P, b->d_ids + G.ids_ws, G.nws, st, true);
     if (G.nfs) launch_bwd_fast(P, b->d_ids + G.ids_fs, G.nfs, st);
     HIPCHK(hipEventRecord(b->gev[4 * g + 1], st));
     if (G.ck1 > G.ck0)
