@@ -320,9 +320,12 @@ def main():
         else:
             dom, dom_ms, dom_cells = "k_fwd_" + fam, ms_f, st0.cells_forward
         achieved = ALGO_BYTES_PER_CELL * dom_cells / (dom_ms * 1e-3) / 1e9
+        if args.workload == "realistic" and dom == "k_bwd_fast":
+            dom = "k_bwd_fast_wide"  # segments of wide-band regions take the batched variant
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")  # written from the rocprofv3 --pmc passes, see DESIGN.md
-        if os.path.exists(tp):
+        # the counters were collected on the headline workload only: no figure for any other
+        if os.path.exists(tp) and args.workload == "gaussian" and args.reads == 2000 and args.events == 5000:
             try:
                 traffic = json.load(open(tp)).get(dom)
             except Exception:
