@@ -1379,11 +1379,17 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
             C.g0 = (int) b->groups.size();
             // a group should still be a sizeable launch: at least 2048 segments each (measured optimum 6-8 groups
             // for 18000 segments; 16 and more lose to launch gaps)
-            long long nseg_chunk = 0;
-            for (long long q = ra; q < rb; q++) nseg_chunk += pl->regions[q].n_seg;
+            long long nseg_chunk = 0, nseg_wide = 0;
+            for (long long q = ra; q < rb; q++) {
+                nseg_chunk += pl->regions[q].n_seg;
+                if (pl->regions[q].kind == SA_KIND_FAST && pl->regions[q].slots >= 2) nseg_wide += pl->regions[q].n_seg;
+            }
+            // k_bwd_fast_wide runs two waves per SIMD (2048 at a time): its launches need twice the segments to keep
+            // the tail short (2000 reads with realistic anchors, 17 300 segments: 4-6 groups 71 ms, 8 groups 75 ms)
+            const long long min_per_group = (2 * nseg_wide > nseg_chunk && m->hdp == nullptr) ? 4096 : 2048;
             int ng = want;
             if (!(envg && atoi(envg) > 0))
-                while (ng > 1 && nseg_chunk / ng < 2048) ng--;
+                while (ng > 1 && nseg_chunk / ng < min_per_group) ng--;
             long long q = ra;
             double acc = 0;
             for (int g = 0; g < ng && q < rb; g++) {
