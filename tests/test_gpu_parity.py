@@ -193,10 +193,10 @@ def test_sparse_anchors_wide_bands(oracle):
         assert cases.same_order(got[j], exp)
 
 
-def test_wide_register_kernel_opt_in_is_bit_identical(oracle, monkeypatch):
+def test_wide_band_kernels_bit_identical_and_close_to_oracle(oracle, monkeypatch):
     # SA_WIDE_KERNEL=1 routes regions whose band needs 2..5 x 64 lanes to k_fwd_wide (band in registers at any
     # width); it must reproduce the default path's forward values exactly, hence identical output pairs
-    pm, _ = _models(oracle, cases.MODEL_6MER)
+    pm, om = _models(oracle, cases.MODEL_6MER)
     p = sa.default_params()
     jobs = cases.realistic_anchor_jobs(cases.MODEL_6MER, 8, 2500, 600)
     jobs += cases.synthetic_jobs(cases.MODEL_6MER, 4, 900, 300)  # narrow regions stay on k_fwd_fast
@@ -206,6 +206,18 @@ def test_wide_register_kernel_opt_in_is_bit_identical(oracle, monkeypatch):
     assert sum(len(w) for w in want) > 0
     for j in range(len(jobs)):
         assert np.array_equal(got[j], want[j]), j
+    # the backward sweep of such regions runs on k_bwd_fast_wide by default (loads of a wide diagonal batched):
+    # same pairs as k_bwd_fast, and within tolerance of the CPU restatement
+    monkeypatch.delenv("SA_WIDE_KERNEL")
+    monkeypatch.setenv("SA_WIDE_BWD", "0")
+    narrow, _st = _run(pm, p, jobs)
+    for j in range(len(jobs)):
+        assert np.array_equal(narrow[j], want[j]), j
+    op = cases.oracle_params(oracle, p)
+    for j in (0, 5):
+        exp = cases.oracle_pairs(oracle, om, jobs[j], op)
+        cases.compare_pairs(want[j], exp, TOL_E7, p.threshold)
+        assert cases.same_order(want[j], exp)
 
 
 def test_split_regions_and_chunked_forward_storage(oracle, monkeypatch):
