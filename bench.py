@@ -320,8 +320,8 @@ def main():
         else:
             dom, dom_ms, dom_cells = "k_fwd_" + fam, ms_f, st0.cells_forward
         achieved = ALGO_BYTES_PER_CELL * dom_cells / (dom_ms * 1e-3) / 1e9
-        if args.workload == "realistic" and dom == "k_bwd_fast":
-            dom = "k_bwd_fast_wide"  # segments of wide-band regions take the batched variant
+        if os.environ.get("SA_WIDE_BWD") == "1" and args.workload == "realistic" and dom == "k_bwd_fast":
+            dom = "k_bwd_fast_wide"  # opt-in variant for the segments of wide-band regions
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")  # written from the rocprofv3 --pmc passes, see DESIGN.md
         # the counters were collected on the headline workload only: no figure for any other

@@ -1384,9 +1384,10 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
                 nseg_chunk += pl->regions[q].n_seg;
                 if (pl->regions[q].kind == SA_KIND_FAST && pl->regions[q].slots >= 2) nseg_wide += pl->regions[q].n_seg;
             }
-            // k_bwd_fast_wide runs two waves per SIMD (2048 at a time): its launches need twice the segments to keep
-            // the tail short (2000 reads with realistic anchors, 17 300 segments: 4-6 groups 71 ms, 8 groups 75 ms)
-            const long long min_per_group = (2 * nseg_wide > nseg_chunk && m->hdp == nullptr) ? 4096 : 2048;
+            // segments of wide-band regions live three to four times longer than those of dense anchors (4 ms against
+            // 1.2 ms), and so do the tails of their launches: fewer, larger groups.  2000 reads with realistic anchors,
+            // 17 300 segments, step time with 1 / 2 / 3 / 4 / 6 / 8 groups: 70.2 / 67.8 / 69.3 / 73.1 / 80.2 / 87 ms
+            const long long min_per_group = (2 * nseg_wide > nseg_chunk) ? 8192 : 2048;
             int ng = want;
             if (!(envg && atoi(envg) > 0))
                 while (ng > 1 && nseg_chunk / ng < min_per_group) ng--;
@@ -1403,8 +1404,11 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
                 G.seg0 = G.seg1 = G.ck0 = G.ck1 = 0;
                 std::vector<int> gs, fs, ws;
                 bool any = false;
-                // SA_WIDE_BWD=0 keeps the segments of wide-band regions on k_bwd_fast (comparison hook)
-                const bool wide_bwd = !(getenv("SA_WIDE_BWD") && atoi(getenv("SA_WIDE_BWD")) == 0) && m->hdp == nullptr;
+                // SA_WIDE_BWD=1 sends the segments of wide-band regions to k_bwd_fast_wide (loads of a wide diagonal
+                // batched, 2 waves per SIMD).  Off by default: it beats k_bwd_fast only when the launches are small
+                // (8 result groups: 53 against 65 ms); with the two groups such batches now get, k_bwd_fast's five
+                // waves per SIMD win (43 against 45 ms backward, 67.8 against 72.4 ms per step).  DESIGN.md section 8.
+                const bool wide_bwd = getenv("SA_WIDE_BWD") && atoi(getenv("SA_WIDE_BWD")) == 1 && m->hdp == nullptr;
                 for (long long t = qa; t < q; t++) {
                     const sa_region_t *R = &pl->regions[t];
                     for (long long sg = R->seg_off; sg < R->seg_off + R->n_seg; sg++) {

@@ -206,13 +206,13 @@ def test_wide_band_kernels_bit_identical_and_close_to_oracle(oracle, monkeypatch
     assert sum(len(w) for w in want) > 0
     for j in range(len(jobs)):
         assert np.array_equal(got[j], want[j]), j
-    # the backward sweep of such regions runs on k_bwd_fast_wide by default (loads of a wide diagonal batched):
-    # same pairs as k_bwd_fast, and within tolerance of the CPU restatement
+    # SA_WIDE_BWD=1: the backward sweep of such regions on k_bwd_fast_wide (loads of a wide diagonal batched):
+    # same pairs as k_bwd_fast; both within tolerance of the CPU restatement
     monkeypatch.delenv("SA_WIDE_KERNEL")
-    monkeypatch.setenv("SA_WIDE_BWD", "0")
-    narrow, _st = _run(pm, p, jobs)
+    monkeypatch.setenv("SA_WIDE_BWD", "1")
+    batched, _st = _run(pm, p, jobs)
     for j in range(len(jobs)):
-        assert np.array_equal(narrow[j], want[j]), j
+        assert np.array_equal(batched[j], want[j]), j
     op = cases.oracle_params(oracle, p)
     for j in (0, 5):
         exp = cases.oracle_pairs(oracle, om, jobs[j], op)
