@@ -48,10 +48,49 @@ def compute(name, npread, model_path, nhdp):
                 kmer_id=pairs["kmer_id"].astype(np.int32), prob_e7=pairs["prob_e7"].astype(np.int64))
 
 
+# The reference's whole-read test inputs (tests/stateMachineTests.c:842-983): ZymoC x ZymoRef with the anchors of the
+# reference's lastz subprocess (tests/zymo_wholeread.py), banding defaults of pairwiseAlignmentBandingParameters_construct,
+# read parameters from the .npRead header.  "zymo_lastz_hdp" IS the reference's test_sm3Hdp_getAlignedPairsWithBanding job
+# (its emission is the one signalMachine --sm3Hdp uses): 1217 pairs.  The Gaussian variants run the same jobs with the
+# emission signalMachine installs (MeanOnly, impl/signalMachine.c:347-349) instead of the unit tests' two-distribution
+# one, so their counts are the oracle's, not the reference's 1076 / 7349 (those are asserted in test_oracle_kats.py).
+ZYMO_CASES = ["zymo_lastz_C", "zymo_lastz_E", "zymo_lastz_O", "zymo_lastz_L", "zymo_lastz_hdp"]
+
+
+def zymo_job(name):
+    import zymo_wholeread as z
+    r = z.read_fixture()
+    ax, ay = z.remapped_anchors()
+    tp = r["template_params"]
+    hdp = name.endswith("_hdp")
+    ref = r["ref"] if hdp else r["ref"].replace("C", name[-1])
+    ev = z.hdp_test_events(r) if hdp else r["template_events"]
+    b = z.BANDING
+    return dict(ref=ref, events=np.ascontiguousarray(ev), ax=ax, ay=ay, scale=tp["scale"], shift=tp["shift"],
+                var=tp["var"]), dict(b, threshold=0.1 if hdp else b["threshold"]), hdp
+
+
+def compute_zymo(name):
+    job, b, hdp = zymo_job(name)
+    om = oracle.Model.from_file(cases.MODEL_R73)
+    if hdp:
+        om.load_hdp(cases.NHDP)       # getHdpStateMachine: no setModelToHdpExpectedValues (impl/stateMachine.c:1778)
+    om.set_read_params(job["scale"], job["shift"], job["var"])
+    p = oracle.Params(b["threshold"], b["expansion"], b["trace_back"], b["min_diags"], b["split"], 14)
+    pairs = oracle.align(om, job["ref"], job["events"], job["ax"], job["ay"], p)
+    return dict(threshold=np.float64(b["threshold"]), x=pairs["x"].astype(np.int32), y=pairs["y"].astype(np.int32),
+                path=pairs["path"].astype(np.int32), kmer_id=pairs["kmer_id"].astype(np.int32),
+                prob_e7=pairs["prob_e7"].astype(np.int64))
+
+
 if __name__ == "__main__":
     out = os.path.join(HERE, "expected")
     os.makedirs(out, exist_ok=True)
     for name, npread, model_path, nhdp in CASES:
         d = compute(name, npread, model_path, nhdp)
+        np.savez_compressed(os.path.join(out, name + ".npz"), **d)
+        print(name, len(d["x"]), "pairs")
+    for name in ZYMO_CASES:
+        d = compute_zymo(name)
         np.savez_compressed(os.path.join(out, name + ".npz"), **d)
         print(name, len(d["x"]), "pairs")

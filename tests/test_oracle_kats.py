@@ -202,6 +202,13 @@ def test_oracle_reproduces_committed_expected_outputs(oracle, golden):
             assert float(got[key]) == float(want[key]), (name, key)
         for key in ("ax", "ay", "x", "y", "path", "kmer_id", "prob_e7"):
             assert np.array_equal(got[key], want[key]), (name, key)
+    for name in mk.ZYMO_CASES:
+        want = np.load(os.path.join(GOLDEN, "expected", name + ".npz"))
+        got = mk.compute_zymo(name)
+        for key in ("x", "y", "path", "kmer_id", "prob_e7"):
+            assert np.array_equal(got[key], want[key]), (name, key)
+    # the HDP case is the reference's own job and count (tests/stateMachineTests.c:912)
+    assert len(np.load(os.path.join(GOLDEN, "expected", "zymo_lastz_hdp.npz"))["x"]) == 1217
 
 
 def test_scale_params_from_strand_read_and_drift(oracle, golden):
@@ -260,3 +267,76 @@ def test_path_legal_transitions_and_substituted_kmers(oracle, golden):
                 assert j // A in pre
                 checked += 1
     assert checked >= 3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Whole-read known answers of the reference: ZymoC_ch_1_file1.npRead (799 template events) x ZymoRef.txt
+# (tests/stateMachineTests.c:842-983).  Anchors: the committed output of the reference's lastz subprocess, converted by
+# tests/zymo_wholeread.py.  These are the only reference-held vectors over a real read; they pin the banded driver
+# (A12/A13), the split/anchor handling (A15/A16), the ambiguity expansion (A5) and the HDP emission (A10) of the oracle.
+# ---------------------------------------------------------------------------------------------------------------------
+def _zymo(oracle, golden):
+    import zymo_wholeread as z
+    r = z.read_fixture()
+    d = oracle.parse_model_file(os.path.join(golden, "models", "testModelR73_acegot_template.model"))
+    ax, ay = z.remapped_anchors()
+    b = z.BANDING
+    p = oracle.Params(b["threshold"], b["expansion"], b["trace_back"], b["min_diags"], b["split"], z.TRIM)
+    return z, r, d, ax, ay, p
+
+
+def test_zymo_whole_read_without_banding_1076(oracle, golden):
+    # tests/stateMachineTests.c:855-868: getAlignedPairsWithoutBanding, scaled R7.3 model (loadScaledStateMachine3 :69-79,
+    # emissions_signal_scaleModel impl/stateMachine.c:743-779), threshold 0.01 -> exactly 1076 pairs
+    z, r, d, ax, ay, p = _zymo(oracle, golden)
+    m = oracle.Model(d["alphabet"], d["k"], d["transitions10"], z.scaled_table(d["table5"], r["template_params"]),
+                     emission=oracle.EM_TWODIST)
+    tF, tB, diag, pairs = oracle.kat_unbanded(m, r["ref"], r["template_events"], 0.01)
+    assert len(pairs) == z.N_PAIRS_GAUSS
+    assert abs(tF - tB) < 0.01
+    lX = len(r["ref"]) - 5
+    assert pairs["x"].min() >= 0 and pairs["x"].max() < lX and pairs["y"].min() >= 0 and pairs["y"].max() < 799
+
+
+def test_zymo_whole_read_banded_1076_scaled_and_descaled(oracle, golden):
+    # tests/stateMachineTests.c:851-852: getAlignedPairsUsingAnchors (ragged 1, 1) with the scaled model and with the
+    # descaled one (getStateMachine3_descaled + scaleNoise, impl/stateMachine.c:1739-1755): 1076 == the un-banded count
+    z, r, d, ax, ay, p = _zymo(oracle, golden)
+    tp = r["template_params"]
+    assert len(ax) == 39
+    m = oracle.Model(d["alphabet"], d["k"], d["transitions10"], z.scaled_table(d["table5"], tp), emission=oracle.EM_TWODIST)
+    assert len(oracle.align(m, r["ref"], r["template_events"], ax, ay, p, ragged=(1, 1))) == z.N_PAIRS_GAUSS
+    m2 = oracle.Model(d["alphabet"], d["k"], d["transitions10"], d["table5"], emission=oracle.EM_TWODIST_DESCALED)
+    m2.set_read_params(tp["scale"], tp["shift"], tp["var"])
+    m2.scale_noise(tp["scale_sd"], tp["var_sd"])
+    assert len(oracle.align(m2, r["ref"], r["template_events"], ax, ay, p, ragged=(1, 1))) == z.N_PAIRS_GAUSS
+
+
+def test_zymo_whole_read_degenerate_nucleotides(oracle, golden):
+    # tests/stateMachineTests.c:920-983 test_DegenerateNucleotides: every C of the reference replaced by C / E / O keeps
+    # 1076 pairs; replaced by the ambiguity letter L (C, E or O: three paths per C in the k-mer) gives 7349.  Ragged 0, 0.
+    z, r, d, ax, ay, p = _zymo(oracle, golden)
+    tp = r["template_params"]
+    m = oracle.Model(d["alphabet"], d["k"], d["transitions10"], d["table5"], emission=oracle.EM_TWODIST_DESCALED)
+    m.set_read_params(tp["scale"], tp["shift"], tp["var"])
+    m.scale_noise(tp["scale_sd"], tp["var_sd"])
+    for letter, want in z.N_PAIRS_DEGENERATE.items():
+        pairs = oracle.align(m, r["ref"].replace("C", letter), r["template_events"], ax, ay, p, ragged=(0, 0))
+        assert len(pairs) == want, (letter, len(pairs))
+        # checkAlignedPairs[WithOverlap] (:154-221): coordinates inside the matrix, probabilities in (0, PROB_1]
+        assert pairs["prob_e7"].min() > 0 and pairs["prob_e7"].max() <= 10000000
+        if letter != "L":
+            assert len({(int(a), int(b)) for a, b in zip(pairs["x"], pairs["y"])}) == want
+
+
+def test_zymo_whole_read_hdp_1217(oracle, golden):
+    # tests/stateMachineTests.c:902-918 test_sm3Hdp_getAlignedPairsWithBanding: the bundled single-level HDP, threshold 0.1,
+    # events "descaled" by nanopore_descaleNanoporeRead (see zymo_wholeread.hdp_test_events) -> exactly 1217 pairs
+    z, r, d, ax, ay, p = _zymo(oracle, golden)
+    tp = r["template_params"]
+    m = oracle.Model(d["alphabet"], d["k"], d["transitions10"], d["table5"], emission=oracle.EM_HDP)
+    m.load_hdp(os.path.join(golden, "models", "templateSingleLevelFixed.nhdp"))
+    m.set_read_params(tp["scale"], tp["shift"], tp["var"])
+    p.threshold = 0.1
+    pairs = oracle.align(m, r["ref"], z.hdp_test_events(r), ax, ay, p, ragged=(1, 1))
+    assert len(pairs) == z.N_PAIRS_HDP_AT_0p1
