@@ -29,26 +29,83 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALGO_BYTES_PER_CELL = 24.0     # 3 fp64 states of every band cell, written once, read once
 
 
-def cpu_baseline(alpha, k, t10, tab, n_events, reads_per_thread, first_index):
-    """The CPU restatement (oracle, 'port') on a bounded sample of the same workload, one read per thread."""
-    from oracle import sa_oracle_py as oracle
-    from signalalign_amd import synth
-    cores = min(os.cpu_count() or 1, 16)
+def host_cpu_info():
+    """Socket model, physical cores per socket and the logical CPUs of socket 0's physical cores (first hardware thread of
+    each core), from /proc/cpuinfo; plus what this process may actually use (affinity mask, cgroup quota)."""
+    model, phys = "unknown", {}
     try:
-        cores = min(cores, len(os.sched_getaffinity(0)))
+        cur = {}
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k_, v_ = [t.strip() for t in line.split(":", 1)]
+                cur[k_] = v_
+            elif cur:
+                model = cur.get("model name", model)
+                key = (int(cur.get("physical id", 0)), int(cur.get("core id", 0)))
+                phys.setdefault(key, []).append(int(cur["processor"]))
+                cur = {}
     except Exception:
         pass
-    n = cores * reads_per_thread
-    jobs = synth.make_jobs(n, n_events, alpha, k, tab, first_index=first_index)
+    sockets = sorted({k_[0] for k_ in phys}) or [0]
+    s0 = sorted(min(v_) for k_, v_ in phys.items() if k_[0] == sockets[0])
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except Exception:
+        allowed = list(range(os.cpu_count() or 1))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    return dict(model=model, sockets=len(sockets), cores_per_socket=len(s0) or None, socket0_cpus=s0, allowed=allowed,
+                cgroup_cpu_quota=quota)
+
+
+def cpu_baseline(alpha, k, t10, tab, n_events, reads_per_thread, first_index):
+    """The CPU restatement (oracle, 'port') on a bounded sample of the same workload, one read per thread, threads pinned
+    to the physical cores of ONE socket (north_star: single-socket baseline); a one-thread figure beside it."""
+    from oracle import sa_oracle_py as oracle
+    from signalalign_amd import synth
+    info = host_cpu_info()
+    pin = [c for c in info["socket0_cpus"] if c in set(info["allowed"])] or info["allowed"]
+    cores = len(pin)
+    if info["cgroup_cpu_quota"]:
+        cores = max(1, min(cores, int(info["cgroup_cpu_quota"])))
+    cores = min(cores, int(os.environ.get("SA_CPU_BASELINE_THREADS", "64")))
+    pin = pin[:cores]
+    old = None
+    try:
+        old = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, pin)
+    except Exception:
+        old = None
     om = oracle.Model(alpha, k, t10, tab)
     p = oracle.default_params()
-    t0 = time.perf_counter()
-    npairs, cells = oracle.align_batch_mt(om, jobs, p, cores)
-    dt = time.perf_counter() - t0
+    try:
+        one = synth.make_jobs(max(8, reads_per_thread), n_events, alpha, k, tab, first_index=first_index)
+        t0 = time.perf_counter()
+        _, c1 = oracle.align_batch_mt(om, one, p, 1)
+        dt1 = time.perf_counter() - t0
+        n = cores * reads_per_thread
+        jobs = synth.make_jobs(n, n_events, alpha, k, tab, first_index=first_index + 1000)
+        t0 = time.perf_counter()
+        npairs, cells = oracle.align_batch_mt(om, jobs, p, cores)
+        dt = time.perf_counter() - t0
+    finally:
+        if old is not None:
+            try:
+                os.sched_setaffinity(0, old)
+            except Exception:
+                pass
     return dict(value=float(cells.sum() / dt), unit="cell_updates/s", cores=cores, kind="port",
                 sample="%d reads x %d events (same generator and parameters as the GPU workload), oracle/sa_oracle.c, "
-                       "%d threads, %.1f s wall" % (n, n_events, cores, dt),
-                events_per_s=float(sum(len(j["events"]) for j in jobs) / dt))
+                       "%d threads pinned to physical cores of socket 0, %.1f s wall; 1 thread: %d reads, %.1f s"
+                       % (n, n_events, cores, dt, len(one), dt1),
+                events_per_s=float(sum(len(j["events"]) for j in jobs) / dt),
+                one_thread_value=float(c1.sum() / dt1),
+                socket_model=info["model"], sockets=info["sockets"], physical_cores_per_socket=info["cores_per_socket"],
+                logical_cpus_allowed=len(info["allowed"]), cgroup_cpu_quota=info["cgroup_cpu_quota"])
 
 
 def bench_event_align(args):
@@ -175,20 +232,47 @@ def bench_mea(args):
     print(json.dumps(res))
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks, one per GPU, as children of this process --
+    which itself never touches the GPU (no HIP call, no torch.cuda call before or after) -- through
+    torch.distributed.run on 127.0.0.1, relay rank 0's JSON line and exit with the launcher's code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=2000, help="reads per GPU (BASELINE configs[1]: 2000)")
-    ap.add_argument("--events", type=int, default=5000, help="events per read (BASELINE configs[1]: 5000)")
-    ap.add_argument("--workload", choices=["gaussian", "cpg", "hdp", "realistic", "event_align", "mea"], default="gaussian",
-                    help="gaussian = BASELINE configs[1] (the headline); cpg = configs[2] (ACEGT model, every CpG cytosine "
-                         "ambiguous C/E); hdp = configs[3] (HDP emissions); realistic = configs[1] reads with the sparse anchors "
-                         "of a real guide alignment; event_align, mea = the steps either side of the pair-HMM.")
+    ap.add_argument("--reads", type=int, default=None, help="reads per GPU (default: 2000 = BASELINE configs[1]; "
+                                                             "scaling: 12500 = configs[4]'s 100k reads / 8 GPUs)")
+    ap.add_argument("--events", type=int, default=None, help="events per read (default 5000; scaling: 10000)")
+    ap.add_argument("--workload", choices=["gaussian", "scaling", "cpg", "hdp", "realistic", "event_align", "mea"],
+                    default="gaussian",
+                    help="gaussian = BASELINE configs[1] (the headline); scaling = configs[4]'s per-GPU slice (12500 "
+                         "10k-event reads per GPU, several forward-storage passes); cpg = configs[2] (ACEGT model, every "
+                         "CpG cytosine ambiguous C/E); hdp = configs[3] (HDP emissions); realistic = configs[1] reads with "
+                         "the sparse anchors of a real guide alignment; event_align, mea = the steps either side of the "
+                         "pair-HMM.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reads-per-thread", type=int, default=30)
     args = ap.parse_args()
+    if args.reads is None:
+        args.reads = 12500 if args.workload == "scaling" else 2000
+    if args.events is None:
+        args.events = 10000 if args.workload == "scaling" else 5000
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: become one (nothing in this process has touched or will touch the GPU)
+        sys.exit(self_launch(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -222,6 +306,8 @@ def main():
         model_path = os.path.join(gold, "testModelR9.4_450bps.cpg.6mer.template.model")
         ambig, read_kw = sa.default_ambig({"X": "CE"}), {"cpg_ambiguous": True}
         wl_name = "BASELINE configs[2]: R9.4 6-mer CpG model (ACEGT), every CpG cytosine ambiguous (C/E)"
+    elif args.workload == "scaling":
+        wl_name = "BASELINE configs[4], one GPU's slice (100k reads / 8): R9.4 6-mer template Gaussian HMM"
     elif args.workload == "hdp":
         model_path = os.path.join(gold, "testModelR73_acegot_template.model")
         nhdp = os.path.join(gold, "templateSingleLevelFixed.nhdp")
@@ -367,7 +453,7 @@ def main():
                          "stage_ms": dom_ms,
                          "launches_per_step": int(st0.n_groups) if dom.startswith("k_bwd") else int(st0.n_chunks)},
         }
-        if not args.no_cpu_baseline and args.workload == "gaussian":
+        if not args.no_cpu_baseline and args.workload in ("gaussian", "scaling"):
             out["cpu_baseline"] = cpu_baseline(alpha, k, t10, tab, args.events, args.cpu_reads_per_thread,
                                                first_index=10 ** 6)
         print(json.dumps(out))
