@@ -104,6 +104,9 @@ def cpu_baseline(alpha, k, t10, tab, n_events, reads_per_thread, first_index):
                        % (n, n_events, cores, dt, len(one), dt1),
                 events_per_s=float(sum(len(j["events"]) for j in jobs) / dt),
                 one_thread_value=float(c1.sum() / dt1),
+                # the GPU box grants this job a CPU quota below one socket: the full-socket figure is bounded from above by
+                # linear scaling of the one-thread rate over the socket's physical cores
+                single_socket_linear_extrapolation=float(c1.sum() / dt1) * float(info["cores_per_socket"] or cores),
                 socket_model=info["model"], sockets=info["sockets"], physical_cores_per_socket=info["cores_per_socket"],
                 logical_cpus_allowed=len(info["allowed"]), cgroup_cpu_quota=info["cgroup_cpu_quota"])
 

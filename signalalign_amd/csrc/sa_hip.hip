@@ -1069,9 +1069,14 @@ struct SaHandles {
     }
     void park(hipEvent_t e, int dev) {
         if (!e) return;
-        if (!SaPool::enabled() || events.size() > 4096) { (void) hipEventDestroy(e); return; }
-        std::lock_guard<std::mutex> g(mu);
-        events.push_back(E{e, dev});
+        if (SaPool::enabled()) {
+            std::lock_guard<std::mutex> g(mu);   // events.size() is read under the lock: batches may be destroyed from several threads
+            if (events.size() <= 4096) {
+                events.push_back(E{e, dev});
+                return;
+            }
+        }
+        (void) hipEventDestroy(e);
     }
     void release() {
         std::lock_guard<std::mutex> g(mu);

@@ -37,13 +37,17 @@ char *sa_read_line(FILE *f) {
 int64_t sa_split_ws(char *line, char ***toks) {
     int64_t cap = 256, n = 0;
     char **t = malloc(sizeof(char *) * (size_t) cap);
+    *toks = NULL;
+    if (!t) return -1;
     char *p = line;
     for (;;) {
         while (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n') p++;
         if (!*p) break;
         if (n == cap) {
             cap *= 2;
-            t = realloc(t, sizeof(char *) * (size_t) cap);
+            char **t2 = realloc(t, sizeof(char *) * (size_t) cap);
+            if (!t2) { free(t); return -1; }
+            t = t2;
         }
         t[n++] = p;
         while (*p && *p != ' ' && *p != '\t' && *p != '\r' && *p != '\n') p++;
@@ -75,9 +79,9 @@ static double *parse_doubles(char *line, int64_t expect) {
     char **tok;
     int64_t n = sa_split_ws(line, &tok);
     double *v = NULL;
-    if (n == expect) {
-        v = malloc(sizeof(double) * (size_t) n);
-        for (int64_t i = 0; i < n; i++) v[i] = strtod(tok[i], NULL);
+    if (n == expect && n >= 0) {
+        v = malloc(sizeof(double) * (size_t) (n > 0 ? n : 1));
+        for (int64_t i = 0; v && i < n; i++) v[i] = strtod(tok[i], NULL);
     }
     free(tok);
     return v;
@@ -87,7 +91,9 @@ static nhdp_file_t *nhdp_read(const char *path) {
     FILE *f = fopen(path, "r");
     if (!f) return NULL;
     nhdp_file_t *h = calloc(1, sizeof(*h));
+    if (!h) { fclose(f); return NULL; }
     char *ln;
+    int64_t n_data = 0, *dp_ids = NULL;
 #define NEXT() do { ln = sa_read_line(f); if (!ln) goto bad; } while (0)
     NEXT(); h->n_alpha = (int) strtol(ln, NULL, 10); free(ln);
     NEXT(); sscanf(ln, "%63s", h->alphabet); free(ln);
@@ -96,14 +102,16 @@ static nhdp_file_t *nhdp_read(const char *path) {
     NEXT(); int has_data = strtol(ln, NULL, 10) != 0; free(ln);
     NEXT(); int sample_gamma = strtol(ln, NULL, 10) != 0; free(ln);
     NEXT(); h->num_dps = strtoll(ln, NULL, 10); free(ln);
-    if (h->num_dps <= 0) goto bad;
-    int64_t n_data = 0, *dp_ids = NULL;
+    if (h->num_dps <= 0 || h->num_dps > ((int64_t) 1 << 31) || h->n_alpha < 1 || h->n_alpha > 60 || h->k < 1 || h->k > 12)
+        goto bad;
     if (has_data) {
         NEXT(); free(ln); /* data values */
         NEXT();
         char **tok;
         n_data = sa_split_ws(ln, &tok);
+        if (n_data < 0) { free(ln); goto bad; }
         dp_ids = malloc(sizeof(int64_t) * (size_t) (n_data > 0 ? n_data : 1));
+        if (!dp_ids) { free(tok); free(ln); goto bad; }
         for (int64_t i = 0; i < n_data; i++) dp_ids[i] = strtoll(tok[i], NULL, 10);
         free(tok);
         free(ln);
@@ -111,7 +119,7 @@ static nhdp_file_t *nhdp_read(const char *path) {
     NEXT(); free(ln); /* mu nu alpha beta */
     NEXT();
     long long gl = 0;
-    if (sscanf(ln, "%lg %lg %lld", &h->grid_start, &h->grid_stop, &gl) != 3) { free(ln); free(dp_ids); goto bad; }
+    if (sscanf(ln, "%lg %lg %lld", &h->grid_start, &h->grid_stop, &gl) != 3 || gl < 2 || gl > (1 << 24)) { free(ln); goto bad; }
     h->grid_length = gl;
     free(ln);
     NEXT(); free(ln); /* gamma */
@@ -120,6 +128,7 @@ static nhdp_file_t *nhdp_read(const char *path) {
     h->observed = calloc((size_t) h->num_dps, 1);
     h->post = calloc((size_t) h->num_dps, sizeof(double *));
     h->slope = calloc((size_t) h->num_dps, sizeof(double *));
+    if (!h->parent || !h->observed || !h->post || !h->slope) goto bad;
     for (int64_t id = 0; id < h->num_dps; id++) {
         NEXT();
         h->parent[id] = ln[0] == '-' ? -1 : strtoll(ln, NULL, 10);
@@ -127,7 +136,9 @@ static nhdp_file_t *nhdp_read(const char *path) {
     }
     if (has_data) {
         for (int64_t i = 0; i < n_data; i++) /* every named DP and all its ancestors */
-            for (int64_t a = dp_ids[i]; a >= 0 && a < h->num_dps && !h->observed[a]; a = h->parent[a]) h->observed[a] = 1;
+            for (int64_t a = dp_ids[i], guard = 0; a >= 0 && a < h->num_dps && !h->observed[a] && guard <= h->num_dps;
+                 a = h->parent[a], guard++)
+                h->observed[a] = 1;
         for (int64_t id = 0; id < h->num_dps; id++) {
             NEXT();
             h->post[id] = parse_doubles(ln, h->grid_length);
@@ -145,6 +156,7 @@ static nhdp_file_t *nhdp_read(const char *path) {
     fclose(f);
     return h;
 bad:
+    free(dp_ids);
     fclose(f);
     nhdp_file_free(h);
     return NULL;
@@ -164,8 +176,9 @@ int sa_model_load(sa_model_t **out, const char *model_path, const char *nhdp_pat
     if (!l0 || !l1 || !l2) goto done;
     if (sa_split_ws(l0, &t0) != 4) goto done; /* stateNumber alphabetSize alphabet kmerLength */
     int n_states = (int) strtol(t0[0], NULL, 10), n_alpha = (int) strtol(t0[1], NULL, 10), k = (int) strtol(t0[3], NULL, 10);
-    if ((int) strlen(t0[2]) != n_alpha || k < 1 || k > 12) goto done;
-    if (sa_split_ws(l1, &t1) != (int64_t) n_states * n_states + 1) goto done;
+    if ((int) strlen(t0[2]) != n_alpha || n_alpha < 1 || n_alpha > 60 || k < 1 || k > 12) goto done;
+    if (n_states != 3) { rc = SA_EUNSUPPORTED; goto done; } /* the 5-state machine aborts in the reference (impl/stateMachine.c:907) */
+    if (sa_split_ws(l1, &t1) != 10) goto done;               /* 3 x 3 transitions + 1 */
     double t10[10];
     for (int i = 0; i < 10; i++) t10[i] = strtod(t1[i], NULL);
     int64_t nk = 1;
@@ -173,6 +186,7 @@ int sa_model_load(sa_model_t **out, const char *model_path, const char *nhdp_pat
     int64_t n2 = sa_split_ws(l2, &t2);
     if (n2 != nk * 5) goto done;
     table = malloc(sizeof(double) * (size_t) n2);
+    if (!table) { rc = SA_ENOMEM; goto done; }
     for (int64_t i = 0; i < n2; i++) table[i] = strtod(t2[i], NULL);
     if (nhdp_path) {
         h = nhdp_read(nhdp_path);
@@ -201,8 +215,9 @@ done:
 static int parse_i64_line(char *line, int64_t expect, int64_t **out) {
     char **tok;
     int64_t n = sa_split_ws(line, &tok);
-    if (n != expect) { free(tok); return SA_EIO; }
+    if (n != expect || n < 0) { free(tok); return SA_EIO; }
     int64_t *v = malloc(sizeof(int64_t) * (size_t) (n > 0 ? n : 1));
+    if (!v) { free(tok); return SA_ENOMEM; }
     for (int64_t i = 0; i < n; i++) v[i] = strtoll(tok[i], NULL, 10);
     free(tok);
     *out = v;
@@ -218,13 +233,18 @@ void sa_npread_free(sa_npread_t *r) {
     free(r);
 }
 
+/* A sequence line of the .npRead: its first token, cut at the declared length as the reference does.  NULL when the
+ * declared length is negative or the line holds fewer characters than declared (the k-mer walk of the parameter estimation
+ * reads declared-length - k + 1 k-mers). */
 static char *first_token_copy(const char *line, int64_t want_len) {
+    if (want_len < 0) return NULL;
     while (*line == ' ' || *line == '\t') line++;
     size_t n = strcspn(line, " \t\r\n");
-    char *s = malloc(n + 1 > (size_t) want_len + 1 ? n + 1 : (size_t) want_len + 1);
-    memcpy(s, line, n);
-    s[n] = 0;
-    if ((int64_t) n > want_len) s[want_len] = 0; /* the reference terminates at the declared length */
+    if ((int64_t) n < want_len) return NULL;
+    char *s = malloc((size_t) want_len + 1);
+    if (!s) return NULL;
+    memcpy(s, line, (size_t) want_len);
+    s[want_len] = 0;
     return s;
 }
 
@@ -232,6 +252,7 @@ int sa_npread_load(const char *path, sa_npread_t **out) {
     FILE *f = fopen(path, "r");
     if (!f) return SA_EIO;
     sa_npread_t *r = calloc(1, sizeof(*r));
+    if (!r) { fclose(f); return SA_ENOMEM; }
     char *ln[14];
     memset(ln, 0, sizeof(ln));
     int rc = SA_EIO;
@@ -263,10 +284,15 @@ int sa_npread_load(const char *path, sa_npread_t **out) {
         free(t);
         free(h);
     }
+    if (r->read_length < 0 || r->n_template_events < 0 || r->n_complement_events < 0 || r->template_read_length < 0 ||
+        r->complement_read_length < 0)
+        goto done;
     r->two_d_read = r->two_d ? first_token_copy(ln[1], r->read_length) : strdup("");
     r->template_read = first_token_copy(ln[2], r->template_read_length);
+    if (!r->two_d_read || !r->template_read) goto done;
     if (parse_i64_line(ln[3], r->template_read_length, &r->template_strand_event_map)) goto done;
     r->complement_read = r->two_d ? first_token_copy(ln[4], r->complement_read_length) : strdup("");
+    if (!r->complement_read) goto done;
     if (parse_i64_line(ln[5], r->complement_read_length, &r->complement_strand_event_map)) goto done;
     if (parse_i64_line(ln[6], r->read_length, &r->template_event_map)) goto done;
     r->template_events = parse_doubles(ln[7], r->n_template_events * 4);

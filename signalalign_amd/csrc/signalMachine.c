@@ -428,6 +428,17 @@ static int prepare_read(const run_t *R, read_t *rd, int fatal) {
     }
     free(gx);
     free(gy);
+    if (!fatal) {
+        /* batch mode: the reads of a slice share one GPU batch, and the planner rejects a whole batch for one bad job
+         * (a reference window with a letter outside the alphabet, anchors that give an invalid diagonal).  The reference
+         * runs one process per read, so only that read may fail: plan every job alone on the host first (integer
+         * geometry only, no GPU) and drop the offender here. */
+        for (int s = 0; s < (R->two_d ? 2 : 1); s++) {
+            int rc = sa_plan_describe(s == 0 ? R->smt.model : R->smc.model, &R->p, &rd->jobs[s], R->ambig, 0, NULL, NULL, 0,
+                                      NULL, 0, NULL, 0);
+            if (rc != SA_OK) return fail(rd, 0, "alignment job rejected: %s", sa_strerror(rc));
+        }
+    }
     return 0;
 }
 

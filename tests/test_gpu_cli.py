@@ -215,12 +215,28 @@ def test_signalmachine_batch_front_door(oracle, tmp_path):
     manifest_rows.insert(1, "# a comment line")
     manifest_rows.append("\t".join(["broken", str(tmp_path / "missing.npRead"), str(tmp_path / "readA.cigar"),
                                     str(tmp_path / "broken.tsv")]))
+    # a read whose reference window holds a letter outside the model's alphabet: the planner rejects its job
+    # (kmer_id aborts in the reference, impl/nanopore_hdp.c:387-403 -- for that read's process only), so here only that read
+    # may fail, not the GPU batch it shares with the others
+    contig = "ACGTTGCA" * 20 + read + "GATTACA" * 10
+    fasta_n = str(tmp_path / "refN.fa")
+    _write_fasta(fasta_n, "chrN", contig[:160 + 700] + "N" + contig[160 + 701:])
+    os.remove(fasta_n + ".fai")                  # two records in one file: let the loader scan it (no index)
+    with open(fasta, "a") as f:
+        f.write(open(fasta_n).read())
+    os.remove(fasta + ".fai")
+    cigar_n = str(tmp_path / "readN.cigar")
+    with open(cigar_n, "w") as f:
+        f.write("cigar: readN %d %d + chrN %d %d + 1 M %d\n" % (400, 1900, 560, 2060, 1500))
+    manifest_rows.insert(2, "\t".join(["readN", npread_path, cigar_n, str(tmp_path / "readN.tsv"), "-", "chrN"]))
     manifest = str(tmp_path / "manifest.tsv")
     with open(manifest, "w") as f:
         f.write("\n".join(manifest_rows) + "\n")
     pr = subprocess.run([BIN] + common + ["--batch", manifest], capture_output=True, text=True, timeout=600)
-    assert pr.returncode == 1  # one read of the manifest is broken; the others are done
-    assert "read broken skipped" in pr.stderr and "3 of 4 reads aligned" in pr.stderr
+    assert pr.returncode == 1  # two reads of the manifest are broken; the others are done
+    assert "read broken skipped" in pr.stderr and "3 of 5 reads aligned" in pr.stderr
+    assert "read readN skipped: alignment job rejected: k-mer contains a character outside the model alphabet" in pr.stderr
+    assert not os.path.exists(str(tmp_path / "readN.tsv"))
     for name, _, _ in specs:
         assert open(str(tmp_path / (name + ".batch.tsv"))).read() == single_out[name][0], name
         assert single_out[name][1] in pr.stdout
@@ -230,7 +246,7 @@ def test_signalmachine_batch_front_door(oracle, tmp_path):
     # reused by the next, identical files (appended a second time) and the same summary
     pr = subprocess.run([BIN] + common + ["--batch", manifest, "--batch-reads", "2", "--mea"], capture_output=True, text=True,
                         timeout=600)
-    assert pr.returncode == 1 and "3 of 4 reads aligned" in pr.stderr
+    assert pr.returncode == 1 and "3 of 5 reads aligned" in pr.stderr
     for name, _, _ in specs:
         assert open(str(tmp_path / (name + ".batch.tsv"))).read() == 2 * single_out[name][0], name
         assert single_out[name][1] in pr.stdout

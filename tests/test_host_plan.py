@@ -365,3 +365,59 @@ def test_cigar_loader_on_the_reference_guide_alignment(oracle):
         # indel every ten to fifty bases)
         assert len(a[0]) == (m - 5 if trim == 0 else 1801)
     L.sa_cigar_free(pc)
+
+
+def test_loaders_reject_malformed_files(tmp_path):
+    """Malformed .model / .npRead / .nhdp files are refused with an error code -- no read past a short token list, no
+    write in front of a buffer for a negative declared length, no k-mer walk over a sequence shorter than declared.
+    (probes/host_asan.sh runs this file under AddressSanitizer + UBSan.)"""
+    import ctypes as C
+    L = sa.lib()
+    good = open(cases.MODEL_5MER).read().split("\n")
+    # a 2-state header with the 5 tokens that would pass a "n_states^2 + 1" check: must not index ten transitions
+    bad_model = tmp_path / "two_state.model"
+    bad_model.write_text("2\t4\tACGT\t5\n0.1 0.2 0.3 0.4 0.5\n" + good[2] + "\n")
+    h = C.c_void_p()
+    assert L.sa_model_load(C.byref(h), str(bad_model).encode(), None) != 0 and not h.value
+    short_table = tmp_path / "short_table.model"
+    short_table.write_text(good[0] + "\n" + good[1] + "\n" + " ".join(good[2].split()[:-5]) + "\n")
+    assert L.sa_model_load(C.byref(h), str(short_table).encode(), None) != 0 and not h.value
+    L.sa_npread_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    L.sa_npread_load.restype = C.c_int
+    L.sa_npread_free.argtypes = [C.c_void_p]
+    src = open(os.path.join(cases.GOLDEN, "npReads", "c2925_ecoli_ch34_read1023.npRead")).read().split("\n")
+    r = C.c_void_p()
+    ok = tmp_path / "ok.npRead"
+    ok.write_text("\n".join(src))
+    assert L.sa_npread_load(str(ok).encode(), C.byref(r)) == 0 and r.value
+    L.sa_npread_free(r)
+
+    def variant(name, edit):
+        lines = list(src)
+        edit(lines)
+        p = tmp_path / name
+        p.write_text("\n".join(lines))
+        out = C.c_void_p()
+        rc = L.sa_npread_load(str(p).encode(), C.byref(out))
+        assert rc != 0 and not out.value, name
+
+    def header(lines, idx, value):
+        t = lines[0].split()
+        t[idx] = str(value)
+        lines[0] = " ".join(t)
+    variant("neg_template_len.npRead", lambda l: header(l, 3, -1))
+    variant("neg_events.npRead", lambda l: header(l, 1, -4))
+    variant("short_template_read.npRead", lambda l: l.__setitem__(2, l[2].strip()[:-7]))
+    variant("short_event_map.npRead", lambda l: l.__setitem__(3, " ".join(l[3].split()[:-1])))
+    variant("truncated.npRead", lambda l: l.__delitem__(slice(6, None)))
+    # .nhdp: a zero grid length, and a file that ends inside the parent table (the dp-id list is already allocated)
+    nh = open(cases.NHDP).read().split("\n")
+    grid_line = 10                              # "grid_start grid_stop grid_length" (serialize_hdp, impl/hdp.c:2919-3050)
+    assert nh[grid_line].split() == ["0", "100", "100"]
+    for name, edit in (("zero_grid.nhdp", lambda l: l.__setitem__(grid_line, "0.0 100.0 0")),
+                       ("cut.nhdp", lambda l: l.__delitem__(slice(grid_line + 40, None)))):
+        lines = list(nh)
+        edit(lines)
+        p = tmp_path / name
+        p.write_text("\n".join(lines))
+        assert L.sa_model_load(C.byref(h), cases.MODEL_R73.encode(), str(p).encode()) != 0 and not h.value, name
