@@ -6,6 +6,7 @@ import subprocess
 import numpy as np
 import pytest
 
+import format_checks as fc
 import sa_cases as cases
 
 pytestmark = pytest.mark.gpu
@@ -89,6 +90,8 @@ def test_signalmachine_full_tsv(oracle, tmp_path, npread, model):
                                                           read_start, L, params)
     got = open(out).readlines()
     assert len(got) == len(rows)
+    # the checker that accepts the reference's own golden full TSV (tests/test_format_fixtures.py) accepts this file
+    fc.check_full_rows(open(out).read(), 5 if model == cases.MODEL_5MER else 6, "ACGT")
     bad = 0
     for g, e in zip(got, rows):
         if g != e:
@@ -188,6 +191,37 @@ def test_signalmachine_expectations_file(oracle, tmp_path):
     assert lines[3] == "0.000000\t" * (2 * n_kmers)
     assert lines[4] == "0.001000\t" * n_kmers
     assert lines[5] == "0\t" * n_kmers
+
+
+def test_signalmachine_expectations_file_matches_the_reference_golden_layout(oracle, tmp_path):
+    # The reference's golden Gaussian expectations file (tests/test_expectation_files/4f9a316c-...: ACEGT 6-mer) has
+    # 6 lines of 4 / 10 / 78125 / 31250 / 15625 / 15625 tokens, all but the transitions line tab-terminated.  The same
+    # model (the bundled R9.4 CpG model, ACEGT 6-mer) through -t here must give exactly that layout.
+    import gzip
+    model = cases.MODEL_CPG
+    npread_path = os.path.join(cases.GOLDEN, "npReads", "r9p4_oneD.npRead")
+    r = oracle.parse_npread(npread_path)
+    read = r["template_read"]
+    read_start, L = 0, 1500
+    fasta = str(tmp_path / "ref.fa")
+    _write_fasta(fasta, "chrE", "ACGT" * 10 + read[:L + 30])
+    cigar = str(tmp_path / "guide.cigar")
+    with open(cigar, "w") as f:
+        f.write("cigar: r %d %d + chrE 40 %d + 1 M %d\n" % (read_start, read_start + L, 40 + L, L))
+    out = str(tmp_path / "t.expectations")
+    pr = subprocess.run([BIN, "-T", model, "-q", npread_path, "-f", fasta, "-n", "chrE", "-p", cigar, "-t", out,
+                         "-L", "r", "-g", "100"], capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr
+    ours = fc.check_expectations_file(open(out).read(), 5, "ACEGT", 6)
+    gold = fc.check_expectations_file(
+        gzip.open(os.path.join(cases.GOLDEN, "format", "4f9a316c-8bb3-410a-8cfc-026061f7e8db.template.expectations.tsv.gz"),
+                  "rt").read(), 5, "ACEGT", 6)
+    count = lambda l: len([t for t in l.split("\t") if t != ""])
+    assert [count(l) for l in ours[:6]] == [count(l) for l in gold[:6]] == [4, 10, 78125, 31250, 15625, 15625]
+    assert ours[0] == gold[0]
+    # the two dead transitions sit at the pseudocount in both files; the likelihood is the per-diagonal sum (negative)
+    to, tg = ours[1].split("\t"), gold[1].split("\t")
+    assert to[5] == tg[5] == "0.001000" and to[7] == tg[7] == "0.001000" and float(to[9]) < 0 and float(tg[9]) < 0
 
 
 def test_signalmachine_batch_front_door(oracle, tmp_path):
@@ -373,6 +407,7 @@ def test_signalmachine_minus_strand_and_assignments(oracle, tmp_path):
         assert pr.returncode == 0, pr.stderr
     rows = [l.rstrip("\n").split("\t") for l in open(full)]
     arows = [l.rstrip("\n").split("\t") for l in open(assign)]
+    fc.check_assignment_rows(open(assign).read(), len(arows[0][0]), "ACGT")   # as the reference's golden assignments file
     assert len(rows) == len(pairs) == len(arows)
     ref_len, ref_len_kmers = len(target), len(target) - k
     for g, a, p in zip(rows, arows, pairs):
