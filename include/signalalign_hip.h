@@ -99,6 +99,8 @@ typedef struct sa_batch_stats {
     int64_t n_fast_regions;  /* regions handled by the register-resident kernels    */
     int64_t n_chunks;        /* passes needed to fit forward storage in HBM         */
     int64_t n_groups;        /* backward/posterior launches per pass (result copy of one overlaps the next) */
+    int64_t n_ring_regions;  /* regions handled by the LDS-ring kernels (several paths per cell, or a band mostly wider
+                                than a wave)                                           */
 } sa_batch_stats_t;
 
 /* ---- model -------------------------------------------------------------------------------------
@@ -165,12 +167,19 @@ typedef struct sa_plan_info {
     int64_t f_cellpaths;   /* cell-paths of forward storage */
     int64_t max_span;      /* widest 3-row window in (x-y)/2 units          */
     int64_t n_fast_regions;
+    int64_t n_ring_regions;
 } sa_plan_info_t;
 int sa_plan_describe(const sa_model_t *m, const sa_params_t *p, const sa_job_t *job, const char *const *ambig256,
                      unsigned flags, sa_plan_info_t *info,
                      int64_t *regions4_out, int64_t regions_cap,   /* x1,y1,x2,y2 per region             */
                      int64_t *rows3_out, int64_t rows_cap,         /* region,xmyL,xmyR per diagonal      */
                      int64_t *segs4_out, int64_t segs_cap);        /* region,start,from,to per traceback */
+
+/* Test hook (host only): the per-path neighbour records the planner writes for regions with ambiguous positions, checked
+ * against path_checkLegal (impl/pairwiseAligner.c:595-621) pair by pair.  Returns the number of wrong entries (0 = all
+ * good) or a negative SA_E* code; *n_checked = entries examined. */
+int64_t sa_plan_check_path_records(const sa_model_t *m, const sa_params_t *p, const sa_job_t *job,
+                                   const char *const *ambig256, int64_t *n_checked);
 
 /* ---- event <-> k-mer pre-alignment (the step upstream of the pair-HMM) ------------
  * adaptive_banded_simple_event_align (impl/eventAligner.c:899-1235): adaptive banded Viterbi of a raw event table

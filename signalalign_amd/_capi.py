@@ -48,7 +48,7 @@ class BatchStats(C.Structure):
                 ("ms_backward", C.c_double), ("ms_fold", C.c_double), ("ms_total_device", C.c_double),
                 ("f_bytes", C.c_double), ("n_regions", C.c_int64), ("n_segments", C.c_int64),
                 ("n_checkpoints", C.c_int64), ("n_fast_regions", C.c_int64), ("n_chunks", C.c_int64),
-                ("n_groups", C.c_int64)]
+                ("n_groups", C.c_int64), ("n_ring_regions", C.c_int64)]
 
 
 class EaJob(C.Structure):
@@ -68,7 +68,7 @@ MEA_STATUS = {0: "ok", 1: "empty", 2: "single event", 3: "no forward edge", 4: "
 class PlanInfo(C.Structure):
     _fields_ = [("n_regions", C.c_int64), ("n_segments", C.c_int64), ("n_checkpoints", C.c_int64),
                 ("cells_forward", C.c_double), ("cells_backward", C.c_double), ("f_cellpaths", C.c_int64),
-                ("max_span", C.c_int64), ("n_fast_regions", C.c_int64)]
+                ("max_span", C.c_int64), ("n_fast_regions", C.c_int64), ("n_ring_regions", C.c_int64)]
 
 
 PAIR_DTYPE = np.dtype([("prob_e7", "<i8"), ("x", "<i4"), ("y", "<i4"), ("path", "<i4"), ("kmer_id", "<i4")])
@@ -77,6 +77,7 @@ EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alp
            "sa_model_set_to_hdp_expected_values", "sa_kmer_id", "sa_default_ambig", "sa_load_ambig",
            "sa_batch_create", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_stats",
            "sa_batch_job_cells", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_plan_describe", "sa_plan_digest",
+           "sa_plan_check_path_records",
            "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_fasta_subsequence", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_strerror",
            "sa_version", "sa_free"]
 
@@ -522,3 +523,16 @@ def estimate_params(model, table5, strand_event_map, events4, strand_read):
     _chk(lib().sa_estimate_params(model._h, _dp(table5), _ip(em), _dp(events4), events4.shape[0],
                                   strand_read.encode(), len(strand_read), _dp(out)), "sa_estimate_params")
     return dict(zip(["scale", "shift", "var", "drift", "scale_sd", "var_sd", "shift_sd"], out.tolist()))
+
+
+def plan_check_path_records(model, params, job, ambig=None):
+    """Host-only test hook: (wrong entries, entries checked) of the per-path neighbour records of `job`'s plan."""
+    arr, keep = _make_jobs([job])
+    amb = ambig if ambig is not None else default_ambig()
+    n = C.c_int64(0)
+    L = lib()
+    L.sa_plan_check_path_records.restype = C.c_int64
+    bad = L.sa_plan_check_path_records(model._h, C.byref(params), arr, amb, C.byref(n))
+    if bad < 0:
+        _chk(int(bad), "sa_plan_check_path_records")
+    return int(bad), int(n.value)

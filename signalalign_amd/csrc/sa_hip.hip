@@ -61,6 +61,7 @@ struct DevPlan {
     const int *pid;
     const int *px;        // reference position (region-relative x) of every pid entry: cell-path -> cell
     const double *xc;
+    const sa_prec_t *prec; // per cell-path records of SA_KIND_RING regions with several paths per cell
     const double *ev;
     const sa_seg_t *segs;
     const sa_ck_t *cks;
@@ -162,6 +163,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
 }
 
 #include "sa_fast.inc"
+#include "sa_ring.inc"
 
 // ---------------------------------------------------------------------------------------------------
 // The memory-resident kernels come in two flavours.  EXACT (SA_FLAG_EXACT, the expectation pass, HDP with several
@@ -877,12 +879,16 @@ struct sa_launch_chunk {
     int ngr, nfr;
     long long ids_fw[7];       // register-kernel regions whose band needs 2..6 x 64 lanes (k_fwd_wide<S>), by S
     int nfw[7];
+    long long ids_rr[8];       // ring-kernel regions by class: [multi * 4 + cap class], cap = 64 << class
+    int nrr[8];
     int g0, g1;                // groups [g0, g1)
 };
 struct sa_launch_group {
     long long seg0, seg1, ck0, ck1;
     long long ids_gs, ids_fs, ids_ws;   // segments of memory-resident / register / register, wide-band regions
     int ngs, nfs, nws;
+    long long ids_rs[8];                // segments of ring-kernel regions, by the class of their region
+    int nrs[8];
 };
 
 struct sa_batch {
@@ -893,6 +899,7 @@ struct sa_batch {
     hipStream_t cstream[2];        // compute streams; groups alternate between them
     // device buffers
     sa_region_t *d_regions; sa_row_t *d_rows; int *d_pk; int *d_poff; int *d_pid; int *d_px; double *d_xc; double *d_ev;
+    sa_prec_t *d_prec;
     sa_seg_t *d_segs; sa_ck_t *d_cks;
     double *d_F; double *d_vbuf; sa_cand_t *d_cands; int *d_cand_count; int *d_overflow; double *d_totals;
     double *d_bscratch;
@@ -943,6 +950,7 @@ static DevPlan make_devplan(const sa_batch *b) {
     DevPlan P;
     memset(&P, 0, sizeof(P));
     P.regions = b->d_regions; P.rows = b->d_rows; P.pk = b->d_pk; P.poff = b->d_poff; P.pid = b->d_pid; P.px = b->d_px; P.xc = b->d_xc; P.ev = b->d_ev;
+    P.prec = b->d_prec;
     P.segs = b->d_segs; P.cks = b->d_cks; P.F = b->d_F; P.vbuf = b->d_vbuf; P.cands = b->d_cands;
     P.cand_count = b->d_cand_count; P.overflow = b->h_overflow; P.totals = b->d_totals; P.bscratch = b->d_bscratch;
     P.gsum = b->d_gsum; P.gmc = b->d_gmc;
@@ -1124,7 +1132,7 @@ void sa_batch_destroy(sa_batch_t *b) {
     for (int i = 0; i < 2; i++)
         if (b->cstream[i]) (void) hipStreamSynchronize(b->cstream[i]);
     if (b->pair_stream) (void) hipStreamSynchronize(b->pair_stream);
-    void *ptrs[] = {b->d_regions, b->d_rows, b->d_pk, b->d_poff, b->d_pid, b->d_px, b->d_xc, b->d_ev, b->d_segs, b->d_cks, b->d_F,
+    void *ptrs[] = {b->d_regions, b->d_rows, b->d_pk, b->d_poff, b->d_pid, b->d_px, b->d_xc, b->d_prec, b->d_ev, b->d_segs, b->d_cks, b->d_F,
                     b->d_vbuf, b->d_cands, b->d_cand_count, b->d_overflow, b->d_totals, b->d_bscratch, b->d_tab6,
                     b->d_hdp_slot, b->d_hdp_y, b->d_hdp_slope, b->d_hdp_grid, b->d_hdp_tab, b->d_prob, b->d_seg_pass, b->d_seg_off,
                     b->d_out, b->d_ids, b->d_gsum, b->d_gmc};
@@ -1187,6 +1195,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     b->ran = false;
     b->runner = nullptr; b->runner_rc = SA_OK;
     b->d_regions = nullptr; b->d_rows = nullptr; b->d_pk = nullptr; b->d_poff = nullptr; b->d_pid = nullptr; b->d_px = nullptr; b->d_xc = nullptr;
+    b->d_prec = nullptr;
     b->d_ev = nullptr; b->d_segs = nullptr; b->d_cks = nullptr; b->d_F = nullptr; b->d_vbuf = nullptr;
     b->d_cands = nullptr; b->d_cand_count = nullptr; b->d_overflow = nullptr; b->d_totals = nullptr;
     b->d_bscratch = nullptr; b->d_tab6 = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr;
@@ -1247,6 +1256,11 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     TRY(upload(&b->d_pk, pl->pk, pl->n_pk, 0, big_pinned));
     TRY(upload(&b->d_poff, pl->poff, pl->n_poff, 0, big_pinned));
     TRY(upload(&b->d_pid, pl->pid, pl->n_pid, 0, big_pinned));
+    {   // per-path records: only batches that hold ring-kernel regions with several paths per cell have (and read) them
+        bool need = false;
+        for (long long r = 0; r < pl->n_regions && !need; r++) need = pl->regions[r].kind == SA_KIND_RING && pl->regions[r].max_p > 1;
+        if (need && pl->prec) TRY(upload(&b->d_prec, pl->prec, pl->n_pid, 0, big_pinned));
+    }
     std::vector<int> px;   // (alive until the uploader has drained)
     {   // cell-path -> reference position, for the memory-resident kernels (one lane per cell-path); register-kernel
         // regions never read it
@@ -1358,9 +1372,15 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
             // against 20.9 ms forward on 2000 reads with realistic anchors (the path is bound by the fp64 logAdd
             // arithmetic, not by re-reading the band, and slot granularity adds idle lanes); DESIGN.md section 8.
             const bool wide_on = getenv("SA_WIDE_KERNEL") && atoi(getenv("SA_WIDE_KERNEL")) == 1 && m->hdp == nullptr;
+            std::vector<int> rr[8];
+            auto ring_class = [](const sa_region_t &Rq) {
+                const int cl = Rq.max_rowpaths <= 64 ? 0 : (Rq.max_rowpaths <= 128 ? 1 : (Rq.max_rowpaths <= 256 ? 2 : 3));
+                return (Rq.max_p > 1 ? 4 : 0) + cl;
+            };
             for (long long q = ra; q < rb; q++) {
                 const sa_region_t &Rq = pl->regions[q];
-                if (Rq.kind != SA_KIND_FAST) gr.push_back((int) q);
+                if (Rq.kind == SA_KIND_RING) rr[ring_class(Rq)].push_back((int) q);
+                else if (Rq.kind != SA_KIND_FAST) gr.push_back((int) q);
                 else if (wide_on && Rq.slots >= 2 && Rq.slots <= SA_WIDE_SLOTS_MAX) fw[2].push_back((int) q);
                 else fr.push_back((int) q);
                 work += (double) Rq.N;
@@ -1380,6 +1400,11 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
                 std::stable_sort(fw[sl].begin(), fw[sl].end(), by_work_r);
                 C.ids_fw[sl] = (long long) b->ids_flat.size(); C.nfw[sl] = (int) fw[sl].size();
                 b->ids_flat.insert(b->ids_flat.end(), fw[sl].begin(), fw[sl].end());
+            }
+            for (int cl = 0; cl < 8; cl++) {
+                std::stable_sort(rr[cl].begin(), rr[cl].end(), by_len_r);
+                C.ids_rr[cl] = (long long) b->ids_flat.size(); C.nrr[cl] = (int) rr[cl].size();
+                b->ids_flat.insert(b->ids_flat.end(), rr[cl].begin(), rr[cl].end());
             }
             C.g0 = (int) b->groups.size();
             // a group should still be a sizeable launch: at least 2048 segments each (measured optimum 6-8 groups
@@ -1407,7 +1432,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
                 while (q < rb && pl->regions[q].job == pl->regions[q - 1].job) { acc += (double) pl->regions[q].N; q++; }
                 sa_launch_group G;
                 G.seg0 = G.seg1 = G.ck0 = G.ck1 = 0;
-                std::vector<int> gs, fs, ws;
+                std::vector<int> gs, fs, ws, rs[8];
                 bool any = false;
                 // SA_WIDE_BWD=1 sends the segments of wide-band regions to k_bwd_fast_wide (loads of a wide diagonal
                 // batched, 2 waves per SIMD).  Off by default: it beats k_bwd_fast only when the launches are small
@@ -1417,7 +1442,8 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
                 for (long long t = qa; t < q; t++) {
                     const sa_region_t *R = &pl->regions[t];
                     for (long long sg = R->seg_off; sg < R->seg_off + R->n_seg; sg++) {
-                        (R->kind != SA_KIND_FAST ? gs : (wide_bwd && R->slots >= 2 ? ws : fs)).push_back((int) sg);
+                        if (R->kind == SA_KIND_RING) rs[ring_class(*R)].push_back((int) sg);
+                        else (R->kind != SA_KIND_FAST ? gs : (wide_bwd && R->slots >= 2 ? ws : fs)).push_back((int) sg);
                         const sa_seg_t *S = &pl->segs[sg];
                         if (!any) { G.seg0 = sg; G.ck0 = S->ck_base; any = true; }
                         G.seg1 = sg + 1;
@@ -1437,6 +1463,11 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
                 std::stable_sort(ws.begin(), ws.end(), by_len_s);
                 G.ids_ws = (long long) b->ids_flat.size(); G.nws = (int) ws.size();
                 b->ids_flat.insert(b->ids_flat.end(), ws.begin(), ws.end());
+                for (int cl = 0; cl < 8; cl++) {
+                    std::stable_sort(rs[cl].begin(), rs[cl].end(), by_len_s);
+                    G.ids_rs[cl] = (long long) b->ids_flat.size(); G.nrs[cl] = (int) rs[cl].size();
+                    b->ids_flat.insert(b->ids_flat.end(), rs[cl].begin(), rs[cl].end());
+                }
                 b->groups.push_back(G);
             }
             C.g1 = (int) b->groups.size();
@@ -1472,6 +1503,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     b->stats.n_segments = pl->n_segs;
     b->stats.n_checkpoints = pl->n_cks;
     b->stats.n_fast_regions = pl->n_fast_regions;
+    b->stats.n_ring_regions = pl->n_ring_regions;
     b->stats.n_chunks = pl->n_chunks;
     b->stats.n_groups = (int64_t) b->groups.size();
     double fb = 0;
@@ -1502,6 +1534,8 @@ static int submit_group(sa_batch *b, const DevPlan &P, int g, int which_stream, 
                            b->ring_cap);
     else if (G.ngs)
         hipLaunchKernelGGL((k_bwd_generic<false, false>), dim3(G.ngs), dim3(b->gen_threads), 0, st, P, b->d_ids + G.ids_gs, G.ngs, 0);
+    for (int cl = 7; cl >= 0; cl--)   // widest (longest-running) classes first
+        if (G.nrs[cl]) launch_bwd_ring(P, b->d_ids + G.ids_rs[cl], G.nrs[cl], st, 64 << (cl & 3), cl >= 4);
     if (G.nws) launch_bwd_fast(P, b->d_ids + G.ids_ws, G.nws, st, true);
     if (G.nfs) launch_bwd_fast(P, b->d_ids + G.ids_fs, G.nfs, st);
     HIPCHK(hipEventRecord(b->gev[4 * g + 1], st));
@@ -1537,6 +1571,11 @@ static int enqueue_pass(sa_batch *b, bool finalize, AfterGroup after_group) {
                                s0, P, b->d_ids + C.ids_gr, C.ngr, b->ring_cap);
         else if (C.ngr)
             hipLaunchKernelGGL(k_fwd_generic<false>, dim3(C.ngr), dim3(b->gen_threads), 0, s0, P, b->d_ids + C.ids_gr, C.ngr, 0);
+        for (int cl = 7; cl >= 0; cl--)
+            if (C.nrr[cl]) {
+                const int cap = 64 << (cl & 3);
+                launch_fwd_ring(P, b->d_ids + C.ids_rr[cl], C.nrr[cl], s0, cap, ring_fwd_waves(cap), cl >= 4);
+            }
         if (C.nfr) launch_fwd_fast(P, b->d_ids + C.ids_fr, C.nfr, s0, b->wide_cap);
         if (C.nfw[2]) launch_fwd_wide(P, b->d_ids + C.ids_fw[2], C.nfw[2], s0);
         HIPCHK(hipEventRecord(b->cev[2 * c + 1], s0));

@@ -56,7 +56,25 @@ typedef struct sa_row {
     int64_t foff;  /* offset (cell-paths) of the row inside the region's forward storage */
 } sa_row_t;        /* 16 bytes per anti-diagonal: with 9000 diagonals per read the largest array of a plan */
 
-enum { SA_KIND_GENERIC = 0, SA_KIND_FAST = 1 };
+/* SA_KIND_RING: lane-per-cell-path kernels with the three live diagonals' messages in an LDS ring (sa_ring.inc): regions with
+ * several paths per cell (ambiguous positions) and one-path regions whose band is mostly wider than a wave.  Forward storage
+ * in planes like SA_KIND_FAST; rows[d].foff holds (g0 << 32) | offset, g0 = poff[first x of the diagonal] (so that a
+ * diagonal's record is one 16-byte scalar load), and rows[N + 1] is a sentinel whose offset closes the last diagonal. */
+enum { SA_KIND_GENERIC = 0, SA_KIND_FAST = 1, SA_KIND_RING = 2 };
+#define SA_RING_MAX_ROWPATHS 512      /* widest diagonal (cell-paths) the LDS ring takes: 3 rows x 3 messages x 8 B x 512 = 36 KB */
+#define SA_RING_WIDE_FRACTION 0.5     /* one-path regions go to the ring kernels when more than this share of their cells lies on
+                                       * diagonals the register kernels cannot hold (SA_PK_FWD clear) */
+
+/* per cell-path record of SA_KIND_RING regions with several paths per cell (index: pid_off + poff[x] + path).
+ * Legal predecessors in column x-1 (path_checkLegal, impl/pairwiseAligner.c:595-621: k-1 shared letters) are the paths
+ * pred0 + i * stride, i < npred; legal successors in column x+1 the contiguous paths succ0 .. succ0 + nsucc - 1
+ * (both as region-relative path-space indices poff[.] + path; -1 / 0 when there is none). */
+typedef struct sa_prec {
+    int32_t x;
+    int32_t pred0;
+    int32_t succ0;
+    uint32_t meta;     /* stride << 16 | npred << 8 | nsucc */
+} sa_prec_t;
 
 typedef struct sa_region {
     int32_t job, kind;
@@ -74,7 +92,7 @@ typedef struct sa_region {
     int32_t max_rowpaths;
     int32_t slots;    /* 64-lane slots the widest 3-diagonal window needs               */
     int32_t chunk;    /* which forward-storage pass handles this region                 */
-    int32_t pad;
+    int32_t max_p;    /* paths of the cell with the most                                */
     double scale, shift, var, lvar; /* lvar = log(1/var), impl/stateMachine.c:602       */
     int64_t f_cellpaths;
 } sa_region_t;
@@ -137,6 +155,8 @@ typedef struct sa_plan {
     int32_t *poff;        int64_t n_poff, cap_poff;
     int32_t *pid;         int64_t n_pid, cap_pid;
     double *xc;           /* 4 doubles per pid entry: m, inv_s, cM, cY (read-params folded in) */
+    sa_prec_t *prec;      /* one per pid entry (allocated when the batch may hold SA_KIND_RING regions with several paths) */
+    int64_t prec_cap;
     double *ev;           int64_t n_ev, cap_ev;
     sa_seg_t *segs;       int64_t n_segs, cap_segs;
     sa_ck_t *cks;         int64_t n_cks, cap_cks;
@@ -147,6 +167,7 @@ typedef struct sa_plan {
     int32_t n_chunks;
     double cells_fwd, cells_bwd;
     int64_t n_fast_regions;
+    int64_t n_ring_regions;
     int64_t max_span;
     int32_t pooled;       /* rows, pk, poff, pid, xc, ev came from plan_big_alloc and go back to its cache */
     void (*big_free)(void *p, size_t bytes); /* ... or from the caller's allocator (sa_plan_use_allocator): pinned host

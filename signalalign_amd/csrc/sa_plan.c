@@ -446,6 +446,7 @@ void sa_plan_free(sa_plan_t *pl) {
         pl->big_free(pl->poff, sizeof(int32_t) * (size_t) (pl->cap_poff > 0 ? pl->cap_poff : 1));
         pl->big_free(pl->pid, sizeof(int32_t) * (size_t) (pl->cap_pid > 0 ? pl->cap_pid : 1));
         if (pl->xc) pl->big_free(pl->xc, sizeof(double) * 4 * (size_t) (pl->cap_pid > 0 ? pl->cap_pid : 1));
+        if (pl->prec) pl->big_free(pl->prec, sizeof(sa_prec_t) * (size_t) (pl->cap_pid > 0 ? pl->cap_pid : 1));
         pl->big_free(pl->ev, sizeof(double) * (size_t) (pl->cap_ev > 0 ? pl->cap_ev : 1));
     } else if (pl->pooled) { /* sizes as allocated by sa_plan_build */
         plan_big_free(pl->rows, sizeof(sa_row_t) * (size_t) (pl->cap_rows > 0 ? pl->cap_rows : 1));
@@ -453,12 +454,93 @@ void sa_plan_free(sa_plan_t *pl) {
         plan_big_free(pl->poff, sizeof(int32_t) * (size_t) (pl->cap_poff > 0 ? pl->cap_poff : 1));
         plan_big_free(pl->pid, sizeof(int32_t) * (size_t) (pl->cap_pid > 0 ? pl->cap_pid : 1));
         plan_big_free(pl->xc, sizeof(double) * 4 * (size_t) (pl->cap_pid > 0 ? pl->cap_pid : 1));
+        plan_big_free(pl->prec, sizeof(sa_prec_t) * (size_t) (pl->cap_pid > 0 ? pl->cap_pid : 1));
         plan_big_free(pl->ev, sizeof(double) * (size_t) (pl->cap_ev > 0 ? pl->cap_ev : 1));
     } else if (!pl->borrowed) {
-        free(pl->rows); free(pl->pk); free(pl->poff); free(pl->pid); free(pl->xc); free(pl->ev);
+        free(pl->rows); free(pl->pk); free(pl->poff); free(pl->pid); free(pl->xc); free(pl->ev); free(pl->prec);
     }
     free(pl->segs); free(pl->cks);
     free(pl);
+}
+
+static int ring_env_on(void) { /* SA_RING=0: never use the ring kernels (test / comparison hook) */
+    const char *e = getenv("SA_RING");
+    return !(e && atoi(e) == 0);
+}
+static int ring_wide_env_on(void) { /* SA_RING_WIDE=0: one-path regions stay on the register kernels whatever their band */
+    const char *e = getenv("SA_RING_WIDE");
+    return !(e && atoi(e) == 0);
+}
+/* The index form of path legality (fill_prec) needs the options of every ambiguity letter to be distinct characters */
+static int ambig_options_distinct(const char *const *ambig) {
+    if (!ambig) return 1;
+    for (int ch = 0; ch < 256; ch++) {
+        const char *r = ambig[ch];
+        if (!r) continue;
+        for (int i = 0; r[i]; i++)
+            for (int j = i + 1; r[j]; j++)
+                if (r[i] == r[j]) return 0;
+    }
+    return 1;
+}
+
+/* Per cell-path records of a SA_KIND_RING region with ambiguous positions.  Paths of column x enumerate the substitutions of
+ * the window s[x-1 .. x+k-2] with the LAST position varying fastest (expand_kmer), so with n(c) options for letter c,
+ *   shared(x) = product of n over the first k-1 letters of the window = P(x) / n(last letter),
+ * path p of column x and path q of column x-1 are a legal step (k-1 shared letters, path_checkLegal) iff
+ *   q mod shared(x) == p / n(last letter of x):
+ * the legal predecessors of p are q = j * shared(x) + p / n_last(x), j < n(first letter of x-1) (strided), and the legal
+ * successors of q in column x+1 are the n_last(x+1) consecutive paths from (q mod shared(x+1)) * n_last(x+1).  The NULL
+ * k-mer of column 0 is a legal neighbour of everything (path_checkLegal with a NULL k-mer). */
+static int fill_prec(sa_plan_t *pl, const sa_region_t *R, const char *s, const char *const *ambig) {
+    const int k = pl->model->k;
+    const int64_t lX = R->lX;
+    if (!pl->prec) {
+        if (pl->borrowed) return SA_EINVAL; /* sized by sa_plan_build whenever a thread counted several paths */
+        pl->prec = calloc((size_t) (pl->cap_pid > 0 ? pl->cap_pid : 1), sizeof(sa_prec_t));
+        if (!pl->prec) return SA_ENOMEM;
+        pl->prec_cap = pl->cap_pid;
+    } else if (!pl->borrowed && pl->prec_cap < pl->cap_pid) {
+        sa_prec_t *np_ = realloc(pl->prec, sizeof(sa_prec_t) * (size_t) pl->cap_pid);
+        if (!np_) return SA_ENOMEM;
+        memset(np_ + pl->prec_cap, 0, sizeof(sa_prec_t) * (size_t) (pl->cap_pid - pl->prec_cap));
+        pl->prec = np_;
+        pl->prec_cap = pl->cap_pid;
+    }
+    const int32_t *poff = pl->poff + R->poff_off;
+    sa_prec_t *pr = pl->prec + R->pid_off;
+#define NOPT(c) ((ambig && ambig[(unsigned char) (c)]) ? (int64_t) strlen(ambig[(unsigned char) (c)]) : 1)
+    /* column 0: the NULL k-mer; every path of column 1 is a successor */
+    {
+        int64_t P1 = lX >= 1 ? poff[2] - poff[1] : 0;
+        if (P1 > 255) return SA_EUNSUPPORTED;
+        pr[0].x = 0; pr[0].pred0 = -1; pr[0].succ0 = lX >= 1 ? poff[1] : -1;
+        pr[0].meta = (uint32_t) P1;
+    }
+    for (int64_t x = 1; x <= lX; x++) {
+        const char *w = s + (x - 1);
+        const int64_t P = poff[x + 1] - poff[x];
+        const int64_t n_last = NOPT(w[k - 1]);
+        const int64_t shared = P / n_last;
+        int64_t npred = 1, stride = 0;
+        if (x >= 2) { npred = NOPT(w[-1]); stride = shared; }
+        int64_t nsucc = 0, shared_n = 1, n_last_n = 1;
+        if (x < lX) {
+            n_last_n = NOPT(w[k]);
+            shared_n = P / NOPT(w[0]);
+            nsucc = n_last_n;
+        }
+        if (npred > 255 || nsucc > 255 || stride > 65535) return SA_EUNSUPPORTED;
+        for (int64_t p = 0; p < P; p++) {
+            sa_prec_t *o = &pr[poff[x] + p];
+            o->x = (int32_t) x;
+            o->pred0 = (int32_t) (x >= 2 ? poff[x - 1] + p / n_last : 0);
+            o->succ0 = x < lX ? (int32_t) (poff[x + 1] + (p % shared_n) * n_last_n) : -1;
+            o->meta = (uint32_t) (stride << 16) | (uint32_t) (npred << 8) | (uint32_t) nsucc;
+        }
+    }
+#undef NOPT
+    return SA_OK;
 }
 
 static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc, const int64_t *ax, const int64_t *ay,
@@ -516,13 +598,13 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
         free(lo); free(hi); free(span3);
         return rcode;
     }
-    if (pl->n_rows + N + 1 > pl->cap_rows) {
+    if (pl->n_rows + N + 2 > pl->cap_rows) {
         if (pl->borrowed) {
             free(lo); free(hi); free(span3);
             return SA_EINVAL; /* the counting pass undercounted */
         }
         int64_t nc = pl->cap_rows ? pl->cap_rows * 2 : 4096;
-        while (nc < pl->n_rows + N + 1) nc *= 2;
+        while (nc < pl->n_rows + N + 2) nc *= 2;
         void *np_ = realloc(pl->rows, sizeof(sa_row_t) * (size_t) nc);
         if (!np_) {
             free(lo); free(hi); free(span3);
@@ -533,7 +615,7 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
     }
     R->row_off = pl->n_rows;
     sa_row_t *rows = pl->rows + pl->n_rows;
-    pl->n_rows += N + 1;
+    pl->n_rows += N + 2; /* one sentinel row behind diagonal N (SA_KIND_RING: its offset closes the last diagonal) */
     poff = pl->poff + R->poff_off;
     int64_t K = lY + (lY & 1) + 2;
     R->K = (int32_t) K;
@@ -589,7 +671,33 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
     R->slots = (int32_t) ((span + 63) / 64);
     if (span > pl->max_span) pl->max_span = span;
     if (foff + 1 > SA_FAST_MAX_CELLS || ((lX + lY + K) >> 1) >= (1ll << (31 - SA_PK_SHIFT))) fast_ok = 0;
-    R->kind = fast_ok ? SA_KIND_FAST : SA_KIND_GENERIC;
+    rows[N + 1].xmyL = 0; rows[N + 1].width = 0; rows[N + 1].foff = foff;
+    /* ring kernels (sa_ring.inc): several paths per cell, or one path and a band mostly wider than a wave */
+    int ring_ok = !(pl->flags & (SA_FLAG_EXACT | SA_FLAG_FORCE_GENERIC | SA_FLAG_EXPECT_INTERNAL)) && m->hdp == NULL &&
+                  max_rowpaths <= SA_RING_MAX_ROWPATHS && foff + 1 <= SA_FAST_MAX_CELLS && ring_env_on() &&
+                  (maxP == 1 || (maxP <= 255 && ambig_options_distinct(ambig)));
+    int use_ring = 0;
+    if (ring_ok && maxP > 1) use_ring = 1;
+    if (ring_ok && maxP == 1 && fast_ok) {
+        double wide_cells = 0;
+        for (int64_t d = 1; d <= N; d++)
+            if (span3[d] > 64) wide_cells += (double) rows[d].width;
+        use_ring = wide_cells > SA_RING_WIDE_FRACTION * cf && ring_wide_env_on();
+    }
+    if (use_ring) {
+        fast_ok = 0;
+        for (int64_t d = 0; d <= N + 1; d++) { /* (g0 << 32) | offset: see sa_internal.h */
+            int64_t g0 = d <= N ? (int64_t) poff[(d + lo[d]) / 2] : 0;
+            rows[d].foff |= g0 << 32;
+        }
+        if (maxP > 1) {
+            int rcp = fill_prec(pl, R, jb->ref + rc.x1, ambig);
+            if (rcp) { free(lo); free(hi); free(span3); return rcp; }
+        }
+        pl->n_ring_regions++;
+    }
+    R->kind = use_ring ? SA_KIND_RING : (fast_ok ? SA_KIND_FAST : SA_KIND_GENERIC);
+    R->max_p = maxP; /* 1: the ring kernels skip the per-path records */
     if (fast_ok) pl->n_fast_regions++;
 
     /* traceback schedule */
@@ -643,7 +751,7 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
         S->cand_off = pl->n_cand;
         pl->n_cand += cap;
         S->bscratch_off = pl->n_bscratch;
-        pl->n_bscratch += 12 * (int64_t) max_rowpaths;
+        if (R->kind != SA_KIND_RING) pl->n_bscratch += 12 * (int64_t) max_rowpaths; /* the ring kernels keep backward rows in LDS */
         traced_to = S->from;
     }
     R->n_seg = (int32_t) (pl->n_segs - R->seg_off);
@@ -843,7 +951,7 @@ static void *count_worker(void *arg) {
         for (int64_t i = 0; i < nr; i++) {
             const int64_t rX = rects[i].x2 - rects[i].x1, rY = rects[i].y2 - rects[i].y1, N = rX + rY;
             if (N == 0) continue;
-            c->cap_rows += N + 1;
+            c->cap_rows += N + 2;
             c->cap_pk += N + 1 + SA_PK_PAD + 160;
             c->cap_poff += rX + 2;
             int64_t paths = 1; /* the NULL k-mer of x = 0 */
@@ -854,6 +962,7 @@ static void *count_worker(void *arg) {
                 paths += total;
             }
             c->cap_pid += paths;
+            if (paths > rX + 1) c->prec_cap = 1; /* several paths somewhere: the planning pass may write per-path records */
         }
         free(rects);
     }
@@ -1003,6 +1112,16 @@ int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, co
             pl->pid = get(sizeof(int32_t) * (size_t) (ti > 0 ? ti : 1));
             pl->xc = (flags & SA_FLAG_DEVICE_XC_INTERNAL) ? NULL : get(sizeof(double) * 4 * (size_t) (ti > 0 ? ti : 1));
             pl->ev = get(sizeof(double) * (size_t) (te > 0 ? te : 1));
+            int want_prec = 0;
+            for (int t = 0; t < T; t++) want_prec |= W[t].pl->prec_cap != 0;
+            want_prec = want_prec && !(flags & (SA_FLAG_EXACT | SA_FLAG_FORCE_GENERIC | SA_FLAG_EXPECT_INTERNAL)) && m->hdp == NULL &&
+                        ring_env_on();
+            if (want_prec) {
+                pl->prec = get(sizeof(sa_prec_t) * (size_t) (ti > 0 ? ti : 1));
+                if (!pl->prec) rc = SA_ENOMEM;
+                else memset(pl->prec, 0, sizeof(sa_prec_t) * (size_t) (ti > 0 ? ti : 1));
+                pl->prec_cap = ti;
+            }
             if (!pl->rows || !pl->pk || !pl->poff || !pl->pid || (!pl->xc && !(flags & SA_FLAG_DEVICE_XC_INTERNAL)) || !pl->ev)
                 rc = SA_ENOMEM;
             tr = tk = to = ti = te = 0;
@@ -1011,6 +1130,7 @@ int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, co
                 s->borrowed = 1;
                 s->rows = pl->rows + tr; s->pk = pl->pk + tk; s->poff = pl->poff + to; s->pid = pl->pid + ti;
                 s->xc = pl->xc ? pl->xc + 4 * ti : NULL; s->ev = pl->ev + te;
+                s->prec = pl->prec ? pl->prec + ti : NULL; s->prec_cap = pl->prec ? s->cap_pid : 0;
                 tr += s->cap_rows; tk += s->cap_pk; to += s->cap_poff; ti += s->cap_pid; te += s->cap_ev;
             }
         }
@@ -1046,6 +1166,7 @@ int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, co
                 b.n_pid += s->n_pid; b.n_ev += s->n_ev; b.n_segs += s->n_segs; b.n_cks += s->n_cks;
                 b.n_vbuf += s->n_vbuf; b.n_cand += s->n_cand; b.n_bscratch += s->n_bscratch;
                 b.cells_fwd += s->cells_fwd; b.cells_bwd += s->cells_bwd; b.n_fast_regions += s->n_fast_regions;
+                b.n_ring_regions += s->n_ring_regions;
                 if (s->max_span > b.max_span) b.max_span = s->max_span;
             }
             if (rc == SA_OK) {
@@ -1062,6 +1183,7 @@ int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, co
                 pl->n_ev = pl->cap_ev = b.n_ev; pl->n_segs = pl->cap_segs = b.n_segs; pl->n_cks = pl->cap_cks = b.n_cks;
                 pl->n_vbuf = b.n_vbuf; pl->n_cand = b.n_cand; pl->n_bscratch = b.n_bscratch;
                 pl->cells_fwd = b.cells_fwd; pl->cells_bwd = b.cells_bwd; pl->n_fast_regions = b.n_fast_regions;
+                pl->n_ring_regions = b.n_ring_regions;
                 pl->max_span = b.max_span;
             }
             free(M);
@@ -1175,6 +1297,7 @@ int sa_plan_describe(const sa_model_t *m, const sa_params_t *p, const sa_job_t *
         info->f_cellpaths = pl->max_chunk_cellpaths;
         info->max_span = pl->max_span;
         info->n_fast_regions = pl->n_fast_regions;
+        info->n_ring_regions = pl->n_ring_regions;
     }
     int64_t nrow = 0;
     for (int64_t r = 0; r < pl->n_regions; r++) {
@@ -1198,6 +1321,61 @@ int sa_plan_describe(const sa_model_t *m, const sa_params_t *p, const sa_job_t *
         }
     sa_plan_free(pl);
     return SA_OK;
+}
+
+/* Test hook (host only): plans one job and checks the per-path records of its ring-kernel regions against the definition
+ * they abbreviate -- path q of column x-1 and path p of column x are neighbours iff q's k-mer minus its first letter equals
+ * p's k-mer minus its last (path_checkKmerLegalTransition, impl/pairwiseAligner.c:595-608), the NULL k-mer of column 0
+ * being everybody's neighbour.  Returns the number of (column, path) entries whose predecessor or successor set differs,
+ * or a negative error; *n_checked receives the number of entries looked at (0: the job has no such region). */
+int64_t sa_plan_check_path_records(const sa_model_t *m, const sa_params_t *p, const sa_job_t *job, const char *const *ambig,
+                                   int64_t *n_checked) {
+    sa_plan_t *pl = NULL;
+    int rc = sa_plan_build(&pl, m, p, job, 1, ambig, 0, 0);
+    if (rc) return rc;
+    int64_t bad = 0, seen = 0;
+    for (int64_t r = 0; r < pl->n_regions; r++) {
+        const sa_region_t *R = &pl->regions[r];
+        if (R->kind != SA_KIND_RING || R->max_p <= 1) continue;
+        const int32_t *poff = pl->poff + R->poff_off, *pid = pl->pid + R->pid_off;
+        const sa_prec_t *pr = pl->prec + R->pid_off;
+        for (int64_t x = 0; x <= R->lX; x++)
+            for (int32_t g = poff[x]; g < poff[x + 1]; g++, seen++) {
+                const sa_prec_t *o = &pr[g];
+                int ok = o->x == x;
+                const int npred = (int) ((o->meta >> 8) & 255u), nsucc = (int) (o->meta & 255u), stride = (int) (o->meta >> 16);
+                /* predecessors: column x-1 */
+                if (x >= 1) {
+                    int64_t cnt = 0;
+                    for (int32_t q = poff[x - 1]; q < poff[x]; q++) {
+                        const int legal = pid[q] < 0 || pid[g] < 0 || (pid[q] % m->pow_km1) == (pid[g] / m->n_alpha);
+                        int listed = 0;
+                        for (int i = 0; i < npred; i++) listed |= (o->pred0 + i * stride) == q;
+                        ok &= legal == listed;
+                        cnt += legal;
+                    }
+                    ok &= cnt == npred;
+                } else {
+                    ok &= o->pred0 < 0 || npred == 0;
+                }
+                if (x < R->lX) {
+                    int64_t cnt = 0;
+                    for (int32_t q = poff[x + 1]; q < poff[x + 2]; q++) {
+                        const int legal = pid[q] < 0 || pid[g] < 0 || (pid[g] % m->pow_km1) == (pid[q] / m->n_alpha);
+                        const int listed = q >= o->succ0 && q < o->succ0 + nsucc;
+                        ok &= legal == listed;
+                        cnt += legal;
+                    }
+                    ok &= cnt == nsucc;
+                } else {
+                    ok &= o->succ0 < 0 || nsucc == 0;
+                }
+                bad += !ok;
+            }
+    }
+    if (n_checked) *n_checked = seen;
+    sa_plan_free(pl);
+    return bad;
 }
 
 static uint64_t fnv1a(uint64_t h, const void *data, size_t n) {
@@ -1225,6 +1403,7 @@ int sa_plan_digest(const sa_model_t *m, const sa_params_t *p, const sa_job_t *jo
         info->f_cellpaths = pl->max_chunk_cellpaths;
         info->max_span = pl->max_span;
         info->n_fast_regions = pl->n_fast_regions;
+        info->n_ring_regions = pl->n_ring_regions;
     }
     if (digest) {
         uint64_t h = 1469598103934665603ull;
@@ -1238,6 +1417,11 @@ int sa_plan_digest(const sa_model_t *m, const sa_params_t *p, const sa_job_t *jo
         h = fnv1a(h, pl->ev, sizeof(double) * (size_t) pl->n_ev);
         h = fnv1a(h, pl->segs, sizeof(sa_seg_t) * (size_t) pl->n_segs);
         h = fnv1a(h, pl->cks, sizeof(sa_ck_t) * (size_t) pl->n_cks);
+        for (int64_t r = 0; r < pl->n_regions; r++) { /* per-path records exist for these regions only */
+            const sa_region_t *R = &pl->regions[r];
+            if (R->kind == SA_KIND_RING && R->max_p > 1)
+                h = fnv1a(h, pl->prec + R->pid_off, sizeof(sa_prec_t) * (size_t) pl->poff[R->poff_off + R->lX + 1]);
+        }
         int64_t tail[4] = {pl->n_vbuf, pl->n_cand, pl->n_bscratch, pl->n_chunks};
         h = fnv1a(h, tail, sizeof(tail));
         *digest = h;

@@ -183,19 +183,103 @@ def test_threshold_zero_and_one(oracle):
         assert np.array_equal(got[0]["prob_e7"], exp["prob_e7"])
 
 
-def test_sparse_anchors_wide_bands(oracle):
+def test_sparse_anchors_wide_bands(oracle, monkeypatch):
     # realistic guide alignments: anchor-free windows widen the band beyond 64 cells, the register kernels
     # must hand over to the memory-resident path and back
     pm, om = _models(oracle, cases.MODEL_6MER)
     p = sa.default_params()
     op = cases.oracle_params(oracle, p)
     jobs = cases.synthetic_jobs(cases.MODEL_6MER, 3, 3000, 700, thin_anchors=0.35)
+    exp = [cases.oracle_pairs(oracle, om, job, op) for job in jobs]
+    for ring_wide in ("0", "1"):     # 0: register kernels with their memory-resident hand-over; 1: default routing
+        monkeypatch.setenv("SA_RING_WIDE", ring_wide)
+        got, st = _run(pm, p, jobs)
+        assert st.n_fast_regions + st.n_ring_regions == st.n_regions
+        if ring_wide == "0":
+            assert st.n_fast_regions == st.n_regions
+        for j, job in enumerate(jobs):
+            w, lonely = cases.compare_pairs(got[j], exp[j], TOL_E7, p.threshold)
+            assert cases.same_order(got[j], exp[j])
+
+
+def test_ring_kernels_wide_bands_every_read_against_the_oracle(oracle, monkeypatch):
+    """Anchors as sparse as a real guide alignment leaves them (tests/golden/cigars/ecoli_minus_strand.cigar, -m 14):
+    bands of 100-300 cells.  Such regions run on the LDS-ring kernels (one lane per cell, rows of 128 / 256 / 512
+    cell-paths by the widest diagonal of the region); every read is compared with the CPU restatement, and with the
+    register kernels' own wide-band path (SA_RING_WIDE=0), which computes the same arithmetic in another order."""
+    pm, om = _models(oracle, cases.MODEL_6MER)
+    p = sa.default_params()
+    op = cases.oracle_params(oracle, p)
+    jobs = cases.realistic_anchor_jobs(cases.MODEL_6MER, 10, 2500, 600)
+    alpha, k, t10, tab = synth.parse_model_table(cases.MODEL_6MER)
+    for n_ev, idx in ((260, 41), (520, 42), (90, 43)):   # no anchors at all: the band is the whole matrix (rows up to ~400 cells)
+        r = synth.make_read(idx, n_ev, alpha, k, tab)
+        jobs.append(dict(r, ax=np.zeros(0, dtype=np.int64), ay=np.zeros(0, dtype=np.int64)))
+    jobs += cases.synthetic_jobs(cases.MODEL_6MER, 3, 900, 300)      # dense anchors: these stay on the register kernels
     got, st = _run(pm, p, jobs)
-    assert st.n_fast_regions == st.n_regions
+    assert st.n_ring_regions >= 12 and st.n_fast_regions >= 3 and st.n_ring_regions + st.n_fast_regions == st.n_regions
+    worst = 0
     for j, job in enumerate(jobs):
         exp = cases.oracle_pairs(oracle, om, job, op)
         w, lonely = cases.compare_pairs(got[j], exp, TOL_E7, p.threshold)
-        assert cases.same_order(got[j], exp)
+        worst = max(worst, w)
+        assert lonely <= 2 and cases.same_order(got[j], exp), j
+    assert worst <= 10
+    for waves in ("1", "2", "4"):                     # workgroup size of the forward ring kernel: same bytes
+        monkeypatch.setenv("SA_RING_WAVES", waves)
+        again, _ = _run(pm, p, jobs)
+        for j in range(len(jobs)):
+            assert np.array_equal(again[j], got[j]), (waves, j)
+    monkeypatch.delenv("SA_RING_WAVES")
+    monkeypatch.setenv("SA_RING_WIDE", "0")
+    fast, st2 = _run(pm, p, jobs)
+    assert st2.n_ring_regions == 0
+    for j in range(len(jobs)):
+        cases.compare_pairs(got[j], fast[j], 10, p.threshold)
+
+
+def test_ring_kernels_ambiguous_positions_every_read_against_the_oracle(oracle, monkeypatch):
+    """BASELINE configs[2] shape (ACEGT model, every CpG cytosine X -> C/E: 1, 2, 4 or 8 paths per cell) and the R7.3
+    ACEGOT model with the default table's three-way code L -> C/E/O: the ring kernels with per-path neighbour records
+    against the CPU restatement for every read, and against the memory-resident kernels (SA_RING=0)."""
+    p = sa.default_params()
+    op = cases.oracle_params(oracle, p)
+    for model, amb_tab, jobs in (
+            (cases.MODEL_CPG, {"X": "CE"}, cases.synthetic_jobs(cases.MODEL_CPG, 6, 1400, 20, cpg_ambiguous=True) +
+             cases.realistic_anchor_jobs(cases.MODEL_CPG, 2, 1200, 77)),
+            (cases.MODEL_R73, None, None)):
+        pm, om = _models(oracle, model)
+        amb_p = sa.default_ambig(amb_tab)
+        amb_o = oracle.ambig_map(amb_tab)
+        if jobs is None:
+            jobs = []
+            for j, job in enumerate(cases.synthetic_jobs(model, 3, 600, 50)):
+                ref = list(job["ref"])
+                for i in range(7 + j, len(ref) - 6, 23):
+                    if ref[i] == "C":
+                        ref[i] = "L"
+                jobs.append(dict(job, ref="".join(ref)))
+        else:
+            jobs[-1] = dict(jobs[-1], ref=jobs[-1]["ref"].replace("CG", "XG"))
+            jobs[-2] = dict(jobs[-2], ref=jobs[-2]["ref"].replace("CG", "XG"))
+        got, st = _run(pm, p, jobs, ambig=amb_p)
+        assert st.n_ring_regions == st.n_regions == len(jobs)
+        worst = 0
+        for j, job in enumerate(jobs):
+            exp = cases.oracle_pairs(oracle, om, job, op, ambig=amb_o)
+            assert exp["path"].max() >= 1
+            w, lonely = cases.compare_pairs(got[j], exp, TOL_E7, p.threshold)
+            worst = max(worst, w)
+            assert lonely <= 2 and cases.same_order(got[j], exp), j
+            ek = {(int(r["x"]), int(r["y"]), int(r["path"])): int(r["kmer_id"]) for r in exp}
+            assert all(ek.get((int(r["x"]), int(r["y"]), int(r["path"])), int(r["kmer_id"])) == int(r["kmer_id"]) for r in got[j])
+        assert worst <= 10
+        monkeypatch.setenv("SA_RING", "0")
+        old, st2 = _run(pm, p, jobs, ambig=amb_p)
+        monkeypatch.delenv("SA_RING")
+        assert st2.n_ring_regions == 0
+        for j in range(len(jobs)):
+            cases.compare_pairs(got[j], old[j], 10, p.threshold)
 
 
 def test_wide_band_kernels_bit_identical_and_close_to_oracle(oracle, monkeypatch):
@@ -205,6 +289,7 @@ def test_wide_band_kernels_bit_identical_and_close_to_oracle(oracle, monkeypatch
     p = sa.default_params()
     jobs = cases.realistic_anchor_jobs(cases.MODEL_6MER, 8, 2500, 600)
     jobs += cases.synthetic_jobs(cases.MODEL_6MER, 4, 900, 300)  # narrow regions stay on k_fwd_fast
+    monkeypatch.setenv("SA_RING_WIDE", "0")    # these variants belong to the register kernels (default: ring kernels)
     want, _st = _run(pm, p, jobs)
     monkeypatch.setenv("SA_WIDE_KERNEL", "1")
     got, _st = _run(pm, p, jobs)

@@ -421,3 +421,48 @@ def test_loaders_reject_malformed_files(tmp_path):
         p = tmp_path / name
         p.write_text("\n".join(lines))
         assert L.sa_model_load(C.byref(h), cases.MODEL_R73.encode(), str(p).encode()) != 0 and not h.value, name
+
+
+def test_ring_kernel_routing_and_path_records(oracle):
+    """Regions with ambiguous positions, and one-path regions whose band is mostly wider than a wave, are planned for the
+    LDS-ring kernels; the per-path neighbour records the planner writes for the former equal path_checkLegal
+    (impl/pairwiseAligner.c:595-621) evaluated pair by pair, for two- and three-letter ambiguity codes, runs of adjacent
+    ambiguous letters (up to 3^3 * 2 paths in a window) and the default table."""
+    p = sa.default_params()
+    # (a) dense anchors, one path per cell: register kernels
+    pm6 = sa.Model.load(cases.MODEL_6MER)
+    dense = cases.synthetic_jobs(cases.MODEL_6MER, 3, 900, 5)
+    info, _ = sa.plan_digest(pm6, p, dense)
+    assert info.n_fast_regions == info.n_regions == 3 and info.n_ring_regions == 0
+    # (b) anchors as sparse as a real guide alignment: ring kernels, no per-path records
+    sparse = cases.realistic_anchor_jobs(cases.MODEL_6MER, 3, 1500, 5)
+    info, _ = sa.plan_digest(pm6, p, sparse)
+    assert info.n_ring_regions == info.n_regions == 3 and info.n_fast_regions == 0
+    assert sa.plan_check_path_records(pm6, p, sparse[0]) == (0, 0)
+    info, _ = sa.plan_digest(pm6, p, sparse, flags=sa.FLAG_EXACT)
+    assert info.n_ring_regions == 0
+    # (c) CpG model, every CpG cytosine X -> C/E
+    pmc = sa.Model.load(cases.MODEL_CPG)
+    amb = sa.default_ambig({"X": "CE"})
+    cpg = cases.synthetic_jobs(cases.MODEL_CPG, 3, 700, 11, cpg_ambiguous=True)
+    info, _ = sa.plan_digest(pmc, p, cpg, ambig=amb)
+    assert info.n_ring_regions == info.n_regions == 3
+    for job in cpg:
+        bad, seen = sa.plan_check_path_records(pmc, p, job, ambig=amb)
+        assert bad == 0 and seen > len(job["ref"])
+    # the thread count does not change what is planned (records included in the digest)
+    _, d1 = sa.plan_digest(pmc, p, cpg * 4, ambig=amb, threads=1)
+    _, d3 = sa.plan_digest(pmc, p, cpg * 4, ambig=amb, threads=3)
+    assert d1 == d3
+    # (d) R7.3 ACEGOT model with the default table: L -> C/E/O, P -> C/E, adjacent and clustered
+    pm7 = sa.Model.load(cases.MODEL_R73)
+    job = dict(cases.synthetic_jobs(cases.MODEL_R73, 1, 400, 3)[0])
+    ref = list(job["ref"])
+    for i in (10, 11, 12, 40, 42, 44, 45, 100, 150, 151, 200):
+        ref[i] = "L" if i % 2 == 0 else "P"
+    job["ref"] = "".join(ref)
+    bad, seen = sa.plan_check_path_records(pm7, p, job)
+    assert bad == 0 and seen > len(ref)
+    # (e) an ambiguity code with a repeated option: the index form of legality does not hold -> memory-resident kernels
+    info, _ = sa.plan_digest(pmc, p, cpg, ambig=sa.default_ambig({"X": "CC"}))
+    assert info.n_ring_regions == 0
