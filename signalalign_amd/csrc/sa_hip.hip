@@ -879,16 +879,16 @@ struct sa_launch_chunk {
     int ngr, nfr;
     long long ids_fw[7];       // register-kernel regions whose band needs 2..6 x 64 lanes (k_fwd_wide<S>), by S
     int nfw[7];
-    long long ids_rr[8];       // ring-kernel regions by class: [multi * 4 + cap class], cap = 64 << class
-    int nrr[8];
+    long long ids_rr[16];      // ring-kernel regions by class: [multi * 8 + cap class], cap = 64 * (class + 1)
+    int nrr[16];
     int g0, g1;                // groups [g0, g1)
 };
 struct sa_launch_group {
     long long seg0, seg1, ck0, ck1;
     long long ids_gs, ids_fs, ids_ws;   // segments of memory-resident / register / register, wide-band regions
     int ngs, nfs, nws;
-    long long ids_rs[8];                // segments of ring-kernel regions, by the class of their region
-    int nrs[8];
+    long long ids_rs[16];               // segments of ring-kernel regions, by the class of their region
+    int nrs[16];
 };
 
 struct sa_batch {
@@ -1252,7 +1252,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     if (trace_c) fprintf(stderr, "[trace] create: upload ring ready at %.1f ms\n", now_ms_c() - tc0);
     TRY(upload(&b->d_regions, pl->regions, pl->n_regions));
     const bool big_pinned = pl->pooled && pl->big_free == plan_pinned_free;   // the big arrays are pinned: no staging
-    TRY(upload(&b->d_rows, pl->rows, pl->n_rows, 0, big_pinned));
+    TRY(upload(&b->d_rows, pl->rows, pl->n_rows, 4, big_pinned));
     TRY(upload(&b->d_pk, pl->pk, pl->n_pk, 0, big_pinned));
     TRY(upload(&b->d_poff, pl->poff, pl->n_poff, 0, big_pinned));
     TRY(upload(&b->d_pid, pl->pid, pl->n_pid, 0, big_pinned));
@@ -1372,10 +1372,10 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
             // against 20.9 ms forward on 2000 reads with realistic anchors (the path is bound by the fp64 logAdd
             // arithmetic, not by re-reading the band, and slot granularity adds idle lanes); DESIGN.md section 8.
             const bool wide_on = getenv("SA_WIDE_KERNEL") && atoi(getenv("SA_WIDE_KERNEL")) == 1 && m->hdp == nullptr;
-            std::vector<int> rr[8];
+            std::vector<int> rr[16];
             auto ring_class = [](const sa_region_t &Rq) {
-                const int cl = Rq.max_rowpaths <= 64 ? 0 : (Rq.max_rowpaths <= 128 ? 1 : (Rq.max_rowpaths <= 256 ? 2 : 3));
-                return (Rq.max_p > 1 ? 4 : 0) + cl;
+                const int cl = Rq.max_rowpaths <= 64 ? 0 : (int) ((Rq.max_rowpaths - 1) / 64);   // <= 7 (SA_RING_MAX_ROWPATHS)
+                return (Rq.max_p > 1 ? 8 : 0) + (cl > 7 ? 7 : cl);
             };
             for (long long q = ra; q < rb; q++) {
                 const sa_region_t &Rq = pl->regions[q];
@@ -1401,7 +1401,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
                 C.ids_fw[sl] = (long long) b->ids_flat.size(); C.nfw[sl] = (int) fw[sl].size();
                 b->ids_flat.insert(b->ids_flat.end(), fw[sl].begin(), fw[sl].end());
             }
-            for (int cl = 0; cl < 8; cl++) {
+            for (int cl = 0; cl < 16; cl++) {
                 std::stable_sort(rr[cl].begin(), rr[cl].end(), by_len_r);
                 C.ids_rr[cl] = (long long) b->ids_flat.size(); C.nrr[cl] = (int) rr[cl].size();
                 b->ids_flat.insert(b->ids_flat.end(), rr[cl].begin(), rr[cl].end());
@@ -1412,7 +1412,9 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
             long long nseg_chunk = 0, nseg_wide = 0;
             for (long long q = ra; q < rb; q++) {
                 nseg_chunk += pl->regions[q].n_seg;
-                if (pl->regions[q].kind == SA_KIND_FAST && pl->regions[q].slots >= 2) nseg_wide += pl->regions[q].n_seg;
+                if ((pl->regions[q].kind == SA_KIND_FAST && pl->regions[q].slots >= 2) ||
+                    (pl->regions[q].kind == SA_KIND_RING && pl->regions[q].max_rowpaths > 64))
+                    nseg_wide += pl->regions[q].n_seg;
             }
             // segments of wide-band regions live three to four times longer than those of dense anchors (4 ms against
             // 1.2 ms), and so do the tails of their launches: fewer, larger groups.  2000 reads with realistic anchors,
@@ -1432,7 +1434,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
                 while (q < rb && pl->regions[q].job == pl->regions[q - 1].job) { acc += (double) pl->regions[q].N; q++; }
                 sa_launch_group G;
                 G.seg0 = G.seg1 = G.ck0 = G.ck1 = 0;
-                std::vector<int> gs, fs, ws, rs[8];
+                std::vector<int> gs, fs, ws, rs[16];
                 bool any = false;
                 // SA_WIDE_BWD=1 sends the segments of wide-band regions to k_bwd_fast_wide (loads of a wide diagonal
                 // batched, 2 waves per SIMD).  Off by default: it beats k_bwd_fast only when the launches are small
@@ -1463,7 +1465,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
                 std::stable_sort(ws.begin(), ws.end(), by_len_s);
                 G.ids_ws = (long long) b->ids_flat.size(); G.nws = (int) ws.size();
                 b->ids_flat.insert(b->ids_flat.end(), ws.begin(), ws.end());
-                for (int cl = 0; cl < 8; cl++) {
+                for (int cl = 0; cl < 16; cl++) {
                     std::stable_sort(rs[cl].begin(), rs[cl].end(), by_len_s);
                     G.ids_rs[cl] = (long long) b->ids_flat.size(); G.nrs[cl] = (int) rs[cl].size();
                     b->ids_flat.insert(b->ids_flat.end(), rs[cl].begin(), rs[cl].end());
@@ -1534,8 +1536,8 @@ static int submit_group(sa_batch *b, const DevPlan &P, int g, int which_stream, 
                            b->ring_cap);
     else if (G.ngs)
         hipLaunchKernelGGL((k_bwd_generic<false, false>), dim3(G.ngs), dim3(b->gen_threads), 0, st, P, b->d_ids + G.ids_gs, G.ngs, 0);
-    for (int cl = 7; cl >= 0; cl--)   // widest (longest-running) classes first
-        if (G.nrs[cl]) launch_bwd_ring(P, b->d_ids + G.ids_rs[cl], G.nrs[cl], st, 64 << (cl & 3), cl >= 4);
+    for (int cl = 15; cl >= 0; cl--)   // widest (longest-running) classes first
+        if (G.nrs[cl]) launch_bwd_ring(P, b->d_ids + G.ids_rs[cl], G.nrs[cl], st, 64 * ((cl & 7) + 1), cl >= 8);
     if (G.nws) launch_bwd_fast(P, b->d_ids + G.ids_ws, G.nws, st, true);
     if (G.nfs) launch_bwd_fast(P, b->d_ids + G.ids_fs, G.nfs, st);
     HIPCHK(hipEventRecord(b->gev[4 * g + 1], st));
@@ -1571,11 +1573,8 @@ static int enqueue_pass(sa_batch *b, bool finalize, AfterGroup after_group) {
                                s0, P, b->d_ids + C.ids_gr, C.ngr, b->ring_cap);
         else if (C.ngr)
             hipLaunchKernelGGL(k_fwd_generic<false>, dim3(C.ngr), dim3(b->gen_threads), 0, s0, P, b->d_ids + C.ids_gr, C.ngr, 0);
-        for (int cl = 7; cl >= 0; cl--)
-            if (C.nrr[cl]) {
-                const int cap = 64 << (cl & 3);
-                launch_fwd_ring(P, b->d_ids + C.ids_rr[cl], C.nrr[cl], s0, cap, ring_fwd_waves(cap), cl >= 4);
-            }
+        for (int cl = 15; cl >= 0; cl--)
+            if (C.nrr[cl]) launch_fwd_ring(P, b->d_ids + C.ids_rr[cl], C.nrr[cl], s0, 64 * ((cl & 7) + 1), cl >= 8);
         if (C.nfr) launch_fwd_fast(P, b->d_ids + C.ids_fr, C.nfr, s0, b->wide_cap);
         if (C.nfw[2]) launch_fwd_wide(P, b->d_ids + C.ids_fw[2], C.nfw[2], s0);
         HIPCHK(hipEventRecord(b->cev[2 * c + 1], s0));
