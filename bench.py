@@ -1,14 +1,20 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X pair-HMM path.
 
-One "step" = one pass of the hot path (forward, backward/posterior, fold, finalisation, result copy) over
-one batch of synthetic reads whose inputs are ALREADY resident in HBM (sa_batch_create uploaded them).
-Workload at every N: BASELINE.json configs[1] per GPU -- R9.4 6-mer template Gaussian HMM, 2000 synthetic
-5k-event reads, band (diagonal expansion) 50, threshold 0.01, traceBackDiagonals 100 -- i.e. weak scaling:
-reads are independent, each rank aligns its own 2000 (different seeds), no collective on the data path.
+One "step" = one batch of FRESH synthetic reads through the whole C-ABI boundary: sa_batch_create (input checks, planning --
+band, split, traceback schedule, on the device when the batch allows it -- and upload), sa_batch_run (forward,
+backward/posterior, fold, finalisation, result copy to the host), results read, sa_batch_destroy.  The next batch is created
+while the current one is on the GPU (sa_batch_start / sa_batch_wait), as a pipeline that sees every read once would do it;
+consecutive steps take different read sets.  The kernels-only rate on a planned, HBM-resident batch (what round 1
+reported as its headline) is measured first and reported beside it (config.kernels_only_resident_inputs); the roofline
+figures come from that phase's HIP-event times.
 
-metric: DP cell updates per second: sum over reads, traceback segments and
-anti-diagonals of width x paths, forward sweep plus backward sweep actually executed.
+Workload at every N: BASELINE.json configs[1] per GPU -- R9.4 6-mer template Gaussian HMM, 2000 synthetic 5k-event reads,
+band (diagonal expansion) 50, threshold 0.01, traceBackDiagonals 100 -- i.e. weak scaling: reads are independent, each rank
+aligns its own (different seeds), no collective on the data path.  `--gpus N` without a launcher starts the N ranks itself.
+
+metric: DP cell updates per second: sum over reads, traceback segments and anti-diagonals of
+width x paths, forward sweep plus backward sweep actually executed.
 
 Prints ONE JSON line on rank 0.
 """
@@ -324,12 +330,12 @@ def main():
     from signalalign_amd import shard
     mine = shard.shard_indices([args.events] * (world * args.reads), rank, world)
     jobs = [synth.make_read(int(i), args.events, alpha, k, tab, **read_kw) for i in mine]
-    if args.workload == "realistic":
-        # the anchors a real guide alignment leaves: the run structure of the reference's own example cigar (an indel
-        # every 10-50 bases), 14 bases trimmed off both ends of every match run as signalMachine -m 14 does
+    def thin_like_a_guide_alignment(job_list, indices):
+        # the anchors a real guide alignment leaves: the run structure of the reference's own example cigar (an indel every
+        # 10-50 bases), 14 bases trimmed off both ends of every match run as signalMachine -m 14 does
         toks = open(os.path.join(ROOT, "tests", "golden", "cigars", "ecoli_minus_strand.cigar")).read().split()[10:]
         runs = [(toks[i], int(toks[i + 1])) for i in range(0, len(toks), 2)]
-        for idx, job in zip(mine, jobs):
+        for idx, job in zip(indices, job_list):
             keep = np.zeros(len(job["ax"]), dtype=bool)
             pos, r = 0, (7 * int(idx)) % len(runs)
             while pos < len(keep):
@@ -342,14 +348,22 @@ def main():
                 elif op == "D":
                     pos += ln
             job["ax"], job["ay"] = job["ax"][keep], job["ay"][keep]
+
+    if args.workload == "realistic":
+        thin_like_a_guide_alignment(jobs, [int(i) for i in mine])
         wl_name = ("BASELINE configs[1] reads with the anchor density of a real guide alignment "
                    "(tests/golden/cigars/ecoli_minus_strand.cigar, -m 14: a sixth of the bases)")
+    # ---- read sets: every timed step aligns reads the library has not seen in the step before ----
+    n_sets = 2 if args.workload == "scaling" else 3
+    sets = [jobs]
+    for q in range(1, n_sets):
+        more = shard.shard_indices([args.events] * (world * args.reads), rank, world)
+        extra = [synth.make_read(int(i) + q * world * args.reads, args.events, alpha, k, tab, **read_kw) for i in more]
+        if args.workload == "realistic":
+            thin_like_a_guide_alignment(extra, [int(i) + q * world * args.reads for i in more])
+        sets.append(extra)
+    arrays = [sa.JobArray(js) for js in sets]          # marshalled once: a C caller holds sa_job_t arrays anyway
     n_events_total = sum(len(j["events"]) for j in jobs)
-    t_create = time.perf_counter()
-    batch = sa.Batch(pm, params, jobs, ambig=ambig, device=device)  # planning + upload to HBM
-    t_create = time.perf_counter() - t_create
-    st0 = batch.stats()
-    cells = st0.cells_forward + st0.cells_backward
 
     def sync():
         if dist is not None:
@@ -358,47 +372,87 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # ---- phase 1 (not the headline): the kernels alone, on a batch whose plan and inputs are resident in HBM ----
+    t_create = time.perf_counter()
+    batch = sa.Batch(pm, params, arrays[0], ambig=ambig, device=device)
+    t_create = time.perf_counter() - t_create
+    st0 = batch.stats()
+    cells = st0.cells_forward + st0.cells_backward
+    KR = max(3, min(args.steps, 10))
+    for _ in range(max(1, min(args.warmup, 3))):
         batch.run()
-    sync()
     t0 = time.perf_counter()
     ms_f = ms_b = ms_fold = 0.0
-    for _ in range(args.steps):
-        batch.run()  # synchronous: returns when the pairs are on the host
-        s = batch.stats()
-        ms_f += s.ms_forward
-        ms_b += s.ms_backward
-        ms_fold += s.ms_fold
+    for _ in range(KR):
+        batch.run()
+        s_ = batch.stats()
+        ms_f += s_.ms_forward
+        ms_b += s_.ms_backward
+        ms_fold += s_.ms_fold
+    dt_resident = (time.perf_counter() - t0) / KR
+    ms_f, ms_b, ms_fold = ms_f / KR, ms_b / KR, ms_fold / KR
+    n_pairs = sum(batch.n_pairs(j) for j in range(len(jobs)))
+    batch.close()
+    # ---- phase 2 (the headline): one step = one batch of FRESH reads through the whole boundary -- sa_batch_create (checks,
+    # planning, upload), run (forward, backward/posterior, fold, finalisation, result copy to the host), results read,
+    # sa_batch_destroy -- with the next batch being created while the current one is on the GPU (sa_batch_start/wait) ----
+    depth = 1 if args.workload == "scaling" else 2       # two 10k-event slices do not fit the forward storage together
+    cells_done = [0.0]
+
+    def stream(n_steps, first):
+        prev = None
+        for s in range(n_steps):
+            cur = sa.Batch(pm, params, arrays[(first + s) % n_sets], ambig=ambig, device=device)
+            stc = cur.stats()
+            cells_done[0] += stc.cells_forward + stc.cells_backward
+            if depth == 1:
+                cur.run()
+                cur.n_pairs(0)
+                cur.close()
+                continue
+            cur.start()
+            if prev is not None:
+                prev.wait()
+                prev.n_pairs(0)
+                prev.close()
+            prev = cur
+        if prev is not None:
+            prev.wait()
+            prev.n_pairs(0)
+            prev.close()
+
+    stream(args.warmup, 0)
+    sync()
+    cells_done[0] = 0.0
+    t0 = time.perf_counter()
+    stream(args.steps, args.warmup)
     sync()
     dt = time.perf_counter() - t0
-    n_pairs = sum(batch.n_pairs(j) for j in range(len(jobs)))
-    # outside the timed region: what a pipeline that sees every read ONCE pays per batch -- destroy, create, first run
-    # (the storage of the destroyed batch is reused through the library's caching allocators)
-    cycle = None
-    if rank == 0:
-        tc0 = time.perf_counter()
-        batch.close()
-        tc1 = time.perf_counter()
-        batch = sa.Batch(pm, params, jobs, ambig=ambig, device=device)
-        tc2 = time.perf_counter()
-        batch.run()
-        tc3 = time.perf_counter()
-        cycle = {"destroy": (tc1 - tc0) * 1e3, "create": (tc2 - tc1) * 1e3, "first_run": (tc3 - tc2) * 1e3}
+    cells_streamed = cells_done[0]
+    # one more cycle, serially and outside the timed region: what a caller without overlap pays per batch in steady state
+    tc0 = time.perf_counter()
+    bb = sa.Batch(pm, params, arrays[1 % n_sets], ambig=ambig, device=device)
+    tc1 = time.perf_counter()
+    bb.run()
+    tc2 = time.perf_counter()
+    bb.close()
+    tc3 = time.perf_counter()
+    cycle = {"create": (tc1 - tc0) * 1e3, "run": (tc2 - tc1) * 1e3, "destroy": (tc3 - tc2) * 1e3}
+
     if dist is not None:
         import torch
         tdev = "cuda" if backend == "nccl" else "cpu"
         t = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tot = torch.tensor([cells, float(n_events_total)], dtype=torch.float64, device=tdev)
+        tot = torch.tensor([cells_streamed, float(n_events_total) * args.steps], dtype=torch.float64, device=tdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         cells_all, events_all = float(tot[0].item()), float(tot[1].item())
     else:
-        cells_all, events_all = cells, float(n_events_total)
+        cells_all, events_all = cells_streamed, float(n_events_total) * args.steps
 
     if rank == 0:
         K = args.steps
-        ms_f, ms_b, ms_fold = ms_f / K, ms_b / K, ms_fold / K
         # dominant kernel of rank 0, timed with HIP events on the library's own streams.  k_bwd_fast runs as
         # n_groups launches per step that overlap pairwise on two streams: its duration here is
         # the wall time of the whole traceback stage (end of forward -> end of the last k_bwd_fast), which also
@@ -421,7 +475,7 @@ def main():
                 traffic = None
         out = {
             "metric": "dp_cell_updates_per_s",
-            "value": cells_all * K / dt,
+            "value": cells_all / dt,
             "unit": "cell_updates/s",
             "n_gpus": world,
             "steps": K,
@@ -436,17 +490,23 @@ def main():
                 "workload": "%s, %d synthetic %d-event reads per GPU, band=50, threshold 0.01, traceBackDiagonals 100"
                             % (wl_name, args.reads, args.events),
                 "reads_per_gpu": args.reads, "events_per_read": args.events,
-                "events_per_s": events_all * K / dt,
+                "events_per_s": events_all / dt,
                 "cells_per_event": cells / max(n_events_total, 1),
                 "pairs_rank0": n_pairs,
                 "regions_on_register_kernels": "%d/%d" % (st0.n_fast_regions, st0.n_regions),
                 "regions_on_ring_kernels": "%d/%d" % (st0.n_ring_regions, st0.n_regions),
                 "forward_storage_passes": int(st0.n_chunks),
                 "result_groups": int(st0.n_groups),
-                "batch_create_s": t_create,
-                "value_if_planning_and_upload_charged_to_every_step": cells / (t_create + dt / K),
-                "new_batch_cycle_ms": cycle,
-                "value_streaming_every_read_once": cells / (sum(cycle.values()) * 1e-3) if cycle else None,
+                "step": "one batch of fresh reads through the whole boundary: sa_batch_create (checks, planning, upload) + run + "
+                        "results on the host + sa_batch_destroy; %s" % ("two batches in flight (sa_batch_start / sa_batch_wait)"
+                                                                        if depth == 2 else "one batch at a time"),
+                "read_sets_cycled": n_sets,
+                "first_batch_create_s": t_create,
+                "serial_cycle_ms": cycle,
+                "value_serial_cycle": cells / (sum(cycle.values()) * 1e-3),
+                "kernels_only_resident_inputs": {"value": cells / dt_resident, "ms_per_step": dt_resident * 1e3,
+                                                 "note": "sa_batch_run repeated on one planned, HBM-resident batch "
+                                                         "(the round-1 headline)"},
                 "kernel_ms": {"forward": ms_f, "backward_posterior": ms_b, "fold_and_finalize": ms_fold},
                 "kernel_cell_updates_per_s": {"forward": st0.cells_forward / (ms_f * 1e-3),
                                               "backward_posterior": st0.cells_backward / (ms_b * 1e-3)},
@@ -461,7 +521,6 @@ def main():
             out["cpu_baseline"] = cpu_baseline(alpha, k, t10, tab, args.events, args.cpu_reads_per_thread,
                                                first_index=10 ** 6)
         print(json.dumps(out))
-    batch.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -181,6 +181,12 @@ int sa_plan_describe(const sa_model_t *m, const sa_params_t *p, const sa_job_t *
 int64_t sa_plan_check_path_records(const sa_model_t *m, const sa_params_t *p, const sa_job_t *job,
                                    const char *const *ambig256, int64_t *n_checked);
 
+/* Test hook (needs a GPU): plans the batch on the device and on the host and compares every array the kernels read.
+ * 0: identical; > 0: bit mask of the arrays that differ (1 << 30: the batch is not one the device planner takes);
+ * < 0: SA_E* code. */
+int sa_dplan_compare(const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs, int64_t n_jobs,
+                     const char *const *ambig256, int device, unsigned flags);
+
 /* ---- event <-> k-mer pre-alignment (the step upstream of the pair-HMM) ------------
  * adaptive_banded_simple_event_align (impl/eventAligner.c:899-1235): adaptive banded Viterbi of a raw event table
  * against the k-mers of the basecalled sequence, with the state machine's MeanOnly match emission

@@ -77,7 +77,7 @@ EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alp
            "sa_model_set_to_hdp_expected_values", "sa_kmer_id", "sa_default_ambig", "sa_load_ambig",
            "sa_batch_create", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_stats",
            "sa_batch_job_cells", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_plan_describe", "sa_plan_digest",
-           "sa_plan_check_path_records",
+           "sa_plan_check_path_records", "sa_dplan_compare",
            "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_fasta_subsequence", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_strerror",
            "sa_version", "sa_free"]
 
@@ -261,15 +261,27 @@ def _make_jobs(jobs):
     return arr, keep
 
 
+class JobArray:
+    """A list of jobs marshalled once into the C array sa_batch_create takes (a C caller has it anyway; building it costs
+    Python several milliseconds per thousand reads).  Pass it to Batch in place of the list."""
+
+    def __init__(self, jobs):
+        self.n = len(jobs)
+        self.arr, self._keep = _make_jobs(jobs)
+
+
 class Batch:
     """sa_batch_t: plan + HBM-resident inputs; run() launches the kernels."""
 
     def __init__(self, model, params, jobs, ambig=None, device=0, flags=0):
         self._h = C.c_void_p()
-        self.n_jobs = len(jobs)
-        arr, self._keep = _make_jobs(jobs)
+        if isinstance(jobs, JobArray):
+            self.n_jobs, arr, self._keep = jobs.n, jobs.arr, jobs
+        else:
+            self.n_jobs = len(jobs)
+            arr, self._keep = _make_jobs(jobs)
         amb = ambig if ambig is not None else default_ambig()
-        _chk(lib().sa_batch_create(C.byref(self._h), model._h, C.byref(params), arr, len(jobs), amb, device, flags),
+        _chk(lib().sa_batch_create(C.byref(self._h), model._h, C.byref(params), arr, self.n_jobs, amb, device, flags),
              "sa_batch_create")
 
     def run(self):
@@ -536,3 +548,14 @@ def plan_check_path_records(model, params, job, ambig=None):
     if bad < 0:
         _chk(int(bad), "sa_plan_check_path_records")
     return int(bad), int(n.value)
+
+
+def dplan_compare(model, params, jobs, ambig=None, device=0, flags=0):
+    """Test hook (GPU): 0 when the device planner and the host planner produce identical arrays for `jobs`."""
+    arr, keep = _make_jobs(jobs)
+    amb = ambig if ambig is not None else default_ambig()
+    rc = lib().sa_dplan_compare(model._h, C.byref(params), arr, len(jobs), amb, device, flags)
+    del keep
+    if rc < 0:
+        _chk(rc, "sa_dplan_compare")
+    return rc

@@ -932,6 +932,7 @@ struct sa_batch {
     sa_pair_t *d_pairs_up;                // host-finalised pairs uploaded for a downstream device step (sa_batch_mea)
     long long d_pairs_up_cap;
     bool ran;
+    bool dev_planned;      // the plan was built on the device (sa_dplan.inc): its big arrays exist in HBM only
     std::thread *runner;   // sa_batch_start .. sa_batch_wait
     int runner_rc;
     sa_batch_stats_t stats;
@@ -1153,6 +1154,8 @@ void sa_batch_destroy(sa_batch_t *b) {
     delete b;
 }
 
+#include "sa_dplan.inc"
+
 int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs, int64_t n_jobs,
                     const char *const *ambig, int device, unsigned flags) {
     if (!out || !m || !p) return SA_EINVAL;
@@ -1174,17 +1177,9 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     const bool trace_c = getenv("SA_TRACE") != nullptr;
     auto now_ms_c = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double tc0 = now_ms_c();
-    sa_plan_t *pl = nullptr;
-    // pinning memory costs about 0.25 ms per MB: it pays for a process that streams batches (the blocks are reused), not
-    // for the one or two batches of a command-line run, which stage their plan through the uploader's ring instead
-    static std::atomic<int> batches_created(0);
-    if (SaPool::enabled() && batches_created.fetch_add(1) >= 2) sa_plan_use_allocator(plan_pinned_alloc, plan_pinned_free);
-    int rc = sa_plan_build(&pl, m, p, jobs, n_jobs, ambig, flags | SA_FLAG_DEVICE_XC_INTERNAL, budget);
-    sa_plan_use_allocator(nullptr, nullptr);
-    if (rc) return rc;
-    if (trace_c) fprintf(stderr, "[trace] create: planned at %.1f ms\n", now_ms_c() - tc0);
     sa_batch *b = new sa_batch();
-    b->plan = pl;
+    b->plan = nullptr;
+    b->dev_planned = false;
     b->device = device;
     b->flags = flags;
     b->stream = nullptr;
@@ -1201,6 +1196,46 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     b->d_bscratch = nullptr; b->d_tab6 = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr;
     b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr; b->d_hdp_tab = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr;
     b->d_seg_off = nullptr; b->d_out = nullptr; b->d_ids = nullptr; b->d_gsum = nullptr; b->d_gmc = nullptr;
+    b->cand_alloc = 0; b->out_alloc = 0;
+    b->h_pairs = nullptr; b->h_pairs_cap = 0; b->n_pairs_total = 0;
+    b->d_pairs_up = nullptr; b->d_pairs_up_cap = 0;
+    memset(&b->stats, 0, sizeof(b->stats));
+    for (int i = 0; i < 8; i++) b->ev[i] = nullptr;
+#define TRY(x) do { int rc_ = (x); if (rc_) { sa_batch_destroy(b); return rc_; } } while (0)
+    if (g_handles.stream(&b->cstream[0], device, 0) != hipSuccess || g_handles.stream(&b->cstream[1], device, 0) != hipSuccess) {
+        sa_batch_destroy(b);
+        return SA_ENODEVICE;
+    }
+    b->stream = b->cstream[0];
+    {   // the copy stream outranks the compute streams
+        if (g_handles.stream(&b->pair_stream, device, 1) != hipSuccess) {
+            sa_batch_destroy(b);
+            return SA_ENODEVICE;
+        }
+    }
+    for (int i = 0; i < 8; i++)
+        if (g_handles.event(&b->ev[i], device) != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
+    // ---- the plan: on the device when the batch allows it (sa_dplan.inc), else on the host ----
+    sa_plan_t *pl = nullptr;
+    {
+        std::unique_lock<std::mutex> dp_lock(g_uploader.mu);
+        TRY(g_uploader.bind(device));
+        const int rcd = dplan_build(b, m, p, jobs, n_jobs, ambig, flags, budget);
+        if (rcd < 0) { dp_lock.unlock(); sa_batch_destroy(b); return rcd; }
+        if (rcd == SA_OK) pl = b->plan;
+    }
+    if (!pl) {
+        // pinning memory costs about 0.25 ms per MB: it pays for a process that streams batches (the blocks are reused), not
+        // for the one or two batches of a command-line run, which stage their plan through the uploader's ring instead
+        static std::atomic<int> batches_created(0);
+        if (SaPool::enabled() && batches_created.fetch_add(1) >= 2) sa_plan_use_allocator(plan_pinned_alloc, plan_pinned_free);
+        int rc = sa_plan_build(&pl, m, p, jobs, n_jobs, ambig, flags | SA_FLAG_DEVICE_XC_INTERNAL, budget);
+        sa_plan_use_allocator(nullptr, nullptr);
+        if (rc) { sa_batch_destroy(b); return rc; }
+        if (trace_c) fprintf(stderr, "[trace] create: planned at %.1f ms\n", now_ms_c() - tc0);
+        b->plan = pl;
+    }
+    if (trace_c) fprintf(stderr, "[trace] create: planned (%s) at %.1f ms\n", b->dev_planned ? "device" : "host", now_ms_c() - tc0);
     b->expect = (flags & SA_FLAG_EXPECT_INTERNAL) != 0;
     b->relax = !(flags & SA_FLAG_EXACT) && !b->expect && m->hdp == nullptr;
     b->ring_cap = 0;
@@ -1228,35 +1263,19 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
         if (lim > 900) lim = 900;                   // 64 KB of dynamic LDS
         b->ring_cap = (int) (cap < lim ? cap : lim);
     }
-    b->cand_alloc = 0; b->out_alloc = 0;
-    b->h_pairs = nullptr; b->h_pairs_cap = 0; b->n_pairs_total = 0;
-    b->d_pairs_up = nullptr; b->d_pairs_up_cap = 0;
-    memset(&b->stats, 0, sizeof(b->stats));
-    for (int i = 0; i < 8; i++) b->ev[i] = nullptr;
-#define TRY(x) do { int rc_ = (x); if (rc_) { sa_batch_destroy(b); return rc_; } } while (0)
-    if (g_handles.stream(&b->cstream[0], device, 0) != hipSuccess || g_handles.stream(&b->cstream[1], device, 0) != hipSuccess) {
-        sa_batch_destroy(b);
-        return SA_ENODEVICE;
-    }
-    b->stream = b->cstream[0];
-    {   // the copy stream outranks the compute streams
-        if (g_handles.stream(&b->pair_stream, device, 1) != hipSuccess) {
-            sa_batch_destroy(b);
-            return SA_ENODEVICE;
-        }
-    }
-    for (int i = 0; i < 8; i++)
-        if (g_handles.event(&b->ev[i], device) != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
     std::unique_lock<std::mutex> up_lock(g_uploader.mu);
     TRY(g_uploader.bind(device));
     if (trace_c) fprintf(stderr, "[trace] create: upload ring ready at %.1f ms\n", now_ms_c() - tc0);
-    TRY(upload(&b->d_regions, pl->regions, pl->n_regions));
     const bool big_pinned = pl->pooled && pl->big_free == plan_pinned_free;   // the big arrays are pinned: no staging
-    TRY(upload(&b->d_rows, pl->rows, pl->n_rows, 4, big_pinned));
-    TRY(upload(&b->d_pk, pl->pk, pl->n_pk, 0, big_pinned));
-    TRY(upload(&b->d_poff, pl->poff, pl->n_poff, 0, big_pinned));
-    TRY(upload(&b->d_pid, pl->pid, pl->n_pid, 0, big_pinned));
-    {   // per-path records: only batches that hold ring-kernel regions with several paths per cell have (and read) them
+    if (!b->dev_planned) {
+        TRY(upload(&b->d_regions, pl->regions, pl->n_regions));
+        TRY(upload(&b->d_rows, pl->rows, pl->n_rows, 4, big_pinned));
+        TRY(upload(&b->d_pk, pl->pk, pl->n_pk, 0, big_pinned));
+        TRY(upload(&b->d_poff, pl->poff, pl->n_poff, 0, big_pinned));
+        TRY(upload(&b->d_pid, pl->pid, pl->n_pid, 0, big_pinned));
+    } else {   // the scan kernel set f_base / chunk / seg_off on the device; the host copy has them too
+    }
+    if (!b->dev_planned) {   // per-path records: only batches that hold ring-kernel regions with several paths per cell have (and read) them
         bool need = false;
         for (long long r = 0; r < pl->n_regions && !need; r++) need = pl->regions[r].kind == SA_KIND_RING && pl->regions[r].max_p > 1;
         if (need && pl->prec) TRY(upload(&b->d_prec, pl->prec, pl->n_pid, 0, big_pinned));
@@ -1265,7 +1284,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     {   // cell-path -> reference position, for the memory-resident kernels (one lane per cell-path); register-kernel
         // regions never read it
         bool any_generic = false;
-        for (long long r = 0; r < pl->n_regions && !any_generic; r++) any_generic = pl->regions[r].kind == SA_KIND_GENERIC;
+        for (long long r = 0; r < pl->n_regions && !any_generic && !b->dev_planned; r++) any_generic = pl->regions[r].kind == SA_KIND_GENERIC;
         if (any_generic) {
             px.assign((size_t) (pl->n_pid > 0 ? pl->n_pid : 1), 0);
             for (long long r = 0; r < pl->n_regions; r++) {
@@ -1281,9 +1300,11 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
         }
     }
     // readable padding behind the events: the kernels clamp event indices to 0 even for reads without events
-    TRY(upload(&b->d_ev, pl->ev, pl->n_ev, 8, big_pinned));
-    TRY(upload(&b->d_segs, pl->segs, pl->n_segs));
-    TRY(upload(&b->d_cks, pl->cks, pl->n_cks));
+    if (!b->dev_planned) {
+        TRY(upload(&b->d_ev, pl->ev, pl->n_ev, 8, big_pinned));
+        TRY(upload(&b->d_segs, pl->segs, pl->n_segs));
+        TRY(upload(&b->d_cks, pl->cks, pl->n_cks));
+    }
     {   // model tables
         std::vector<double> tab6((size_t) m->n_kmers * 6);
         for (long long i = 0; i < m->n_kmers; i++) {
@@ -1514,6 +1535,83 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
 #undef TRY
     *out = b;
     return SA_OK;
+}
+
+// Test hook: plans the batch twice -- on the device (sa_dplan.inc) and with sa_plan.c -- and compares every array the kernels
+// read, byte for byte.  Returns 0 when all agree, a bit mask of the arrays that differ (1 regions, 2 rows, 4 packed words,
+// 8 path offsets, 16 k-mer ids, 32 events, 64 segments, 128 checkpoints, 256 totals), 1 << 30 when the batch is not one the
+// device planner takes, or a negative SA_E* code.
+int sa_dplan_compare(const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs, int64_t n_jobs, const char *const *ambig,
+                     int device, unsigned flags) {
+    if (!m || !p) return SA_EINVAL;
+    HIPCHK(hipSetDevice(device));
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    free_b += g_sa_pool.idle_bytes(SaPool::DEVICE, device);
+    long long budget = (long long) ((double) free_b * 0.60 / 24.0);
+    const char *envb = getenv("SA_F_BUDGET_CELLPATHS");
+    if (envb && atoll(envb) > 0) budget = atoll(envb);
+    sa_batch *b = new sa_batch();
+    b->device = device;
+    b->plan = nullptr;
+    b->dev_planned = false;
+    b->runner = nullptr;
+    b->cstream[0] = b->cstream[1] = nullptr; b->pair_stream = nullptr; b->stream = nullptr;
+    b->h_pairs = nullptr; b->d_pairs_up = nullptr; b->h_seg_off = nullptr; b->h_overflow = nullptr;
+    for (int i = 0; i < 8; i++) b->ev[i] = nullptr;
+    b->d_regions = nullptr; b->d_rows = nullptr; b->d_pk = nullptr; b->d_poff = nullptr; b->d_pid = nullptr; b->d_px = nullptr; b->d_xc = nullptr;
+    b->d_prec = nullptr; b->d_ev = nullptr; b->d_segs = nullptr; b->d_cks = nullptr; b->d_F = nullptr; b->d_vbuf = nullptr;
+    b->d_cands = nullptr; b->d_cand_count = nullptr; b->d_overflow = nullptr; b->d_totals = nullptr; b->d_bscratch = nullptr;
+    b->d_tab6 = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr; b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr;
+    b->d_hdp_tab = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr; b->d_seg_off = nullptr; b->d_out = nullptr;
+    b->d_ids = nullptr; b->d_gsum = nullptr; b->d_gmc = nullptr;
+    int rcd;
+    {
+        std::unique_lock<std::mutex> lk(g_uploader.mu);
+        rcd = g_uploader.bind(device);
+        if (rcd == SA_OK) rcd = dplan_build(b, m, p, jobs, n_jobs, ambig, flags, budget);
+    }
+    if (rcd != SA_OK) {
+        sa_batch_destroy(b);
+        return rcd < 0 ? rcd : (1 << 30);
+    }
+    sa_plan_t *hp = nullptr;
+    int rc = sa_plan_build(&hp, m, p, jobs, n_jobs, ambig, flags | SA_FLAG_DEVICE_XC_INTERNAL, budget);
+    if (rc) { sa_batch_destroy(b); return rc; }
+    const sa_plan_t *dp = b->plan;
+    int mask = 0;
+    auto differs = [&](const void *dev, const void *host, size_t bytes) -> bool {
+        if (bytes == 0) return false;
+        std::vector<char> tmp(bytes);
+        if (hipMemcpy(tmp.data(), dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) return true;
+        return memcmp(tmp.data(), host, bytes) != 0;
+    };
+    if (dp->n_regions != hp->n_regions || dp->n_segs != hp->n_segs || dp->n_cks != hp->n_cks || dp->n_rows != hp->n_rows ||
+        dp->n_pk != hp->n_pk || dp->n_poff != hp->n_poff || dp->n_pid != hp->n_pid || dp->n_ev != hp->n_ev ||
+        dp->n_vbuf != hp->n_vbuf || dp->n_cand != hp->n_cand || dp->n_bscratch != hp->n_bscratch ||
+        dp->n_chunks != hp->n_chunks || dp->max_chunk_cellpaths != hp->max_chunk_cellpaths ||
+        dp->n_fast_regions != hp->n_fast_regions || dp->n_ring_regions != hp->n_ring_regions || dp->cells_fwd != hp->cells_fwd ||
+        dp->cells_bwd != hp->cells_bwd)
+        mask |= 256;
+    if (!(mask & 256)) {
+        if (differs(b->d_regions, hp->regions, sizeof(sa_region_t) * (size_t) hp->n_regions) ||
+            memcmp(dp->regions, hp->regions, sizeof(sa_region_t) * (size_t) hp->n_regions) != 0)
+            mask |= 1;
+        if (differs(b->d_rows, hp->rows, sizeof(sa_row_t) * (size_t) hp->n_rows)) mask |= 2;
+        if (differs(b->d_pk, hp->pk, 4 * (size_t) hp->n_pk)) mask |= 4;
+        if (differs(b->d_poff, hp->poff, 4 * (size_t) hp->n_poff)) mask |= 8;
+        if (differs(b->d_pid, hp->pid, 4 * (size_t) hp->n_pid)) mask |= 16;
+        if (differs(b->d_ev, hp->ev, 8 * (size_t) hp->n_ev)) mask |= 32;
+        if (differs(b->d_segs, hp->segs, sizeof(sa_seg_t) * (size_t) hp->n_segs) ||
+            memcmp(dp->segs, hp->segs, sizeof(sa_seg_t) * (size_t) hp->n_segs) != 0)
+            mask |= 64;
+        if (differs(b->d_cks, hp->cks, sizeof(sa_ck_t) * (size_t) hp->n_cks)) mask |= 128;
+        for (int64_t j = 0; j < hp->n_jobs; j++)
+            if (memcmp(&dp->jobs[j], &hp->jobs[j], sizeof(sa_jobinfo_t)) != 0) mask |= 256;
+    }
+    sa_plan_free(hp);
+    sa_batch_destroy(b);
+    return mask;
 }
 
 // One pass = per chunk the forward sweeps (stream 0), then per group the backward/posterior kernels, the exact fold
