@@ -260,8 +260,10 @@ def self_launch(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--in-flight", type=int, default=2, help="batches in flight in the timed pipeline (create of the next "
+                                                            "overlaps the runs of the previous ones)")
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU (default: 2000 = BASELINE configs[1]; "
                                                              "scaling: 12500 = configs[4]'s 100k reads / 8 GPUs)")
     ap.add_argument("--events", type=int, default=None, help="events per read (default 5000; scaling: 10000)")
@@ -273,6 +275,8 @@ def main():
                          "the sparse anchors of a real guide alignment; event_align, mea = the steps either side of the "
                          "pair-HMM.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernels-only", action="store_true", help="phase 1 only (sa_batch_run on one resident batch): for "
+                                                                "profiler runs that count per-kernel launches")
     ap.add_argument("--cpu-reads-per-thread", type=int, default=30)
     args = ap.parse_args()
     if args.reads is None:
@@ -396,11 +400,11 @@ def main():
     # ---- phase 2 (the headline): one step = one batch of FRESH reads through the whole boundary -- sa_batch_create (checks,
     # planning, upload), run (forward, backward/posterior, fold, finalisation, result copy to the host), results read,
     # sa_batch_destroy -- with the next batch being created while the current one is on the GPU (sa_batch_start/wait) ----
-    depth = 1 if args.workload == "scaling" else 2       # two 10k-event slices do not fit the forward storage together
+    depth = 1 if args.workload == "scaling" else args.in_flight   # two 10k-event slices do not fit the forward storage together
     cells_done = [0.0]
 
     def stream(n_steps, first):
-        prev = None
+        flying = []
         for s in range(n_steps):
             cur = sa.Batch(pm, params, arrays[(first + s) % n_sets], ambig=ambig, device=device)
             stc = cur.stats()
@@ -411,33 +415,39 @@ def main():
                 cur.close()
                 continue
             cur.start()
-            if prev is not None:
-                prev.wait()
-                prev.n_pairs(0)
-                prev.close()
-            prev = cur
-        if prev is not None:
-            prev.wait()
-            prev.n_pairs(0)
-            prev.close()
+            flying.append(cur)
+            if len(flying) >= depth:
+                old = flying.pop(0)
+                old.wait()
+                old.n_pairs(0)
+                old.close()
+        for old in flying:
+            old.wait()
+            old.n_pairs(0)
+            old.close()
 
-    stream(args.warmup, 0)
-    sync()
-    cells_done[0] = 0.0
-    t0 = time.perf_counter()
-    stream(args.steps, args.warmup)
-    sync()
-    dt = time.perf_counter() - t0
+    if args.kernels_only:
+        dt, cells_done[0] = dt_resident * args.steps, cells * args.steps
+    else:
+        stream(args.warmup, 0)
+        sync()
+        cells_done[0] = 0.0
+        t0 = time.perf_counter()
+        stream(args.steps, args.warmup)
+        sync()
+        dt = time.perf_counter() - t0
     cells_streamed = cells_done[0]
     # one more cycle, serially and outside the timed region: what a caller without overlap pays per batch in steady state
-    tc0 = time.perf_counter()
-    bb = sa.Batch(pm, params, arrays[1 % n_sets], ambig=ambig, device=device)
-    tc1 = time.perf_counter()
-    bb.run()
-    tc2 = time.perf_counter()
-    bb.close()
-    tc3 = time.perf_counter()
-    cycle = {"create": (tc1 - tc0) * 1e3, "run": (tc2 - tc1) * 1e3, "destroy": (tc3 - tc2) * 1e3}
+    cycle = {"create": 0.0, "run": dt_resident * 1e3, "destroy": 0.0}
+    if not args.kernels_only:
+        tc0 = time.perf_counter()
+        bb = sa.Batch(pm, params, arrays[1 % n_sets], ambig=ambig, device=device)
+        tc1 = time.perf_counter()
+        bb.run()
+        tc2 = time.perf_counter()
+        bb.close()
+        tc3 = time.perf_counter()
+        cycle = {"create": (tc1 - tc0) * 1e3, "run": (tc2 - tc1) * 1e3, "destroy": (tc3 - tc2) * 1e3}
 
     if dist is not None:
         import torch
@@ -465,12 +475,16 @@ def main():
         achieved = ALGO_BYTES_PER_CELL * dom_cells / (dom_ms * 1e-3) / 1e9
         if os.environ.get("SA_WIDE_BWD") == "1" and args.workload == "realistic" and dom == "k_bwd_fast":
             dom = "k_bwd_fast_wide"  # opt-in variant for the segments of wide-band regions
+        # HBM bytes per step of the dominant kernel from the rocprofv3 --pmc passes (profiles/traffic.json, written by
+        # probes/profile_r02.sh + probes/traffic_from_pmc.py: FETCH_SIZE and WRITE_SIZE in separate passes, fetch doubled as
+        # MI355X_MICROARCH.md prescribes for gfx950); collected at the default size of each workload only
         traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")  # written from the rocprofv3 --pmc passes, see DESIGN.md
-        # the counters were collected on the headline workload only: no figure for any other
-        if os.path.exists(tp) and args.workload == "gaussian" and args.reads == 2000 and args.events == 5000:
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        default_size = (args.reads == (12500 if args.workload == "scaling" else 2000) and
+                        args.events == (10000 if args.workload == "scaling" else 5000))
+        if os.path.exists(tp) and default_size:
             try:
-                traffic = json.load(open(tp)).get(dom)
+                traffic = json.load(open(tp)).get(args.workload, {}).get(dom, {}).get("bytes_per_step")
             except Exception:
                 traffic = None
         out = {
@@ -498,8 +512,8 @@ def main():
                 "forward_storage_passes": int(st0.n_chunks),
                 "result_groups": int(st0.n_groups),
                 "step": "one batch of fresh reads through the whole boundary: sa_batch_create (checks, planning, upload) + run + "
-                        "results on the host + sa_batch_destroy; %s" % ("two batches in flight (sa_batch_start / sa_batch_wait)"
-                                                                        if depth == 2 else "one batch at a time"),
+                        "results on the host + sa_batch_destroy; %s" % ("%d batches in flight (sa_batch_start / sa_batch_wait)" % depth
+                                                                        if depth > 1 else "one batch at a time"),
                 "read_sets_cycled": n_sets,
                 "first_batch_create_s": t_create,
                 "serial_cycle_ms": cycle,
@@ -513,6 +527,10 @@ def main():
             },
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac_by_counters": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "limiter": "instruction issue (VALU + SALU of the serial per-diagonal chain), not HBM: see "
+                                    "profiles/ and DESIGN.md section 4",
+                         "kernel_passes_phase1": (max(1, min(args.warmup, 3)) + KR),
                          "algorithmic_bytes_per_step": ALGO_BYTES_PER_CELL * dom_cells,
                          "stage_ms": dom_ms,
                          "launches_per_step": int(st0.n_groups) if dom.startswith("k_bwd") else int(st0.n_chunks)},

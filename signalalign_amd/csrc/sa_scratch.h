@@ -70,7 +70,7 @@ struct SaScratch {
 // per 2000 reads: hipMalloc / hipFree of its 25 GB (0.1 - 1 s per batch, measured), hipHostMalloc of the 200 MB pinned
 // result buffer (40 ms) and their release (130 ms) cost ten times the kernels.  Blocks handed back are kept (per device
 // and kind) and reused for requests they fit without wasting more than half of the block; sa_pool_release() returns
-// everything, SA_POOL=0 disables the cache, SA_POOL_LIMIT_GB (default 96 / 8) bounds what is held.
+// everything, SA_POOL=0 disables the cache, SA_POOL_LIMIT_GB bounds what is held (default: 90 % of the device's memory, 8 GB pinned).
 struct SaPool {
     enum Kind { DEVICE = 0, PINNED = 1 };
     struct Blk {
@@ -88,8 +88,27 @@ struct SaPool {
     }
     static size_t limit(int kind) {
         const char *e = getenv("SA_POOL_LIMIT_GB");
-        const double gb = e ? atof(e) : (kind == DEVICE ? 96.0 : 8.0);
-        return (size_t) (gb * 1073741824.0);
+        if (e) return (size_t) (atof(e) * 1073741824.0);
+        if (kind != DEVICE) return (size_t) 8 << 30;
+        // device: whatever a destroyed batch held may stay parked (a 10k-event slice holds 170 GB of forward storage, and
+        // hipFree + hipMalloc of it cost seconds); parked blocks are handed back when an allocation fails (get())
+        static size_t dev_limit = 0;
+        if (dev_limit == 0) {
+            size_t free_b = 0, total_b = 0;
+            dev_limit = (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) ? (size_t) ((double) total_b * 0.9)
+                                                                                        : (size_t) 96 << 30;
+        }
+        return dev_limit;
+    }
+    // Requests are rounded up to one of eight sizes per power of two: consecutive batches differ by a few per cent in every
+    // array, and an exact-size cache would miss each time (a miss is a hipMalloc / hipHostMalloc, which also waits for the
+    // batch that is running)
+    static size_t round_up(size_t bytes) {
+        if (bytes <= ((size_t) 1 << 16)) return ((bytes + 4095) / 4096) * 4096;
+        size_t p2 = (size_t) 1 << 16;
+        while (p2 * 2 <= bytes) p2 *= 2;
+        const size_t step = p2 / 8;
+        return ((bytes + step - 1) / step) * step;
     }
     static hipError_t raw_alloc(int kind, void **p, size_t bytes) {
         return kind == DEVICE ? hipMalloc(p, bytes) : hipHostMalloc(p, bytes, hipHostMallocDefault);
@@ -98,6 +117,7 @@ struct SaPool {
     // the current device must be `dev`
     hipError_t get(int kind, void **out, size_t bytes, int dev) {
         if (bytes == 0) bytes = 8;
+        if (enabled()) bytes = round_up(bytes);
         if (enabled()) {
             std::lock_guard<std::mutex> g(mu);
             int best = -1;
