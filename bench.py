@@ -262,7 +262,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--in-flight", type=int, default=2, help="batches in flight in the timed pipeline (create of the next "
+    ap.add_argument("--in-flight", type=int, default=3, help="batches in flight in the timed pipeline (create of the next "
                                                             "overlaps the runs of the previous ones)")
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU (default: 2000 = BASELINE configs[1]; "
                                                              "scaling: 12500 = configs[4]'s 100k reads / 8 GPUs)")
