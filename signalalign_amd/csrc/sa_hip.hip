@@ -897,6 +897,7 @@ struct sa_batch {
     unsigned flags;
     hipStream_t stream;            // == cstream[0]
     hipStream_t cstream[2];        // compute streams; groups alternate between them
+    hipStream_t xstream[2];        // two more, for the forward launches of the ring-kernel classes
     // device buffers
     sa_region_t *d_regions; sa_row_t *d_rows; int *d_pk; int *d_poff; int *d_pid; int *d_px; double *d_xc; double *d_ev;
     sa_prec_t *d_prec;
@@ -1137,6 +1138,8 @@ void sa_batch_destroy(sa_batch_t *b) {
     // batch may still be in flight (only possible after an error inside a run)
     for (int i = 0; i < 2; i++)
         if (b->cstream[i]) (void) hipStreamSynchronize(b->cstream[i]);
+    for (int i = 0; i < 2; i++)
+        if (b->xstream[i]) (void) hipStreamSynchronize(b->xstream[i]);
     if (b->pair_stream) (void) hipStreamSynchronize(b->pair_stream);
     void *ptrs[] = {b->d_regions, b->d_rows, b->d_pk, b->d_poff, b->d_pid, b->d_px, b->d_xc, b->d_prec, b->d_ev, b->d_segs, b->d_cks, b->d_F,
                     b->d_vbuf, b->d_cands, b->d_cand_count, b->d_overflow, b->d_totals, b->d_bscratch, b->d_tab6,
@@ -1150,6 +1153,8 @@ void sa_batch_destroy(sa_batch_t *b) {
     for (hipEvent_t e : b->cev) g_handles.park(e, b->device);
     for (int i = 0; i < 2; i++)
         g_handles.park(b->cstream[i], b->device, 0);
+    for (int i = 0; i < 2; i++)
+        g_handles.park(b->xstream[i], b->device, 0);
     g_handles.park(b->pair_stream, b->device, 1);
     g_sa_pool.put(SaPool::PINNED, b->h_pairs);
     g_sa_pool.put(SaPool::DEVICE, b->d_pairs_up);
@@ -1189,6 +1194,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     b->flags = flags;
     b->stream = nullptr;
     b->cstream[0] = b->cstream[1] = nullptr;
+    b->xstream[0] = b->xstream[1] = nullptr;
     b->pair_stream = nullptr;
     b->h_seg_off = nullptr;
     b->h_overflow = nullptr;
@@ -1274,7 +1280,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     const bool big_pinned = pl->pooled && pl->big_free == plan_pinned_free;   // the big arrays are pinned: no staging
     if (!b->dev_planned) {
         TRY(upload(&b->d_regions, pl->regions, pl->n_regions));
-        TRY(upload(&b->d_rows, pl->rows, pl->n_rows, 4, big_pinned));
+        TRY(upload(&b->d_rows, pl->rows, pl->n_rows, 192, big_pinned));   // (the ring kernels read row tiles up to 127 entries past a region)
         TRY(upload(&b->d_pk, pl->pk, pl->n_pk, 0, big_pinned));
         TRY(upload(&b->d_poff, pl->poff, pl->n_poff, 0, big_pinned));
         TRY(upload(&b->d_pid, pl->pid, pl->n_pid, 0, big_pinned));
@@ -1561,7 +1567,7 @@ int sa_dplan_compare(const sa_model_t *m, const sa_params_t *p, const sa_job_t *
     b->plan = nullptr;
     b->dev_planned = false;
     b->runner = nullptr;
-    b->cstream[0] = b->cstream[1] = nullptr; b->pair_stream = nullptr; b->stream = nullptr;
+    b->cstream[0] = b->cstream[1] = nullptr; b->xstream[0] = b->xstream[1] = nullptr; b->pair_stream = nullptr; b->stream = nullptr;
     b->h_pairs = nullptr; b->d_pairs_up = nullptr; b->h_seg_off = nullptr; b->h_overflow = nullptr;
     for (int i = 0; i < 8; i++) b->ev[i] = nullptr;
     b->d_regions = nullptr; b->d_rows = nullptr; b->d_pk = nullptr; b->d_poff = nullptr; b->d_pid = nullptr; b->d_px = nullptr; b->d_xc = nullptr;
@@ -1676,8 +1682,33 @@ static int enqueue_pass(sa_batch *b, bool finalize, AfterGroup after_group) {
                                s0, P, b->d_ids + C.ids_gr, C.ngr, b->ring_cap);
         else if (C.ngr)
             hipLaunchKernelGGL(k_fwd_generic<false>, dim3(C.ngr), dim3(b->gen_threads), 0, s0, P, b->d_ids + C.ids_gr, C.ngr, 0);
-        for (int cl = 15; cl >= 0; cl--)
-            if (C.nrr[cl]) launch_fwd_ring(P, b->d_ids + C.ids_rr[cl], C.nrr[cl], s0, 64 * ((cl & 7) + 1), cl >= 8);
+        {   // ring-kernel regions, one launch per class of row capacity.  A forward launch holds one workgroup per read and
+            // lasts as long as its longest read's serial chain, so launches that follow each other on one stream leave the chip
+            // mostly empty three times over: the classes alternate between the two compute streams and run side by side
+            int n_cl = 0;
+            for (int cl = 0; cl < 16; cl++) n_cl += C.nrr[cl] > 0;
+            hipStream_t lanes[4] = {s0, s1, b->xstream[0], b->xstream[1]};
+            int n_lanes = n_cl < 4 ? n_cl : 4;
+            for (int q = 2; q < n_lanes; q++)   // the two extra streams are made on first need
+                if (!lanes[q]) {
+                    if (g_handles.stream(&b->xstream[q - 2], b->device, 0) != hipSuccess) { n_lanes = q; break; }
+                    lanes[q] = b->xstream[q - 2];
+                }
+            if (n_lanes > 1) {
+                HIPCHK(hipEventRecord(b->ev[1], s0));
+                for (int q = 1; q < n_lanes; q++) HIPCHK(hipStreamWaitEvent(lanes[q], b->ev[1], 0));
+            }
+            int which = 0;
+            for (int cl = 15; cl >= 0; cl--)
+                if (C.nrr[cl]) {
+                    launch_fwd_ring(P, b->d_ids + C.ids_rr[cl], C.nrr[cl], lanes[n_lanes > 1 ? which : 0], 64 * ((cl & 7) + 1), cl >= 8);
+                    which = (which + 1) % (n_lanes > 1 ? n_lanes : 1);
+                }
+            for (int q = 1; q < n_lanes; q++) {
+                HIPCHK(hipEventRecord(b->ev[1 + q], lanes[q]));
+                HIPCHK(hipStreamWaitEvent(s0, b->ev[1 + q], 0));
+            }
+        }
         if (C.nfr) launch_fwd_fast(P, b->d_ids + C.ids_fr, C.nfr, s0, b->wide_cap);
         if (C.nfw[2]) launch_fwd_wide(P, b->d_ids + C.ids_fw[2], C.nfw[2], s0);
         HIPCHK(hipEventRecord(b->cev[2 * c + 1], s0));
