@@ -440,14 +440,18 @@ def main():
     # one more cycle, serially and outside the timed region: what a caller without overlap pays per batch in steady state
     cycle = {"create": 0.0, "run": dt_resident * 1e3, "destroy": 0.0}
     if not args.kernels_only:
-        tc0 = time.perf_counter()
-        bb = sa.Batch(pm, params, arrays[1 % n_sets], ambig=ambig, device=device)
-        tc1 = time.perf_counter()
-        bb.run()
-        tc2 = time.perf_counter()
-        bb.close()
-        tc3 = time.perf_counter()
-        cycle = {"create": (tc1 - tc0) * 1e3, "run": (tc2 - tc1) * 1e3, "destroy": (tc3 - tc2) * 1e3}
+        samples = []
+        for q in range(1 if args.workload == "scaling" else 5):
+            tc0 = time.perf_counter()
+            bb = sa.Batch(pm, params, arrays[(q + 1) % n_sets], ambig=ambig, device=device)
+            tc1 = time.perf_counter()
+            bb.run()
+            tc2 = time.perf_counter()
+            bb.close()
+            tc3 = time.perf_counter()
+            samples.append(((tc1 - tc0) * 1e3, (tc2 - tc1) * 1e3, (tc3 - tc2) * 1e3))
+        med = sorted(samples, key=lambda t_: sum(t_))[len(samples) // 2]
+        cycle = {"create": med[0], "run": med[1], "destroy": med[2]}
 
     if dist is not None:
         import torch

@@ -977,6 +977,7 @@ static DevPlan make_devplan(const sa_batch *b) {
 // Host -> device copies of the plan (several hundred MB per batch) through a persistent ring of pinned buffers: the
 // runtime's own staging of pageable memory moves about 3 GB/s; here the CPU copy into a pinned slot (all host threads)
 // overlaps the DMA of the previous slots.  One ring per process and device, calls serialise on it.
+static hipError_t sa_sync_stream_fwd(hipStream_t s, int dev);   // sa_sync_stream (below)
 struct SaUploader {
     std::mutex mu;
     int device = -1;
@@ -1005,7 +1006,7 @@ struct SaUploader {
         if (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio_hi) != hipSuccess) return SA_ENODEVICE;
         for (int i = 0; i < SLOTS; i++) {
             if (hipHostMalloc(&slot[i], SLOT_BYTES, hipHostMallocDefault) != hipSuccess) return SA_ENOMEM;
-            if (hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess) return SA_ENODEVICE;
+            if (hipEventCreateWithFlags(&done[i], hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) return SA_ENODEVICE;
         }
         return SA_OK;
     }
@@ -1034,7 +1035,7 @@ struct SaUploader {
         return SA_OK;
     }
     int drain() {
-        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(sa_sync_stream_fwd(stream, device));
         return SA_OK;
     }
 };
@@ -1074,7 +1075,8 @@ struct SaHandles {
                     return hipSuccess;
                 }
         }
-        return hipEventCreate(out);
+        // blocking: a host thread that waits on one of these sleeps instead of spinning (see sa_sync_stream)
+        return hipEventCreateWithFlags(out, hipEventBlockingSync);
     }
     void park(hipStream_t s, int dev, int kind) {
         if (!s) return;
@@ -1102,6 +1104,21 @@ struct SaHandles {
     }
 };
 static SaHandles g_handles;
+
+// Waits for a stream without spinning: hipStreamSynchronize busy-waits by default, and a pipeline with several batches in
+// flight then burns one CPU per waiting thread -- inside a container with a CPU quota that pushes the process over its
+// share and the kernel throttles ALL its threads for the rest of the accounting period (measured: 40 ms stalls in
+// sa_batch_create).  An event created with hipEventBlockingSync sleeps on an interrupt instead.
+static hipError_t sa_sync_stream(hipStream_t s, int dev);
+static hipError_t sa_sync_stream_fwd(hipStream_t s, int dev) { return sa_sync_stream(s, dev); }
+static hipError_t sa_sync_stream(hipStream_t s, int dev) {
+    hipEvent_t e = nullptr;
+    if (g_handles.event(&e, dev) != hipSuccess) { (void) hipGetLastError(); return hipStreamSynchronize(s); }
+    hipError_t r = hipEventRecord(e, s);
+    if (r == hipSuccess) r = hipEventSynchronize(e);
+    g_handles.park(e, dev);
+    return r;
+}
 
 // the planner's big arrays as pinned memory of the caching allocator (the device then reads them by plain DMA)
 static void *plan_pinned_alloc(size_t bytes) {
@@ -1783,8 +1800,8 @@ static int run_passes(sa_batch_t *b) {
     for (int attempt = 0; attempt < 6; attempt++) {
         int rc = enqueue_pass(b, false, [](size_t) { return (int) SA_OK; });
         if (rc) return rc;
-        HIPCHK(hipStreamSynchronize(b->cstream[1]));
-        HIPCHK(hipStreamSynchronize(b->cstream[0]));
+        HIPCHK(sa_sync_stream(b->cstream[1], b->device));
+        HIPCHK(sa_sync_stream(b->cstream[0], b->device));
         rc = collect_times(b);
         if (rc) return rc;
         if (!b->h_overflow[0]) return SA_OK;
@@ -1880,10 +1897,10 @@ int sa_batch_run(sa_batch_t *b) {
         int rc = enqueue_pass(b, true, after_group);
         if (rc) return rc;
         gbase[ng] = running;
-        HIPCHK(hipStreamSynchronize(b->cstream[1]));
-        HIPCHK(hipStreamSynchronize(b->cstream[0]));
+        HIPCHK(sa_sync_stream(b->cstream[1], b->device));
+        HIPCHK(sa_sync_stream(b->cstream[0], b->device));
         if (trace) fprintf(stderr, "[trace] compute stream drained at %.3f ms\n", now_ms() - t0);
-        HIPCHK(hipStreamSynchronize(b->pair_stream));
+        HIPCHK(sa_sync_stream(b->pair_stream, b->device));
         if (trace) fprintf(stderr, "[trace] copies drained at %.3f ms (piped %d)\n", now_ms() - t0, (int) piped);
         rc = collect_times(b);
         if (rc) return rc;
@@ -1902,7 +1919,7 @@ int sa_batch_run(sa_batch_t *b) {
                     HIPCHK(hipMemcpyAsync(b->h_pairs + gbase[g], b->d_out + pl->segs[G.seg0].cand_off,
                                           sizeof(sa_pair_t) * (size_t) tg, hipMemcpyDeviceToHost, b->pair_stream));
             }
-            HIPCHK(hipStreamSynchronize(b->pair_stream));
+            HIPCHK(sa_sync_stream(b->pair_stream, b->device));
         }
         done = true;
     }
