@@ -400,7 +400,13 @@ def main():
     # ---- phase 2 (the headline): one step = one batch of FRESH reads through the whole boundary -- sa_batch_create (checks,
     # planning, upload), run (forward, backward/posterior, fold, finalisation, result copy to the host), results read,
     # sa_batch_destroy -- with the next batch being created while the current one is on the GPU (sa_batch_start/wait) ----
-    depth = 1 if args.workload == "scaling" else args.in_flight   # two 10k-event slices do not fit the forward storage together
+    # batches in flight: as many as asked for, as long as their forward storage (24 B per band cell, the bulk of a batch)
+    # fits HBM together with room to spare -- a 10k-event slice or 10k reads with several paths per cell take half of
+    # the card alone and go one at a time
+    hbm_bytes = float(sa.device_memory(device)[1])
+    depth = max(1, min(args.in_flight, int(0.6 * hbm_bytes / max(1.25 * st0.f_bytes, 1.0))))
+    if args.workload == "scaling":
+        depth = 1
     cells_done = [0.0]
 
     def stream(n_steps, first):

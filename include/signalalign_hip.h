@@ -302,6 +302,9 @@ int sa_estimate_params(const sa_model_t *m, double *table5_inout, const int64_t 
                        int64_t n_events, const char *strand_read, int64_t read_len, double *out7);
 
 int sa_device_count(void);
+/* HBM of `device`: bytes free (what the library's caching allocator holds counts as free) and in total; a caller that keeps
+ * several batches in flight sizes its pipeline with this (sa_batch_stats_t.f_bytes is the bulk of a batch) */
+int sa_device_memory(int device, int64_t *free_bytes, int64_t *total_bytes);
 const char *sa_strerror(int code);
 const char *sa_version(void);
 void sa_free(void *p);

@@ -12,6 +12,7 @@ cat > $OUT/stubs.c <<'EOS'
 #include <stdlib.h>
 #define NODEV { return SA_ENODEVICE; }
 int sa_device_count(void) { return 0; }
+int sa_device_memory(int d, int64_t *f, int64_t *t) NODEV
 int sa_batch_create(sa_batch_t **b, const sa_model_t *m, const sa_params_t *p, const sa_job_t *j, int64_t n, const char *const *a, int d, unsigned f) NODEV
 int sa_batch_run(sa_batch_t *b) NODEV
 int sa_dplan_compare(const sa_model_t *m, const sa_params_t *p, const sa_job_t *j, int64_t n, const char *const *a, int d, unsigned f) NODEV

@@ -940,10 +940,23 @@ struct sa_batch {
     hipEvent_t ev[8];
 };
 
+static size_t g_sa_pool_idle_bytes(int device);
 int sa_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int sa_device_memory(int device, int64_t *free_bytes, int64_t *total_bytes) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SA_ENODEVICE;
+    if (device < 0 || device >= n) return SA_EINVAL;
+    HIPCHK(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t) (f + g_sa_pool_idle_bytes(device));   // what the caching allocator holds is available
+    if (total_bytes) *total_bytes = (int64_t) t;
+    return SA_OK;
 }
 
 static DevPlan make_devplan(const sa_batch *b) {
@@ -1041,6 +1054,7 @@ struct SaUploader {
 };
 static SaUploader g_uploader;
 SaPool g_sa_pool;
+static size_t g_sa_pool_idle_bytes(int device) { return g_sa_pool.idle_bytes(SaPool::DEVICE, device); }
 
 // Streams and events of destroyed batches, kept per device for the next batch (creating three streams and ~50 events is
 // 10 ms per batch).  Handles are only parked after the batch has drained them.
