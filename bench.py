@@ -397,6 +397,22 @@ def main():
     ms_f, ms_b, ms_fold = ms_f / KR, ms_b / KR, ms_fold / KR
     n_pairs = sum(batch.n_pairs(j) for j in range(len(jobs)))
     batch.close()
+    # serial cycles (median of five, outside the timed region): what a caller without overlap pays per batch in steady state
+    cycle = {"create": 0.0, "run": dt_resident * 1e3, "destroy": 0.0}
+    if not args.kernels_only:
+        samples = []
+        for q in range(1 if args.workload == "scaling" else 5):
+            tc0 = time.perf_counter()
+            bb = sa.Batch(pm, params, arrays[(q + 1) % n_sets], ambig=ambig, device=device)
+            tc1 = time.perf_counter()
+            bb.run()
+            tc2 = time.perf_counter()
+            bb.close()
+            tc3 = time.perf_counter()
+            samples.append(((tc1 - tc0) * 1e3, (tc2 - tc1) * 1e3, (tc3 - tc2) * 1e3))
+        med = sorted(samples, key=lambda t_: sum(t_))[len(samples) // 2]
+        cycle = {"create": med[0], "run": med[1], "destroy": med[2]}
+
     # ---- phase 2 (the headline): one step = one batch of FRESH reads through the whole boundary -- sa_batch_create (checks,
     # planning, upload), run (forward, backward/posterior, fold, finalisation, result copy to the host), results read,
     # sa_batch_destroy -- with the next batch being created while the current one is on the GPU (sa_batch_start/wait) ----
@@ -443,22 +459,6 @@ def main():
         sync()
         dt = time.perf_counter() - t0
     cells_streamed = cells_done[0]
-    # one more cycle, serially and outside the timed region: what a caller without overlap pays per batch in steady state
-    cycle = {"create": 0.0, "run": dt_resident * 1e3, "destroy": 0.0}
-    if not args.kernels_only:
-        samples = []
-        for q in range(1 if args.workload == "scaling" else 5):
-            tc0 = time.perf_counter()
-            bb = sa.Batch(pm, params, arrays[(q + 1) % n_sets], ambig=ambig, device=device)
-            tc1 = time.perf_counter()
-            bb.run()
-            tc2 = time.perf_counter()
-            bb.close()
-            tc3 = time.perf_counter()
-            samples.append(((tc1 - tc0) * 1e3, (tc2 - tc1) * 1e3, (tc3 - tc2) * 1e3))
-        med = sorted(samples, key=lambda t_: sum(t_))[len(samples) // 2]
-        cycle = {"create": med[0], "run": med[1], "destroy": med[2]}
-
     if dist is not None:
         import torch
         tdev = "cuda" if backend == "nccl" else "cpu"

@@ -1581,7 +1581,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
 
 // Test hook: plans the batch twice -- on the device (sa_dplan.inc) and with sa_plan.c -- and compares every array the kernels
 // read, byte for byte.  Returns 0 when all agree, a bit mask of the arrays that differ (1 regions, 2 rows, 4 packed words,
-// 8 path offsets, 16 k-mer ids, 32 events, 64 segments, 128 checkpoints, 256 totals), 1 << 30 when the batch is not one the
+// 8 path offsets, 16 k-mer ids, 32 events, 64 segments, 128 checkpoints, 256 totals, 512 per-path records), 1 << 30 when the batch is not one the
 // device planner takes, or a negative SA_E* code.
 int sa_dplan_compare(const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs, int64_t n_jobs, const char *const *ambig,
                      int device, unsigned flags) {
@@ -1648,6 +1648,13 @@ int sa_dplan_compare(const sa_model_t *m, const sa_params_t *p, const sa_job_t *
             memcmp(dp->segs, hp->segs, sizeof(sa_seg_t) * (size_t) hp->n_segs) != 0)
             mask |= 64;
         if (differs(b->d_cks, hp->cks, sizeof(sa_ck_t) * (size_t) hp->n_cks)) mask |= 128;
+        for (int64_t r = 0; r < hp->n_regions; r++) {   // per-path records: they exist for these regions only
+            const sa_region_t *R = &hp->regions[r];
+            if (R->kind != SA_KIND_RING || R->max_p <= 1) continue;
+            if (!b->d_prec || !hp->prec ||
+                differs(b->d_prec + R->pid_off, hp->prec + R->pid_off, sizeof(sa_prec_t) * (size_t) hp->poff[R->poff_off + R->lX + 1]))
+                mask |= 512;
+        }
         for (int64_t j = 0; j < hp->n_jobs; j++)
             if (memcmp(&dp->jobs[j], &hp->jobs[j], sizeof(sa_jobinfo_t)) != 0) mask |= 256;
     }

@@ -46,6 +46,32 @@ def test_device_plan_equals_host_plan(monkeypatch):
     assert sa.dplan_compare(hd, sa.default_params(), cases.synthetic_jobs(cases.MODEL_R73, 3, 900, 5)) == 0
 
 
+def test_device_plan_equals_host_plan_with_ambiguous_positions(monkeypatch):
+    """Several paths per cell: path offsets, k-mer ids in hdCell_construct2's order, band offsets in cell-paths and the
+    per-path neighbour records (compared for every ring-kernel region) -- CpG cytosines C/E, the default table's two- and
+    three-letter codes on the R7.3 ACEGOT model, mixed with canonical reads in one batch."""
+    p = sa.default_params()
+    pmc = sa.Model.load(cases.MODEL_CPG)
+    amb = sa.default_ambig({"X": "CE"})
+    cpg = cases.synthetic_jobs(cases.MODEL_CPG, 6, 1400, 20, cpg_ambiguous=True) + cases.synthetic_jobs(cases.MODEL_CPG, 2, 900, 3)
+    sparse = cases.realistic_anchor_jobs(cases.MODEL_CPG, 2, 1200, 77)
+    cpg += [dict(j, ref=j["ref"].replace("CG", "XG")) for j in sparse]
+    assert sa.dplan_compare(pmc, p, cpg, ambig=amb) == 0
+    monkeypatch.setenv("SA_F_BUDGET_CELLPATHS", "400000")
+    assert sa.dplan_compare(pmc, p, cpg, ambig=amb) == 0
+    monkeypatch.delenv("SA_F_BUDGET_CELLPATHS")
+    pm7 = sa.Model.load(cases.MODEL_R73)
+    jobs = []
+    for j, job in enumerate(cases.synthetic_jobs(cases.MODEL_R73, 3, 600, 50)):
+        ref = list(job["ref"])
+        for i in range(7 + j, len(ref) - 6, 23):
+            ref[i] = "L" if (i // 23) % 2 == 0 else "P"
+        for i in (200, 201, 202):
+            ref[i] = "L"
+        jobs.append(dict(job, ref="".join(ref)))
+    assert sa.dplan_compare(pm7, p, jobs) == 0
+
+
 def test_batches_the_device_planner_leaves_to_the_host(oracle):
     pm = sa.Model.load(cases.MODEL_6MER)
     p = sa.default_params()
@@ -59,7 +85,11 @@ def test_batches_the_device_planner_leaves_to_the_host(oracle):
     big["ax"], big["ay"] = big["ax"][~hole], big["ay"][~hole]
     assert sa.dplan_compare(pm, p, dense + [big]) == NOT_TAKEN                                   # a gap that splits the matrix
     amb = dict(dense[0], ref=dense[0]["ref"][:100] + "R" + dense[0]["ref"][101:])
-    assert sa.dplan_compare(pm, p, dense + [amb]) == NOT_TAKEN                                   # an ambiguity letter
+    assert sa.dplan_compare(pm, p, dense + [amb]) == 0                   # an ambiguity letter (R -> A/G): taken since round 2
+    assert sa.dplan_compare(pm, p, dense + [amb], ambig=sa.default_ambig({"R": "AA"})) == NOT_TAKEN   # repeated options
+    assert sa.dplan_compare(pm, p, dense + [amb], ambig=sa.default_ambig({"R": "AN"})) == NOT_TAKEN   # option outside the alphabet
+    many = dict(dense[0], ref=dense[0]["ref"][:100] + "XXXXXX" + dense[0]["ref"][106:])         # 4^6 paths in one window
+    assert sa.dplan_compare(pm, p, dense + [many]) == NOT_TAKEN
     bad = dict(dense[0], ref=dense[0]["ref"][:100] + "N" + dense[0]["ref"][101:])
     assert sa.dplan_compare(pm, p, dense + [bad]) == NOT_TAKEN                                   # (the host planner names the error)
     empty = dict(ref="", events=np.zeros(0), ax=[], ay=[])
@@ -93,5 +123,28 @@ def test_device_planned_batches_against_the_oracle(oracle, monkeypatch):
     b = sa.Batch(pm, p, jobs)
     b.run()
     for j in range(len(jobs)):
+        assert np.array_equal(b.pairs(j), got[j]), j
+    b.close()
+    monkeypatch.delenv("SA_DEVICE_PLAN")
+    # ambiguous positions (configs[2] shape): device-planned, against the oracle, and identical to the host-planned run
+    pmc = sa.Model.load(cases.MODEL_CPG)
+    alpha, k, t10, tab = synth.parse_model_table(cases.MODEL_CPG)
+    omc = oracle.Model(alpha, k, t10, tab)
+    amb_p, amb_o = sa.default_ambig({"X": "CE"}), oracle.ambig_map({"X": "CE"})
+    cpg = cases.synthetic_jobs(cases.MODEL_CPG, 4, 1100, 20, cpg_ambiguous=True)
+    assert sa.dplan_compare(pmc, p, cpg, ambig=amb_p) == 0
+    b = sa.Batch(pmc, p, cpg, ambig=amb_p)
+    b.run()
+    got = [b.pairs(j) for j in range(len(cpg))]
+    assert b.stats().n_ring_regions == len(cpg)
+    b.close()
+    for j, job in enumerate(cpg):
+        exp = cases.oracle_pairs(oracle, omc, job, op, ambig=amb_o)
+        cases.compare_pairs(got[j], exp, 100, p.threshold)
+        assert cases.same_order(got[j], exp)
+    monkeypatch.setenv("SA_DEVICE_PLAN", "0")
+    b = sa.Batch(pmc, p, cpg, ambig=amb_p)
+    b.run()
+    for j in range(len(cpg)):
         assert np.array_equal(b.pairs(j), got[j]), j
     b.close()
