@@ -478,6 +478,8 @@ def main():
         # the wall time of the whole traceback stage (end of forward -> end of the last k_bwd_fast), which also
         # contains the fold/finalisation kernels of the earlier groups, and the bytes are those of all launches.
         fam = "fast" if st0.n_fast_regions == st0.n_regions else ("ring" if st0.n_ring_regions > 0 else "generic")
+        if fam == "ring" and 2 * st0.n_strip_regions > st0.n_ring_regions:
+            fam = "strip"
         if ms_b >= ms_f:
             dom, dom_ms, dom_cells = "k_bwd_" + fam, ms_b, st0.cells_backward
         else:
@@ -518,7 +520,8 @@ def main():
                 "cells_per_event": cells / max(n_events_total, 1),
                 "pairs_rank0": n_pairs,
                 "regions_on_register_kernels": "%d/%d" % (st0.n_fast_regions, st0.n_regions),
-                "regions_on_ring_kernels": "%d/%d" % (st0.n_ring_regions, st0.n_regions),
+                "regions_on_ring_kernels": "%d/%d" % (st0.n_ring_regions - st0.n_strip_regions, st0.n_regions),
+                "regions_on_strip_kernels": "%d/%d" % (st0.n_strip_regions, st0.n_regions),
                 "forward_storage_passes": int(st0.n_chunks),
                 "result_groups": int(st0.n_groups),
                 "step": "one batch of fresh reads through the whole boundary: sa_batch_create (checks, planning, upload) + run + "

@@ -101,6 +101,8 @@ typedef struct sa_batch_stats {
     int64_t n_groups;        /* backward/posterior launches per pass (result copy of one overlaps the next) */
     int64_t n_ring_regions;  /* regions handled by the LDS-ring kernels (several paths per cell, or a band mostly wider
                                 than a wave)                                           */
+    int64_t n_strip_regions; /* of those: one-path regions swept in strips of 64 reference columns (register-resident,
+                                no barrier; sa_strip.inc)                               */
 } sa_batch_stats_t;
 
 /* ---- model -------------------------------------------------------------------------------------

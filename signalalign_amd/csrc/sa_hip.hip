@@ -164,6 +164,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
 
 #include "sa_fast.inc"
 #include "sa_ring.inc"
+#include "sa_strip.inc"
 
 // ---------------------------------------------------------------------------------------------------
 // The memory-resident kernels come in two flavours.  EXACT (SA_FLAG_EXACT, the expectation pass, HDP with several
@@ -881,6 +882,8 @@ struct sa_launch_chunk {
     int nfw[7];
     long long ids_rr[16];      // ring-kernel regions by class: [multi * 8 + cap class], cap = 64 * (class + 1)
     int nrr[16];
+    long long ids_st;          // one-path ring-kernel regions taken by the strip kernels (sa_strip.inc)
+    int nst;
     int g0, g1;                // groups [g0, g1)
 };
 struct sa_launch_group {
@@ -889,6 +892,9 @@ struct sa_launch_group {
     int ngs, nfs, nws;
     long long ids_rs[16];               // segments of ring-kernel regions, by the class of their region
     int nrs[16];
+    long long ids_ss;                   // segments of strip-kernel regions
+    int nss;
+    unsigned seam_first;                // their first wave slot in the seam storage
 };
 
 struct sa_batch {
@@ -910,6 +916,10 @@ struct sa_batch {
     int ring_cap;            // cell-paths per diagonal of their LDS ring (0: rows stay in global memory)
     int wide_cap;            // cells per row of the register kernels' LDS ring for wide diagonals (0: every diagonal fits)
     int gen_threads;         // 64, or 128 when a diagonal of a memory-resident region holds more than 64 cell-paths
+    bool strip_on;           // one-path ring-kernel regions run on the strip kernels (default; SA_STRIP=0: ring kernels)
+    char *d_seam;            // their seam storage: per wave two arrays of seam_cap records of 16 bytes
+    unsigned seam_cap;
+    unsigned seam_bwd_first; // wave slots [0, seam_bwd_first) serve the forward launch, the rest the backward launches of a pass
     double *d_tab6; int *d_hdp_slot; double *d_hdp_y, *d_hdp_slope, *d_hdp_grid, *d_hdp_tab;
     long long *d_prob; int *d_seg_pass; long long *d_seg_off; sa_pair_t *d_out;
     int *d_ids;  // region / segment id lists per launch
@@ -1175,7 +1185,7 @@ void sa_batch_destroy(sa_batch_t *b) {
     void *ptrs[] = {b->d_regions, b->d_rows, b->d_pk, b->d_poff, b->d_pid, b->d_px, b->d_xc, b->d_prec, b->d_ev, b->d_segs, b->d_cks, b->d_F,
                     b->d_vbuf, b->d_cands, b->d_cand_count, b->d_overflow, b->d_totals, b->d_bscratch, b->d_tab6,
                     b->d_hdp_slot, b->d_hdp_y, b->d_hdp_slope, b->d_hdp_grid, b->d_hdp_tab, b->d_prob, b->d_seg_pass, b->d_seg_off,
-                    b->d_out, b->d_ids, b->d_gsum, b->d_gmc};
+                    b->d_out, b->d_ids, b->d_gsum, b->d_gmc, b->d_seam};
     for (void *p : ptrs)
         if (p) g_sa_pool.put(SaPool::DEVICE, p);
     for (int i = 0; i < 8; i++)
@@ -1235,6 +1245,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     b->d_prec = nullptr;
     b->d_ev = nullptr; b->d_segs = nullptr; b->d_cks = nullptr; b->d_F = nullptr; b->d_vbuf = nullptr;
     b->d_cands = nullptr; b->d_cand_count = nullptr; b->d_overflow = nullptr; b->d_totals = nullptr;
+    b->d_seam = nullptr; b->seam_cap = 0; b->seam_bwd_first = 0; b->strip_on = false;
     b->d_bscratch = nullptr; b->d_tab6 = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr;
     b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr; b->d_hdp_tab = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr;
     b->d_seg_off = nullptr; b->d_out = nullptr; b->d_ids = nullptr; b->d_gsum = nullptr; b->d_gmc = nullptr;
@@ -1422,13 +1433,20 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
         if (envg && atoi(envg) > 0) want = atoi(envg);
         else if (!host_finalize) want = pl->n_chunks == 1 ? 8 : (pl->n_chunks < 4 ? 4 : 2);
         b->ids_flat.clear();
+        // One-path ring-kernel regions go to the strip kernels (sa_strip.inc): Gaussian emissions, default arithmetic,
+        // device-side finalisation, reference windows of fewer than 64 * STRIP_NS_MAX positions.  SA_STRIP=0: ring kernels.
+        b->strip_on = b->relax && !host_finalize && m->hdp == nullptr && !(getenv("SA_STRIP") && atoi(getenv("SA_STRIP")) == 0);
+        auto strip_region = [&](const sa_region_t &Rq) {
+            return b->strip_on && Rq.kind == SA_KIND_RING && Rq.max_p == 1 && Rq.lX < 64ll * STRIP_NS_MAX && Rq.N >= 1;
+        };
+        long long strip_max_n = 0, strip_fwd_slots = 0, strip_bwd_slots = 0;
         long long r = 0;
         for (int c = 0; c < pl->n_chunks; c++) {
             long long ra = r;
             while (r < pl->n_regions && pl->regions[r].chunk == c) r++;
             long long rb = r;
             sa_launch_chunk C;
-            std::vector<int> gr, fr, fw[7];
+            std::vector<int> gr, fr, fw[7], sr_;
             double work = 0;
             // SA_WIDE_KERNEL=1 sends regions whose band needs 2..5 x 64 lanes to k_fwd_wide (band in registers, S cells
             // per lane).  Off by default: bit-identical, but slower than k_fwd_fast's memory-resident path -- 32.7 ms
@@ -1442,7 +1460,8 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
             };
             for (long long q = ra; q < rb; q++) {
                 const sa_region_t &Rq = pl->regions[q];
-                if (Rq.kind == SA_KIND_RING) rr[ring_class(Rq)].push_back((int) q);
+                if (strip_region(Rq)) { sr_.push_back((int) q); strip_max_n = Rq.N > strip_max_n ? Rq.N : strip_max_n; }
+                else if (Rq.kind == SA_KIND_RING) rr[ring_class(Rq)].push_back((int) q);
                 else if (Rq.kind != SA_KIND_FAST) gr.push_back((int) q);
                 else if (wide_on && Rq.slots >= 2 && Rq.slots <= SA_WIDE_SLOTS_MAX) fw[2].push_back((int) q);
                 else fr.push_back((int) q);
@@ -1469,14 +1488,20 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
                 C.ids_rr[cl] = (long long) b->ids_flat.size(); C.nrr[cl] = (int) rr[cl].size();
                 b->ids_flat.insert(b->ids_flat.end(), rr[cl].begin(), rr[cl].end());
             }
+            std::stable_sort(sr_.begin(), sr_.end(), by_len_r);
+            C.ids_st = (long long) b->ids_flat.size(); C.nst = (int) sr_.size();
+            b->ids_flat.insert(b->ids_flat.end(), sr_.begin(), sr_.end());
+            strip_fwd_slots = (long long) sr_.size() > strip_fwd_slots ? (long long) sr_.size() : strip_fwd_slots;
+            long long chunk_bwd_slots = 0;
             C.g0 = (int) b->groups.size();
             // a group should still be a sizeable launch: at least 2048 segments each (measured optimum 6-8 groups
             // for 18000 segments; 16 and more lose to launch gaps)
             long long nseg_chunk = 0, nseg_wide = 0;
             for (long long q = ra; q < rb; q++) {
                 nseg_chunk += pl->regions[q].n_seg;
-                if ((pl->regions[q].kind == SA_KIND_FAST && pl->regions[q].slots >= 2) ||
-                    (pl->regions[q].kind == SA_KIND_RING && pl->regions[q].max_rowpaths > 64))
+                if (!strip_region(pl->regions[q]) &&
+                    ((pl->regions[q].kind == SA_KIND_FAST && pl->regions[q].slots >= 2) ||
+                     (pl->regions[q].kind == SA_KIND_RING && pl->regions[q].max_rowpaths > 64)))
                     nseg_wide += pl->regions[q].n_seg;
             }
             // segments of wide-band regions live three to four times longer than those of dense anchors (4 ms against
@@ -1497,7 +1522,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
                 while (q < rb && pl->regions[q].job == pl->regions[q - 1].job) { acc += (double) pl->regions[q].N; q++; }
                 sa_launch_group G;
                 G.seg0 = G.seg1 = G.ck0 = G.ck1 = 0;
-                std::vector<int> gs, fs, ws, rs[16];
+                std::vector<int> gs, fs, ws, rs[16], ss;
                 bool any = false;
                 // SA_WIDE_BWD=1 sends the segments of wide-band regions to k_bwd_fast_wide (loads of a wide diagonal
                 // batched, 2 waves per SIMD).  Off by default: it beats k_bwd_fast only when the launches are small
@@ -1507,7 +1532,8 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
                 for (long long t = qa; t < q; t++) {
                     const sa_region_t *R = &pl->regions[t];
                     for (long long sg = R->seg_off; sg < R->seg_off + R->n_seg; sg++) {
-                        if (R->kind == SA_KIND_RING) rs[ring_class(*R)].push_back((int) sg);
+                        if (strip_region(*R)) ss.push_back((int) sg);
+                        else if (R->kind == SA_KIND_RING) rs[ring_class(*R)].push_back((int) sg);
                         else (R->kind != SA_KIND_FAST ? gs : (wide_bwd && R->slots >= 2 ? ws : fs)).push_back((int) sg);
                         const sa_seg_t *S = &pl->segs[sg];
                         if (!any) { G.seg0 = sg; G.ck0 = S->ck_base; any = true; }
@@ -1533,10 +1559,24 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
                     G.ids_rs[cl] = (long long) b->ids_flat.size(); G.nrs[cl] = (int) rs[cl].size();
                     b->ids_flat.insert(b->ids_flat.end(), rs[cl].begin(), rs[cl].end());
                 }
+                std::stable_sort(ss.begin(), ss.end(), by_len_s);
+                G.ids_ss = (long long) b->ids_flat.size(); G.nss = (int) ss.size();
+                b->ids_flat.insert(b->ids_flat.end(), ss.begin(), ss.end());
+                G.seam_first = (unsigned) chunk_bwd_slots;   // (rebased behind the forward slots below)
+                chunk_bwd_slots += (long long) ss.size();
                 b->groups.push_back(G);
             }
+            strip_bwd_slots = chunk_bwd_slots > strip_bwd_slots ? chunk_bwd_slots : strip_bwd_slots;
             C.g1 = (int) b->groups.size();
             b->chunks.push_back(C);
+        }
+        if (strip_fwd_slots + strip_bwd_slots > 0) {
+            // seam storage: per wave two arrays of (longest strip-kernel region + lead-in + sentinels) records; the groups of a
+            // pass run side by side, every segment has its own slot behind the forward launch's
+            b->seam_cap = (unsigned) (strip_max_n + 16);
+            b->seam_bwd_first = (unsigned) strip_fwd_slots;
+            for (auto &G : b->groups) G.seam_first += b->seam_bwd_first;
+            TRY(dalloc((void **) &b->d_seam, (long long) (strip_fwd_slots + strip_bwd_slots) * 2ll * 16ll * (long long) b->seam_cap));
         }
         b->gev.resize(4 * b->groups.size(), nullptr);
         b->cev.resize(2 * b->chunks.size(), nullptr);
@@ -1569,6 +1609,8 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     b->stats.n_checkpoints = pl->n_cks;
     b->stats.n_fast_regions = pl->n_fast_regions;
     b->stats.n_ring_regions = pl->n_ring_regions;
+    b->stats.n_strip_regions = 0;
+    for (const auto &C_ : b->chunks) b->stats.n_strip_regions += C_.nst;
     b->stats.n_chunks = pl->n_chunks;
     b->stats.n_groups = (int64_t) b->groups.size();
     double fb = 0;
@@ -1606,7 +1648,7 @@ int sa_dplan_compare(const sa_model_t *m, const sa_params_t *p, const sa_job_t *
     b->d_cands = nullptr; b->d_cand_count = nullptr; b->d_overflow = nullptr; b->d_totals = nullptr; b->d_bscratch = nullptr;
     b->d_tab6 = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr; b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr;
     b->d_hdp_tab = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr; b->d_seg_off = nullptr; b->d_out = nullptr;
-    b->d_ids = nullptr; b->d_gsum = nullptr; b->d_gmc = nullptr;
+    b->d_ids = nullptr; b->d_gsum = nullptr; b->d_gmc = nullptr; b->d_seam = nullptr;
     int rcd;
     {
         std::unique_lock<std::mutex> lk(g_uploader.mu);
@@ -1683,6 +1725,11 @@ static int submit_group(sa_batch *b, const DevPlan &P, int g, int which_stream, 
                            b->ring_cap);
     else if (G.ngs)
         hipLaunchKernelGGL((k_bwd_generic<false, false>), dim3(G.ngs), dim3(b->gen_threads), 0, st, P, b->d_ids + G.ids_gs, G.ngs, 0);
+    if (G.nss) {
+        StripT ST;
+        ST.ev_total = pl->n_ev + 8; ST.seam_cap = b->seam_cap; ST.seam_stride = 32ull * b->seam_cap; ST.seam_first = G.seam_first;
+        launch_bwd_strip(P, b->d_ids + G.ids_ss, G.nss, st, b->d_seam, ST);
+    }
     for (int cl = 15; cl >= 0; cl--)   // widest (longest-running) classes first
         if (G.nrs[cl]) launch_bwd_ring(P, b->d_ids + G.ids_rs[cl], G.nrs[cl], st, 64 * ((cl & 7) + 1), cl >= 8);
     if (G.nws) launch_bwd_fast(P, b->d_ids + G.ids_ws, G.nws, st, true);
@@ -1723,7 +1770,7 @@ static int enqueue_pass(sa_batch *b, bool finalize, AfterGroup after_group) {
         {   // ring-kernel regions, one launch per class of row capacity.  A forward launch holds one workgroup per read and
             // lasts as long as its longest read's serial chain, so launches that follow each other on one stream leave the chip
             // mostly empty three times over: the classes alternate between the two compute streams and run side by side
-            int n_cl = 0;
+            int n_cl = C.nst > 0;
             for (int cl = 0; cl < 16; cl++) n_cl += C.nrr[cl] > 0;
             hipStream_t lanes[4] = {s0, s1, b->xstream[0], b->xstream[1]};
             int n_lanes = n_cl < 4 ? n_cl : 4;
@@ -1737,6 +1784,12 @@ static int enqueue_pass(sa_batch *b, bool finalize, AfterGroup after_group) {
                 for (int q = 1; q < n_lanes; q++) HIPCHK(hipStreamWaitEvent(lanes[q], b->ev[1], 0));
             }
             int which = 0;
+            if (C.nst) {
+                StripT ST;
+                ST.ev_total = pl->n_ev + 8; ST.seam_cap = b->seam_cap; ST.seam_stride = 32ull * b->seam_cap; ST.seam_first = 0;
+                launch_fwd_strip(P, b->d_ids + C.ids_st, C.nst, lanes[0], b->d_seam, ST);
+                which = n_lanes > 1 ? 1 : 0;
+            }
             for (int cl = 15; cl >= 0; cl--)
                 if (C.nrr[cl]) {
                     launch_fwd_ring(P, b->d_ids + C.ids_rr[cl], C.nrr[cl], lanes[n_lanes > 1 ? which : 0], 64 * ((cl & 7) + 1), cl >= 8);

@@ -238,6 +238,44 @@ def test_ring_kernels_wide_bands_every_read_against_the_oracle(oracle, monkeypat
         cases.compare_pairs(got[j], fast[j], 10, p.threshold)
 
 
+def test_strip_kernels_wide_bands_bit_identical_to_the_ring_kernels(oracle, monkeypatch):
+    """One-path regions with wide bands run on the strip kernels (sa_strip.inc: a lane is a reference column, strips of 64
+    columns, seams through HBM, candidates by a second pass over forward + backward).  Per cell they do the ring kernels'
+    arithmetic in the ring kernels' order, so every pair -- rows, order, prob_e7 -- must equal the ring kernels' (SA_STRIP=0),
+    and both are within the tolerance of the CPU restatement.  Cases: anchors of a real guide alignment, no anchors at all
+    (bands of several hundred cells, one strip holds whole diagonals), reads shorter than one strip, several traceback
+    segments per read, ragged ends off (the default)."""
+    pm, om = _models(oracle, cases.MODEL_6MER)
+    p = sa.default_params()
+    op = cases.oracle_params(oracle, p)
+    jobs = cases.realistic_anchor_jobs(cases.MODEL_6MER, 8, 2500, 600) + cases.realistic_anchor_jobs(cases.MODEL_6MER, 2, 5200, 700)
+    alpha, k, t10, tab = synth.parse_model_table(cases.MODEL_6MER)
+    for n_ev, idx in ((260, 41), (520, 42), (90, 43), (35, 44)):
+        r = synth.make_read(idx, n_ev, alpha, k, tab)
+        jobs.append(dict(r, ax=np.zeros(0, dtype=np.int64), ay=np.zeros(0, dtype=np.int64)))
+    jobs += cases.synthetic_jobs(cases.MODEL_6MER, 2, 900, 300)      # dense anchors: register kernels
+    got, st = _run(pm, p, jobs)
+    assert st.n_ring_regions >= 12 and st.n_strip_regions == st.n_ring_regions
+    monkeypatch.setenv("SA_STRIP", "0")
+    ring, st2 = _run(pm, p, jobs)
+    monkeypatch.delenv("SA_STRIP")
+    assert st2.n_strip_regions == 0 and st2.n_ring_regions == st.n_ring_regions
+    for j in range(len(jobs)):
+        assert len(got[j]) == len(ring[j]), (j, len(got[j]), len(ring[j]))
+        for f in ("x", "y", "path", "kmer_id", "prob_e7"):
+            assert np.array_equal(got[j][f], ring[j][f]), (j, f)
+    worst = 0
+    for j, job in enumerate(jobs):
+        exp = cases.oracle_pairs(oracle, om, job, op)
+        w, lonely = cases.compare_pairs(got[j], exp, TOL_E7, p.threshold)
+        worst = max(worst, w)
+        assert lonely <= 2 and cases.same_order(got[j], exp), j
+    assert worst <= 10
+    again, _ = _run(pm, p, jobs)                                      # same bytes on a second batch (seams, atomics, planes)
+    for j in range(len(jobs)):
+        assert np.array_equal(again[j], got[j]), j
+
+
 def test_ring_kernels_ambiguous_positions_every_read_against_the_oracle(oracle, monkeypatch):
     """BASELINE configs[2] shape (ACEGT model, every CpG cytosine X -> C/E: 1, 2, 4 or 8 paths per cell) and the R7.3
     ACEGOT model with the default table's three-way code L -> C/E/O: the ring kernels with per-path neighbour records
