@@ -1499,15 +1499,15 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
             long long nseg_chunk = 0, nseg_wide = 0;
             for (long long q = ra; q < rb; q++) {
                 nseg_chunk += pl->regions[q].n_seg;
-                if (!strip_region(pl->regions[q]) &&
-                    ((pl->regions[q].kind == SA_KIND_FAST && pl->regions[q].slots >= 2) ||
-                     (pl->regions[q].kind == SA_KIND_RING && pl->regions[q].max_rowpaths > 64)))
+                if ((pl->regions[q].kind == SA_KIND_FAST && pl->regions[q].slots >= 2) ||
+                    (pl->regions[q].kind == SA_KIND_RING && pl->regions[q].max_rowpaths > 64))
                     nseg_wide += pl->regions[q].n_seg;
             }
             // segments of wide-band regions live three to four times longer than those of dense anchors (4 ms against
             // 1.2 ms), and so do the tails of their launches: fewer, larger groups.  2000 reads with realistic anchors,
             // 17 300 segments, step time with 1 / 2 / 3 / 4 / 6 / 8 groups: 70.2 / 67.8 / 69.3 / 73.1 / 80.2 / 87 ms
-            const long long min_per_group = (2 * nseg_wide > nseg_chunk) ? 8192 : 2048;
+            // (strip-kernel segments: 1 / 2 / 3 / 4 groups give 39.5 / 38.3 / 37.5 / 42.9 ms per step of fresh reads)
+            const long long min_per_group = (2 * nseg_wide > nseg_chunk) ? (b->strip_on ? 5500 : 8192) : 2048;
             int ng = want;
             if (!(envg && atoi(envg) > 0))
                 while (ng > 1 && nseg_chunk / ng < min_per_group) ng--;
