@@ -485,8 +485,6 @@ def main():
         else:
             dom, dom_ms, dom_cells = "k_fwd_" + fam, ms_f, st0.cells_forward
         achieved = ALGO_BYTES_PER_CELL * dom_cells / (dom_ms * 1e-3) / 1e9
-        if os.environ.get("SA_WIDE_BWD") == "1" and args.workload == "realistic" and dom == "k_bwd_fast":
-            dom = "k_bwd_fast_wide"  # opt-in variant for the segments of wide-band regions
         # HBM bytes per step of the dominant kernel from the rocprofv3 --pmc passes (profiles/traffic.json, written by
         # probes/profile_r02.sh + probes/traffic_from_pmc.py: FETCH_SIZE and WRITE_SIZE in separate passes, fetch doubled as
         # MI355X_MICROARCH.md prescribes for gfx950); collected at the default size of each workload only

@@ -878,8 +878,6 @@ __global__ __launch_bounds__(256) void k_fill_xc(const sa_region_t *__restrict__
 struct sa_launch_chunk {
     long long ids_gr, ids_fr;  // offsets into d_ids: memory-resident / register-kernel regions
     int ngr, nfr;
-    long long ids_fw[7];       // register-kernel regions whose band needs 2..6 x 64 lanes (k_fwd_wide<S>), by S
-    int nfw[7];
     long long ids_rr[16];      // ring-kernel regions by class: [multi * 8 + cap class], cap = 64 * (class + 1)
     int nrr[16];
     long long ids_st;          // one-path ring-kernel regions taken by the strip kernels (sa_strip.inc)
@@ -888,8 +886,8 @@ struct sa_launch_chunk {
 };
 struct sa_launch_group {
     long long seg0, seg1, ck0, ck1;
-    long long ids_gs, ids_fs, ids_ws;   // segments of memory-resident / register / register, wide-band regions
-    int ngs, nfs, nws;
+    long long ids_gs, ids_fs;           // segments of memory-resident / register-kernel regions
+    int ngs, nfs;
     long long ids_rs[16];               // segments of ring-kernel regions, by the class of their region
     int nrs[16];
     long long ids_ss;                   // segments of strip-kernel regions
@@ -1446,13 +1444,8 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
             while (r < pl->n_regions && pl->regions[r].chunk == c) r++;
             long long rb = r;
             sa_launch_chunk C;
-            std::vector<int> gr, fr, fw[7], sr_;
+            std::vector<int> gr, fr, sr_;
             double work = 0;
-            // SA_WIDE_KERNEL=1 sends regions whose band needs 2..5 x 64 lanes to k_fwd_wide (band in registers, S cells
-            // per lane).  Off by default: bit-identical, but slower than k_fwd_fast's memory-resident path -- 32.7 ms
-            // against 20.9 ms forward on 2000 reads with realistic anchors (the path is bound by the fp64 logAdd
-            // arithmetic, not by re-reading the band, and slot granularity adds idle lanes); DESIGN.md section 8.
-            const bool wide_on = getenv("SA_WIDE_KERNEL") && atoi(getenv("SA_WIDE_KERNEL")) == 1 && m->hdp == nullptr;
             std::vector<int> rr[16];
             auto ring_class = [](const sa_region_t &Rq) {
                 const int cl = Rq.max_rowpaths <= 64 ? 0 : (int) ((Rq.max_rowpaths - 1) / 64);   // <= 7 (SA_RING_MAX_ROWPATHS)
@@ -1463,7 +1456,6 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
                 if (strip_region(Rq)) { sr_.push_back((int) q); strip_max_n = Rq.N > strip_max_n ? Rq.N : strip_max_n; }
                 else if (Rq.kind == SA_KIND_RING) rr[ring_class(Rq)].push_back((int) q);
                 else if (Rq.kind != SA_KIND_FAST) gr.push_back((int) q);
-                else if (wide_on && Rq.slots >= 2 && Rq.slots <= SA_WIDE_SLOTS_MAX) fw[2].push_back((int) q);
                 else fr.push_back((int) q);
                 work += (double) Rq.N;
             }
@@ -1475,14 +1467,6 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
             b->ids_flat.insert(b->ids_flat.end(), gr.begin(), gr.end());
             C.ids_fr = (long long) b->ids_flat.size(); C.nfr = (int) fr.size();
             b->ids_flat.insert(b->ids_flat.end(), fr.begin(), fr.end());
-            auto by_work_r = [&](int a, int d) {
-                return pl->regions[a].N * pl->regions[a].slots > pl->regions[d].N * pl->regions[d].slots;
-            };
-            for (int sl = 0; sl < 7; sl++) {
-                std::stable_sort(fw[sl].begin(), fw[sl].end(), by_work_r);
-                C.ids_fw[sl] = (long long) b->ids_flat.size(); C.nfw[sl] = (int) fw[sl].size();
-                b->ids_flat.insert(b->ids_flat.end(), fw[sl].begin(), fw[sl].end());
-            }
             for (int cl = 0; cl < 16; cl++) {
                 std::stable_sort(rr[cl].begin(), rr[cl].end(), by_len_r);
                 C.ids_rr[cl] = (long long) b->ids_flat.size(); C.nrr[cl] = (int) rr[cl].size();
@@ -1522,19 +1506,14 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
                 while (q < rb && pl->regions[q].job == pl->regions[q - 1].job) { acc += (double) pl->regions[q].N; q++; }
                 sa_launch_group G;
                 G.seg0 = G.seg1 = G.ck0 = G.ck1 = 0;
-                std::vector<int> gs, fs, ws, rs[16], ss;
+                std::vector<int> gs, fs, rs[16], ss;
                 bool any = false;
-                // SA_WIDE_BWD=1 sends the segments of wide-band regions to k_bwd_fast_wide (loads of a wide diagonal
-                // batched, 2 waves per SIMD).  Off by default: it beats k_bwd_fast only when the launches are small
-                // (8 result groups: 53 against 65 ms); with the two groups such batches now get, k_bwd_fast's five
-                // waves per SIMD win (43 against 45 ms backward, 67.8 against 72.4 ms per step).  DESIGN.md section 8.
-                const bool wide_bwd = getenv("SA_WIDE_BWD") && atoi(getenv("SA_WIDE_BWD")) == 1 && m->hdp == nullptr;
                 for (long long t = qa; t < q; t++) {
                     const sa_region_t *R = &pl->regions[t];
                     for (long long sg = R->seg_off; sg < R->seg_off + R->n_seg; sg++) {
                         if (strip_region(*R)) ss.push_back((int) sg);
                         else if (R->kind == SA_KIND_RING) rs[ring_class(*R)].push_back((int) sg);
-                        else (R->kind != SA_KIND_FAST ? gs : (wide_bwd && R->slots >= 2 ? ws : fs)).push_back((int) sg);
+                        else (R->kind != SA_KIND_FAST ? gs : fs).push_back((int) sg);
                         const sa_seg_t *S = &pl->segs[sg];
                         if (!any) { G.seg0 = sg; G.ck0 = S->ck_base; any = true; }
                         G.seg1 = sg + 1;
@@ -1551,9 +1530,6 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
                 b->ids_flat.insert(b->ids_flat.end(), gs.begin(), gs.end());
                 G.ids_fs = (long long) b->ids_flat.size(); G.nfs = (int) fs.size();
                 b->ids_flat.insert(b->ids_flat.end(), fs.begin(), fs.end());
-                std::stable_sort(ws.begin(), ws.end(), by_len_s);
-                G.ids_ws = (long long) b->ids_flat.size(); G.nws = (int) ws.size();
-                b->ids_flat.insert(b->ids_flat.end(), ws.begin(), ws.end());
                 for (int cl = 0; cl < 16; cl++) {
                     std::stable_sort(rs[cl].begin(), rs[cl].end(), by_len_s);
                     G.ids_rs[cl] = (long long) b->ids_flat.size(); G.nrs[cl] = (int) rs[cl].size();
@@ -1732,7 +1708,6 @@ static int submit_group(sa_batch *b, const DevPlan &P, int g, int which_stream, 
     }
     for (int cl = 15; cl >= 0; cl--)   // widest (longest-running) classes first
         if (G.nrs[cl]) launch_bwd_ring(P, b->d_ids + G.ids_rs[cl], G.nrs[cl], st, 64 * ((cl & 7) + 1), cl >= 8);
-    if (G.nws) launch_bwd_fast(P, b->d_ids + G.ids_ws, G.nws, st, true);
     if (G.nfs) launch_bwd_fast(P, b->d_ids + G.ids_fs, G.nfs, st);
     HIPCHK(hipEventRecord(b->gev[4 * g + 1], st));
     if (G.ck1 > G.ck0)
@@ -1801,7 +1776,6 @@ static int enqueue_pass(sa_batch *b, bool finalize, AfterGroup after_group) {
             }
         }
         if (C.nfr) launch_fwd_fast(P, b->d_ids + C.ids_fr, C.nfr, s0, b->wide_cap);
-        if (C.nfw[2]) launch_fwd_wide(P, b->d_ids + C.ids_fw[2], C.nfw[2], s0);
         HIPCHK(hipEventRecord(b->cev[2 * c + 1], s0));
         if (C.g1 - C.g0 > 1) HIPCHK(hipStreamWaitEvent(s1, b->cev[2 * c + 1], 0));
         int submitted = C.g0, completed = C.g0;

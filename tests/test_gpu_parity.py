@@ -320,34 +320,6 @@ def test_ring_kernels_ambiguous_positions_every_read_against_the_oracle(oracle, 
             cases.compare_pairs(got[j], old[j], 10, p.threshold)
 
 
-def test_wide_band_kernels_bit_identical_and_close_to_oracle(oracle, monkeypatch):
-    # SA_WIDE_KERNEL=1 routes regions whose band needs 2..5 x 64 lanes to k_fwd_wide (band in registers at any
-    # width); it must reproduce the default path's forward values exactly, hence identical output pairs
-    pm, om = _models(oracle, cases.MODEL_6MER)
-    p = sa.default_params()
-    jobs = cases.realistic_anchor_jobs(cases.MODEL_6MER, 8, 2500, 600)
-    jobs += cases.synthetic_jobs(cases.MODEL_6MER, 4, 900, 300)  # narrow regions stay on k_fwd_fast
-    monkeypatch.setenv("SA_RING_WIDE", "0")    # these variants belong to the register kernels (default: ring kernels)
-    want, _st = _run(pm, p, jobs)
-    monkeypatch.setenv("SA_WIDE_KERNEL", "1")
-    got, _st = _run(pm, p, jobs)
-    assert sum(len(w) for w in want) > 0
-    for j in range(len(jobs)):
-        assert np.array_equal(got[j], want[j]), j
-    # SA_WIDE_BWD=1: the backward sweep of such regions on k_bwd_fast_wide (loads of a wide diagonal batched):
-    # same pairs as k_bwd_fast; both within tolerance of the CPU restatement
-    monkeypatch.delenv("SA_WIDE_KERNEL")
-    monkeypatch.setenv("SA_WIDE_BWD", "1")
-    batched, _st = _run(pm, p, jobs)
-    for j in range(len(jobs)):
-        assert np.array_equal(batched[j], want[j]), j
-    op = cases.oracle_params(oracle, p)
-    for j in (0, 5):
-        exp = cases.oracle_pairs(oracle, om, jobs[j], op)
-        cases.compare_pairs(want[j], exp, TOL_E7, p.threshold)
-        assert cases.same_order(want[j], exp)
-
-
 def test_split_regions_and_chunked_forward_storage(oracle, monkeypatch):
     pm, om = _models(oracle, cases.MODEL_6MER)
     p = sa.default_params()
