@@ -33,6 +33,7 @@ import numpy as np  # noqa: E402
 MODEL = os.path.join(ROOT, "tests", "golden", "models", "testModelR9.4_450bps.nucleotide.6mer.template.model")
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALGO_BYTES_PER_CELL = 24.0     # 3 fp64 states of every band cell, written once, read once
+ISSUE_PEAK_VALU_PER_S = 1024 / 1.83e-9   # 256 CUs x 4 SIMDs, one fp64 VALU wave-instruction per 1.83 ns each (probes/issue_probe.hip)
 
 
 def host_cpu_info():
@@ -497,6 +498,25 @@ def main():
                 traffic = json.load(open(tp)).get(args.workload, {}).get(dom, {}).get("bytes_per_step")
             except Exception:
                 traffic = None
+        # instruction issue of the dominant kernel: wave-instructions per step from the rocprofv3 --pmc passes
+        # (profiles/instr_mix.json, probes/profile_final.sh + probes/instr_from_pmc.py) over the stage time measured here.
+        # Peak: one fp64 VALU instruction per SIMD every 1.83 ns (probes/issue_probe.hip on this part) x 1024 SIMDs.
+        issue = None
+        ip = os.path.join(ROOT, "profiles", "instr_mix.json")
+        if os.path.exists(ip) and default_size:
+            try:
+                rec = json.load(open(ip)).get(args.workload, {}).get(dom)
+            except Exception:
+                rec = None
+            if rec and rec.get("valu_per_step"):
+                valu_rate = rec["valu_per_step"] / (dom_ms * 1e-3)
+                issue = {"kernel": dom, "valu_per_step": rec["valu_per_step"],
+                         "instructions_per_step": rec.get("instructions_per_step"),
+                         "achieved": valu_rate, "peak": ISSUE_PEAK_VALU_PER_S, "unit": "fp64 VALU wave-instructions/s",
+                         "frac": valu_rate / ISSUE_PEAK_VALU_PER_S,
+                         "all_instructions_per_s": (rec.get("instructions_per_step") or 0.0) / (dom_ms * 1e-3),
+                         "wave_wait_frac": rec.get("SQ_WAIT_ANY_frac_of_wave_cycles"),
+                         "source": "profiles/instr_mix.json (SQ_INSTS_* per kernel, rocprofv3 --pmc over bench.py --kernels-only)"}
         out = {
             "metric": "dp_cell_updates_per_s",
             "value": cells_all / dt,
@@ -546,6 +566,8 @@ def main():
                          "stage_ms": dom_ms,
                          "launches_per_step": int(st0.n_groups) if dom.startswith("k_bwd") else int(st0.n_chunks)},
         }
+        if issue:
+            out["issue_roofline"] = issue
         if not args.no_cpu_baseline and args.workload in ("gaussian", "scaling"):
             out["cpu_baseline"] = cpu_baseline(alpha, k, t10, tab, args.events, args.cpu_reads_per_thread,
                                                first_index=10 ** 6)
