@@ -1169,9 +1169,11 @@ static int upload(T **dst, const T *src, long long n, long long pad = 0, bool sr
     return SA_OK;
 }
 
+static std::atomic<int> g_batches_started(0);   // batches between sa_batch_start and sa_batch_wait (this process)
+
 void sa_batch_destroy(sa_batch_t *b) {
     if (!b) return;
-    if (b->runner) { b->runner->join(); delete b->runner; b->runner = nullptr; }
+    if (b->runner) { b->runner->join(); delete b->runner; b->runner = nullptr; g_batches_started.fetch_sub(1); }
     if (b->device >= 0) (void) hipSetDevice(b->device);
     // the storage goes back to the caching allocators without the implicit synchronisation of hipFree: nothing of this
     // batch may still be in flight (only possible after an error inside a run)
@@ -1430,6 +1432,10 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
         const char *envg = getenv("SA_GROUPS");  // test hook
         if (envg && atoi(envg) > 0) want = atoi(envg);
         else if (!host_finalize) want = pl->n_chunks == 1 ? 8 : (pl->n_chunks < 4 ? 4 : 2);
+        // A caller that keeps batches in flight (sa_batch_start: another batch of this process is running while this one is
+        // created) already overlaps a batch's result copy with its neighbours' kernels; what it wants is few, large launches:
+        // 2000 x 5000-event reads, three in flight, step time with 1 / 2 / 3 / 8 groups: 13.9 / 13.1 / 12.9 / 14.9 ms.
+        if (!(envg && atoi(envg) > 0) && !host_finalize && g_batches_started.load() > 0 && want > 3) want = 3;
         b->ids_flat.clear();
         // One-path ring-kernel regions go to the strip kernels (sa_strip.inc): Gaussian emissions, default arithmetic,
         // device-side finalisation, reference windows of fewer than 64 * STRIP_NS_MAX positions.  SA_STRIP=0: ring kernels.
@@ -2038,7 +2044,9 @@ int sa_batch_start(sa_batch_t *b) {
     if (!b) return SA_EINVAL;
     if (b->runner) return SA_ESTATE;
     b->runner_rc = SA_OK;
+    g_batches_started.fetch_add(1);
     b->runner = new (std::nothrow) std::thread([b]() { b->runner_rc = sa_batch_run(b); });
+    if (!b->runner) g_batches_started.fetch_sub(1);
     return b->runner ? SA_OK : SA_ENOMEM;
 }
 int sa_batch_wait(sa_batch_t *b) {
@@ -2047,6 +2055,7 @@ int sa_batch_wait(sa_batch_t *b) {
     b->runner->join();
     delete b->runner;
     b->runner = nullptr;
+    g_batches_started.fetch_sub(1);
     return b->runner_rc;
 }
 
