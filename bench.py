@@ -300,6 +300,15 @@ def main():
         device = local_rank % max(torch.cuda.device_count(), 1)  # identity on a full node
         torch.cuda.set_device(device)
         dist.init_process_group(backend=backend)  # RCCL; only used for the barrier and the max-over-ranks
+    if world > 1:
+        # Ranks of one node share the host (and, in a container, one CPU quota): the library sizes its host fan-out for a process
+        # that has the machine to itself, so every rank gets its share here.  (SA_HOST_THREADS / SA_PLAN_THREADS: DESIGN.md.)
+        info = host_cpu_info()
+        cpus = int(info["cgroup_cpu_quota"]) if info["cgroup_cpu_quota"] else len(info["allowed"])
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        share = max(2, min(16, cpus // max(local_world, 1) - 2))
+        os.environ.setdefault("SA_HOST_THREADS", str(share))
+        os.environ.setdefault("SA_PLAN_THREADS", str(share))
     import signalalign_amd as sa
     from signalalign_amd import synth
 
