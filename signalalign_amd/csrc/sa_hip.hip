@@ -917,7 +917,8 @@ struct sa_batch {
     bool strip_on;           // one-path ring-kernel regions run on the strip kernels (default; SA_STRIP=0: ring kernels)
     char *d_seam;            // their seam storage: per wave two arrays of seam_cap records of 16 bytes
     unsigned seam_cap;
-    unsigned seam_bwd_first; // wave slots [0, seam_bwd_first) serve the forward launch, the rest the backward launches of a pass
+    unsigned seam_cap_bwd;   // records per seam array of the backward launches (a traceback segment is shorter than a region)
+    long long seam_bwd_off;  // bytes: the forward launch's slots come first, then those of a pass's backward launches
     double *d_tab6; int *d_hdp_slot; double *d_hdp_y, *d_hdp_slope, *d_hdp_grid, *d_hdp_tab;
     long long *d_prob; int *d_seg_pass; long long *d_seg_off; sa_pair_t *d_out;
     int *d_ids;  // region / segment id lists per launch
@@ -1245,7 +1246,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     b->d_prec = nullptr;
     b->d_ev = nullptr; b->d_segs = nullptr; b->d_cks = nullptr; b->d_F = nullptr; b->d_vbuf = nullptr;
     b->d_cands = nullptr; b->d_cand_count = nullptr; b->d_overflow = nullptr; b->d_totals = nullptr;
-    b->d_seam = nullptr; b->seam_cap = 0; b->seam_bwd_first = 0; b->strip_on = false;
+    b->d_seam = nullptr; b->seam_cap = 0; b->seam_cap_bwd = 0; b->seam_bwd_off = 0; b->strip_on = false;
     b->d_bscratch = nullptr; b->d_tab6 = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr;
     b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr; b->d_hdp_tab = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr;
     b->d_seg_off = nullptr; b->d_out = nullptr; b->d_ids = nullptr; b->d_gsum = nullptr; b->d_gmc = nullptr;
@@ -1443,7 +1444,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
         auto strip_region = [&](const sa_region_t &Rq) {
             return b->strip_on && Rq.kind == SA_KIND_RING && Rq.max_p == 1 && Rq.lX < 64ll * STRIP_NS_MAX && Rq.N >= 1;
         };
-        long long strip_max_n = 0, strip_fwd_slots = 0, strip_bwd_slots = 0;
+        long long strip_max_n = 0, strip_max_seg = 0, strip_fwd_slots = 0, strip_bwd_slots = 0;
         long long r = 0;
         for (int c = 0; c < pl->n_chunks; c++) {
             long long ra = r;
@@ -1517,7 +1518,11 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
                 for (long long t = qa; t < q; t++) {
                     const sa_region_t *R = &pl->regions[t];
                     for (long long sg = R->seg_off; sg < R->seg_off + R->n_seg; sg++) {
-                        if (strip_region(*R)) ss.push_back((int) sg);
+                        if (strip_region(*R)) {
+                            ss.push_back((int) sg);
+                            const long long span = pl->segs[sg].start - pl->segs[sg].to;
+                            strip_max_seg = span > strip_max_seg ? span : strip_max_seg;
+                        }
                         else if (R->kind == SA_KIND_RING) rs[ring_class(*R)].push_back((int) sg);
                         else (R->kind != SA_KIND_FAST ? gs : fs).push_back((int) sg);
                         const sa_seg_t *S = &pl->segs[sg];
@@ -1553,12 +1558,13 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
             b->chunks.push_back(C);
         }
         if (strip_fwd_slots + strip_bwd_slots > 0) {
-            // seam storage: per wave two arrays of (longest strip-kernel region + lead-in + sentinels) records; the groups of a
-            // pass run side by side, every segment has its own slot behind the forward launch's
+            // seam storage: per wave two arrays of (diagonals of the longest strip-kernel region / traceback segment + lead-in
+            // + sentinels) records; the groups of a pass run side by side, every segment has its own slot behind the forward
+            // launch's
             b->seam_cap = (unsigned) (strip_max_n + 16);
-            b->seam_bwd_first = (unsigned) strip_fwd_slots;
-            for (auto &G : b->groups) G.seam_first += b->seam_bwd_first;
-            TRY(dalloc((void **) &b->d_seam, (long long) (strip_fwd_slots + strip_bwd_slots) * 2ll * 16ll * (long long) b->seam_cap));
+            b->seam_cap_bwd = (unsigned) (strip_max_seg + 16);
+            b->seam_bwd_off = strip_fwd_slots * 32ll * (long long) b->seam_cap;
+            TRY(dalloc((void **) &b->d_seam, b->seam_bwd_off + strip_bwd_slots * 32ll * (long long) b->seam_cap_bwd));
         }
         b->gev.resize(4 * b->groups.size(), nullptr);
         b->cev.resize(2 * b->chunks.size(), nullptr);
@@ -1709,8 +1715,8 @@ static int submit_group(sa_batch *b, const DevPlan &P, int g, int which_stream, 
         hipLaunchKernelGGL((k_bwd_generic<false, false>), dim3(G.ngs), dim3(b->gen_threads), 0, st, P, b->d_ids + G.ids_gs, G.ngs, 0);
     if (G.nss) {
         StripT ST;
-        ST.ev_total = pl->n_ev + 8; ST.seam_cap = b->seam_cap; ST.seam_stride = 32ull * b->seam_cap; ST.seam_first = G.seam_first;
-        launch_bwd_strip(P, b->d_ids + G.ids_ss, G.nss, st, b->d_seam, ST);
+        ST.ev_total = pl->n_ev + 8; ST.seam_cap = b->seam_cap_bwd; ST.seam_stride = 32ull * b->seam_cap_bwd; ST.seam_first = G.seam_first;
+        launch_bwd_strip(P, b->d_ids + G.ids_ss, G.nss, st, b->d_seam + b->seam_bwd_off, ST);
     }
     for (int cl = 15; cl >= 0; cl--)   // widest (longest-running) classes first
         if (G.nrs[cl]) launch_bwd_ring(P, b->d_ids + G.ids_rs[cl], G.nrs[cl], st, 64 * ((cl & 7) + 1), cl >= 8);
