@@ -915,6 +915,7 @@ struct sa_batch {
     int wide_cap;            // cells per row of the register kernels' LDS ring for wide diagonals (0: every diagonal fits)
     int gen_threads;         // 64, or 128 when a diagonal of a memory-resident region holds more than 64 cell-paths
     bool strip_on;           // one-path ring-kernel regions run on the strip kernels (default; SA_STRIP=0: ring kernels)
+    double *d_ckxy;          // ... and the backward kernel's side buffer (2 x n_vbuf doubles)
     char *d_seam;            // their seam storage: per wave two arrays of seam_cap records of 16 bytes
     unsigned seam_cap;
     unsigned seam_cap_bwd;   // records per seam array of the backward launches (a traceback segment is shorter than a region)
@@ -1186,7 +1187,7 @@ void sa_batch_destroy(sa_batch_t *b) {
     void *ptrs[] = {b->d_regions, b->d_rows, b->d_pk, b->d_poff, b->d_pid, b->d_px, b->d_xc, b->d_prec, b->d_ev, b->d_segs, b->d_cks, b->d_F,
                     b->d_vbuf, b->d_cands, b->d_cand_count, b->d_overflow, b->d_totals, b->d_bscratch, b->d_tab6,
                     b->d_hdp_slot, b->d_hdp_y, b->d_hdp_slope, b->d_hdp_grid, b->d_hdp_tab, b->d_prob, b->d_seg_pass, b->d_seg_off,
-                    b->d_out, b->d_ids, b->d_gsum, b->d_gmc, b->d_seam};
+                    b->d_out, b->d_ids, b->d_gsum, b->d_gmc, b->d_seam, b->d_ckxy};
     for (void *p : ptrs)
         if (p) g_sa_pool.put(SaPool::DEVICE, p);
     for (int i = 0; i < 8; i++)
@@ -1246,7 +1247,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     b->d_prec = nullptr;
     b->d_ev = nullptr; b->d_segs = nullptr; b->d_cks = nullptr; b->d_F = nullptr; b->d_vbuf = nullptr;
     b->d_cands = nullptr; b->d_cand_count = nullptr; b->d_overflow = nullptr; b->d_totals = nullptr;
-    b->d_seam = nullptr; b->seam_cap = 0; b->seam_cap_bwd = 0; b->seam_bwd_off = 0; b->strip_on = false;
+    b->d_seam = nullptr; b->d_ckxy = nullptr; b->seam_cap = 0; b->seam_cap_bwd = 0; b->seam_bwd_off = 0; b->strip_on = false;
     b->d_bscratch = nullptr; b->d_tab6 = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr;
     b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr; b->d_hdp_tab = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr;
     b->d_seg_off = nullptr; b->d_out = nullptr; b->d_ids = nullptr; b->d_gsum = nullptr; b->d_gmc = nullptr;
@@ -1565,6 +1566,8 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
             b->seam_cap_bwd = (unsigned) (strip_max_seg + 16);
             b->seam_bwd_off = strip_fwd_slots * 32ll * (long long) b->seam_cap;
             TRY(dalloc((void **) &b->d_seam, b->seam_bwd_off + strip_bwd_slots * 32ll * (long long) b->seam_cap_bwd));
+            // side buffer of the backward strip kernel: the two backward gap sums of every checkpoint cell, laid out like vbuf
+            TRY(dalloc((void **) &b->d_ckxy, 16ll * (pl->n_vbuf > 0 ? pl->n_vbuf : 1)));
         }
         b->gev.resize(4 * b->groups.size(), nullptr);
         b->cev.resize(2 * b->chunks.size(), nullptr);
@@ -1636,7 +1639,7 @@ int sa_dplan_compare(const sa_model_t *m, const sa_params_t *p, const sa_job_t *
     b->d_cands = nullptr; b->d_cand_count = nullptr; b->d_overflow = nullptr; b->d_totals = nullptr; b->d_bscratch = nullptr;
     b->d_tab6 = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr; b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr;
     b->d_hdp_tab = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr; b->d_seg_off = nullptr; b->d_out = nullptr;
-    b->d_ids = nullptr; b->d_gsum = nullptr; b->d_gmc = nullptr; b->d_seam = nullptr;
+    b->d_ids = nullptr; b->d_gsum = nullptr; b->d_gmc = nullptr; b->d_seam = nullptr; b->d_ckxy = nullptr;
     int rcd;
     {
         std::unique_lock<std::mutex> lk(g_uploader.mu);
@@ -1716,7 +1719,8 @@ static int submit_group(sa_batch *b, const DevPlan &P, int g, int which_stream, 
     if (G.nss) {
         StripT ST;
         ST.ev_total = pl->n_ev + 8; ST.seam_cap = b->seam_cap_bwd; ST.seam_stride = 32ull * b->seam_cap_bwd; ST.seam_first = G.seam_first;
-        launch_bwd_strip(P, b->d_ids + G.ids_ss, G.nss, st, b->d_seam + b->seam_bwd_off, ST);
+        ST.ck_half = pl->n_vbuf;
+        launch_bwd_strip(P, b->d_ids + G.ids_ss, G.nss, st, b->d_seam + b->seam_bwd_off, b->d_ckxy, ST);
     }
     for (int cl = 15; cl >= 0; cl--)   // widest (longest-running) classes first
         if (G.nrs[cl]) launch_bwd_ring(P, b->d_ids + G.ids_rs[cl], G.nrs[cl], st, 64 * ((cl & 7) + 1), cl >= 8);
