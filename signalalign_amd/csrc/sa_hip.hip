@@ -1218,6 +1218,10 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
         return SA_ENODEVICE;
     }
     if (device < 0 || device >= ndev) return SA_EINVAL;
+    // Threshold 0 keeps every band cell, the ones of posterior 0 included: the default kernels' candidate filter (forward +
+    // backward >= checkpoint maximum + log threshold) has no lower bound then and would pass lanes that hold no cell.  Such a
+    // batch takes the reference-ordered kernels with host finalisation, which list a diagonal's cells explicitly.
+    if (!(p->threshold > 0.0)) flags |= SA_FLAG_EXACT;
     HIPCHK(hipSetDevice(device));
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));

@@ -183,6 +183,23 @@ def test_threshold_zero_and_one(oracle):
         assert np.array_equal(got[0]["prob_e7"], exp["prob_e7"])
 
 
+def test_threshold_zero_default_flags(oracle):
+    """Threshold 0 keeps every band cell: with default flags the batch is routed to the reference-ordered kernels (the
+    default kernels' candidate filter has no lower bound at log 0) and must list exactly the oracle's rows -- dense anchors
+    (register kernels otherwise) and sparse ones (strip kernels otherwise)."""
+    pm, om = _models(oracle, cases.MODEL_6MER)
+    p = sa.default_params(threshold=0.0)
+    op = cases.oracle_params(oracle, p)
+    jobs = cases.synthetic_jobs(cases.MODEL_6MER, 2, 500, 300) + cases.realistic_anchor_jobs(cases.MODEL_6MER, 1, 900, 600)
+    got, st = _run(pm, p, jobs)
+    assert st.n_fast_regions == 0 and st.n_strip_regions == 0
+    for j, job in enumerate(jobs):
+        exp = cases.oracle_pairs(oracle, om, job, op)
+        assert len(got[j]) == len(exp), j
+        for f in ("x", "y", "prob_e7"):
+            assert np.array_equal(got[j][f], exp[f]), (j, f)
+
+
 def test_sparse_anchors_wide_bands(oracle, monkeypatch):
     # realistic guide alignments: anchor-free windows widen the band beyond 64 cells, the register kernels
     # must hand over to the memory-resident path and back
