@@ -580,7 +580,7 @@ def main():
         }
         if issue:
             out["issue_roofline"] = issue
-        if not args.no_cpu_baseline and args.workload in ("gaussian", "scaling"):
+        if not args.no_cpu_baseline and world == 1 and args.workload in ("gaussian", "scaling"):   # (rank 0 at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(alpha, k, t10, tab, args.events, args.cpu_reads_per_thread,
                                                first_index=10 ** 6)
         print(json.dumps(out))
