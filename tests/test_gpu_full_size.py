@@ -80,3 +80,53 @@ def test_baseline_config_1_full_size(oracle):
         assert all((int(x), int(y)) in have for x, y in path[:: 17])
         assert best <= len(path) + 1e-9
     b.close()
+
+
+def test_realistic_anchor_density_full_size(oracle, monkeypatch):
+    """The same reads with the anchors a real guide alignment leaves (bands of 100-300 cells) at bench size, 5000 events a
+    read: every region runs on the strip kernels.  Checked: posteriors are probabilities in TSV order; a second run and a
+    second batch give the same bytes (seam arrays, side buffers and LDS maxima leave nothing behind); reads run alone in a
+    small batch give the same bytes; the ring kernels (SA_STRIP=0) give the same bytes for every read -- they fold a cell's
+    terms in the same order from LDS rows instead of registers and seams --; two reads agree with the CPU restatement."""
+    n_reads = 600
+    pm = sa.Model.load(cases.MODEL_6MER)
+    p = sa.default_params()
+    jobs = cases.realistic_anchor_jobs(cases.MODEL_6MER, n_reads, N_EVENTS)
+    b = sa.Batch(pm, p, jobs)
+    b.run()
+    st = b.stats()
+    assert st.n_strip_regions == st.n_regions == n_reads
+    for j in range(0, n_reads, 5):
+        pr = b.pairs(j)
+        assert len(pr) > 0.5 * len(jobs[j]["events"])
+        assert pr["prob_e7"].min() >= int(p.threshold * 1e7) and pr["prob_e7"].max() <= 10_000_000
+        assert np.all(np.diff(pr["x"] + pr["y"]) >= 0)
+        assert pr["y"].max() < len(jobs[j]["events"]) and pr["x"].max() <= len(jobs[j]["ref"])
+        assert np.bincount(pr["y"], weights=pr["prob_e7"] / 1e7).max() <= 1.0 + 1e-3
+    first, per_read = _digest(b, n_reads)
+    b.run()
+    assert _digest(b, n_reads)[0] == first
+    b.close()
+    b2 = sa.Batch(pm, p, jobs)
+    b2.run()
+    assert _digest(b2, n_reads)[0] == first
+    b2.close()
+    pick = [3, 77, 311, 598]
+    small = sa.Batch(pm, p, [jobs[j] for j in pick])
+    small.run()
+    for q, j in enumerate(pick):
+        assert zlib.crc32(small.pairs(q).tobytes()) == per_read[j]
+    alpha, k, t10, tab = sa.synth.parse_model_table(cases.MODEL_6MER)
+    om = oracle.Model(alpha, k, t10, tab)
+    op = cases.oracle_params(oracle, p)
+    for q, j in enumerate(pick[:2]):
+        exp = cases.oracle_pairs(oracle, om, jobs[j], op)
+        worst, n_only = cases.compare_pairs(small.pairs(q), exp, 100, p.threshold)
+        assert worst <= 10 and n_only <= 5 and cases.same_order(small.pairs(q), exp)
+    small.close()
+    monkeypatch.setenv("SA_STRIP", "0")
+    ring = sa.Batch(pm, p, jobs)
+    ring.run()
+    assert ring.stats().n_strip_regions == 0
+    assert _digest(ring, n_reads)[1] == per_read
+    ring.close()
