@@ -433,8 +433,9 @@ def main():
     depth = max(1, min(args.in_flight, int(0.6 * hbm_bytes / max(1.25 * st0.f_bytes, 1.0))))
     if args.workload == "scaling":
         depth = 1
-    # ... and as long as their pairs fit the pinned result buffers the library keeps (8 GB by default: beyond that every batch
-    # pins fresh host memory, 0.25 ms per MB) -- the HDP workload returns 4.3 GB of pairs per batch and goes one at a time
+    # ... and only while a batch's pairs are a small part of the traffic: the HDP workload returns 4.3 GB of pairs per batch
+    # (77 ms of PCIe against 28 ms of kernels) and is faster one batch at a time (155 against 220 ms per step with three in
+    # flight: the result copies of the neighbours queue behind each other on the one copy engine)
     depth = max(1, min(depth, int(6e9 / max(24.0 * n_pairs, 1.0))))
     cells_done = [0.0]
 

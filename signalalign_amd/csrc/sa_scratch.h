@@ -72,7 +72,7 @@ struct SaScratch {
 // per 2000 reads: hipMalloc / hipFree of its 25 GB (0.1 - 1 s per batch, measured), hipHostMalloc of the 200 MB pinned
 // result buffer (40 ms) and their release (130 ms) cost ten times the kernels.  Blocks handed back are kept (per device
 // and kind) and reused for requests they fit without wasting more than half of the block; sa_pool_release() returns
-// everything, SA_POOL=0 disables the cache, SA_POOL_LIMIT_GB bounds what is held (default: 90 % of the device's memory, 8 GB pinned).
+// everything, SA_POOL=0 disables the cache, SA_POOL_LIMIT_GB bounds what is held (default: 90 % of the device's memory, 32 GB pinned).
 struct SaPool {
     enum Kind { DEVICE = 0, PINNED = 1 };
     struct Blk {
@@ -91,7 +91,7 @@ struct SaPool {
     static size_t limit(int kind) {
         const char *e = getenv("SA_POOL_LIMIT_GB");
         if (e) return (size_t) (atof(e) * 1073741824.0);
-        if (kind != DEVICE) return (size_t) 8 << 30;
+        if (kind != DEVICE) return (size_t) 32 << 30;   // (pinning costs 0.25 ms per MB: three HDP batches of 4.3 GB of pairs stay cached)
         // device: whatever a destroyed batch held may stay parked (a 10k-event slice holds 170 GB of forward storage, and
         // hipFree + hipMalloc of it cost seconds); parked blocks are handed back when an allocation fails (get())
         static size_t dev_limit = 0;
