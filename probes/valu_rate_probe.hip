@@ -192,7 +192,7 @@ int main(int argc, char **argv) {
     hipEvent_t ev0, ev1;
     HIPCHK(hipEventCreate(&ev0));
     HIPCHK(hipEventCreate(&ev1));
-    for (int wps : {1, 4, 8}) {
+    for (int wps : {1, 2, 4, 8}) {
         const int waves = cus * 4 * wps, blocks = waves / 4;
         Out *d;
         HIPCHK(hipMalloc(&d, sizeof(Out) * waves));
