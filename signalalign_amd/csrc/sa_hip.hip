@@ -1064,6 +1064,7 @@ struct SaUploader {
 };
 static SaUploader g_uploader;
 SaPool g_sa_pool;
+SaWorkers g_sa_workers;
 static size_t g_sa_pool_idle_bytes(int device) { return g_sa_pool.idle_bytes(SaPool::DEVICE, device); }
 
 // Streams and events of destroyed batches, kept per device for the next batch (creating three streams and ~50 events is
@@ -1222,6 +1223,9 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     // backward >= checkpoint maximum + log threshold) has no lower bound then and would pass lanes that hold no cell.  Such a
     // batch takes the reference-ordered kernels with host finalisation, which list a diagonal's cells explicitly.
     if (!(p->threshold > 0.0)) flags |= SA_FLAG_EXACT;
+    const bool trace_c = getenv("SA_TRACE") != nullptr;
+    auto now_ms_c = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double tc0 = now_ms_c();
     HIPCHK(hipSetDevice(device));
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
@@ -1231,9 +1235,6 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     const char *envb = getenv("SA_F_BUDGET_CELLPATHS");  // test hook: force several passes
     if (envb && atoll(envb) > 0) budget = atoll(envb);
 
-    const bool trace_c = getenv("SA_TRACE") != nullptr;
-    auto now_ms_c = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
-    const double tc0 = now_ms_c();
     sa_batch *b = new sa_batch();
     b->plan = nullptr;
     b->dev_planned = false;
@@ -1612,6 +1613,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     for (long long r = 0; r < pl->n_regions; r++) fb += 24.0 * (double) pl->regions[r].f_cellpaths;
     b->stats.f_bytes = fb;
 #undef TRY
+    if (trace_c) fprintf(stderr, "[trace] create: done at %.1f ms\n", now_ms_c() - tc0);
     *out = b;
     return SA_OK;
 }

@@ -7,9 +7,11 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -199,6 +201,60 @@ extern SaPool g_sa_pool;
 int sa_batch_device_view(sa_batch_t *b, const sa_pair_t **pairs, std::vector<long long> *first, std::vector<long long> *count,
                          std::vector<long long> *n_events, int *device);
 
+// Worker threads of the host fan-out below, started on first use and parked between calls: a fresh std::thread per worker and
+// call cost 0.5-0.7 ms per fan-out at 13 workers, and sa_batch_create fans out five times (a third of its host time).  One
+// fan-out at a time; callers from other threads queue up behind it.
+struct SaWorkers {
+    std::mutex call_mu;   // one fan-out at a time
+    std::mutex mu;
+    std::condition_variable cv, done_cv;
+    std::vector<std::thread> th;
+    const std::function<void()> *job = nullptr;
+    unsigned long long gen = 0;
+    unsigned take = 0, active = 0;   // workers that should join the current job / that have not finished it yet
+    bool stop = false;
+    void loop(unsigned idx) {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void()> *f = nullptr;
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen;
+                if (idx < take) f = job;
+            }
+            if (!f) continue;
+            (*f)();
+            std::lock_guard<std::mutex> g(mu);
+            if (--active == 0) done_cv.notify_all();
+        }
+    }
+    // runs `work` on `helpers` pool threads and on the caller; returns when all of them have returned
+    void run(unsigned helpers, const std::function<void()> &work) {
+        std::lock_guard<std::mutex> c(call_mu);
+        {
+            std::lock_guard<std::mutex> g(mu);
+            while (th.size() < helpers) {
+                const unsigned idx = (unsigned) th.size();
+                th.emplace_back([this, idx] { loop(idx); });
+            }
+            job = &work; take = helpers; active = helpers; gen++;
+        }
+        cv.notify_all();
+        work();
+        std::unique_lock<std::mutex> g(mu);
+        done_cv.wait(g, [&] { return active == 0; });
+        job = nullptr;
+    }
+    ~SaWorkers() {
+        { std::lock_guard<std::mutex> g(mu); stop = true; }
+        cv.notify_all();
+        for (std::thread &t : th) t.join();
+    }
+};
+extern SaWorkers g_sa_workers;
+
 // Host-side fan-out for per-read output building (fresh malloc'ed buffers are first-touch page faults: 60-100 MB of
 // them per call are 5-10 ms on one thread).  fn(j) for j in [0, n), work handed out in blocks; SA_HOST_THREADS overrides
 // the thread count (default: hardware threads, at most 16).
@@ -238,6 +294,11 @@ static inline void sa_parallel_for(size_t n, F fn) {
             for (size_t j = a; j < b; j++) fn(j);
         }
     };
+    static const bool parked = !(getenv("SA_WORKER_POOL") && atoi(getenv("SA_WORKER_POOL")) == 0);   // measurement hook
+    if (parked) {
+        g_sa_workers.run(want - 1, std::function<void()>(work));
+        return;
+    }
     std::vector<std::thread> pool;
     for (unsigned t = 1; t < want; t++) pool.emplace_back(work);
     work();
