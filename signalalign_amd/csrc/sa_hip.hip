@@ -943,6 +943,7 @@ struct sa_batch {
     sa_pair_t *d_pairs_up;                // host-finalised pairs uploaded for a downstream device step (sa_batch_mea)
     long long d_pairs_up_cap;
     bool ran;
+    bool quiet;            // the last run returned SA_OK: it waited for everything it had queued, the batch's streams are idle
     bool dev_planned;      // the plan was built on the device (sa_dplan.inc): its big arrays exist in HBM only
     std::thread *runner;   // sa_batch_start .. sa_batch_wait
     int runner_rc;
@@ -1180,11 +1181,18 @@ void sa_batch_destroy(sa_batch_t *b) {
     if (b->device >= 0) (void) hipSetDevice(b->device);
     // the storage goes back to the caching allocators without the implicit synchronisation of hipFree: nothing of this
     // batch may still be in flight (only possible after an error inside a run)
-    for (int i = 0; i < 2; i++)
-        if (b->cstream[i]) (void) hipStreamSynchronize(b->cstream[i]);
-    for (int i = 0; i < 2; i++)
-        if (b->xstream[i]) (void) hipStreamSynchronize(b->xstream[i]);
-    if (b->pair_stream) (void) hipStreamSynchronize(b->pair_stream);
+    const bool trace_d = getenv("SA_TRACE") != nullptr;
+    auto now_ms_d = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double td0 = now_ms_d();
+    if (!b->quiet) {   // (a failed or interrupted run, or a batch that never ran: 0.6-0.9 ms of API calls otherwise, per batch,
+                       // on the thread that is about to plan the next one)
+        for (int i = 0; i < 2; i++)
+            if (b->cstream[i]) (void) hipStreamSynchronize(b->cstream[i]);
+        for (int i = 0; i < 2; i++)
+            if (b->xstream[i]) (void) hipStreamSynchronize(b->xstream[i]);
+        if (b->pair_stream) (void) hipStreamSynchronize(b->pair_stream);
+    }
+    const double td1 = now_ms_d();
     void *ptrs[] = {b->d_regions, b->d_rows, b->d_pk, b->d_poff, b->d_pid, b->d_px, b->d_xc, b->d_prec, b->d_ev, b->d_segs, b->d_cks, b->d_F,
                     b->d_vbuf, b->d_cands, b->d_cand_count, b->d_overflow, b->d_totals, b->d_bscratch, b->d_tab6,
                     b->d_hdp_slot, b->d_hdp_y, b->d_hdp_slope, b->d_hdp_grid, b->d_hdp_tab, b->d_prob, b->d_seg_pass, b->d_seg_off,
@@ -1204,8 +1212,10 @@ void sa_batch_destroy(sa_batch_t *b) {
     g_sa_pool.put(SaPool::DEVICE, b->d_pairs_up);
     g_sa_pool.put(SaPool::PINNED, b->h_seg_off);
     g_sa_pool.put(SaPool::PINNED, b->h_overflow);
+    const double td2 = now_ms_d();
     sa_plan_free(b->plan);
     delete b;
+    if (trace_d) fprintf(stderr, "[trace] destroy: streams idle after %.2f ms, blocks parked after %.2f ms, done after %.2f ms\n", td1 - td0, td2 - td0, now_ms_d() - td0);
 }
 
 #include "sa_dplan.inc"
@@ -1247,6 +1257,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     b->h_seg_off = nullptr;
     b->h_overflow = nullptr;
     b->ran = false;
+    b->quiet = false;
     b->runner = nullptr; b->runner_rc = SA_OK;
     b->d_regions = nullptr; b->d_rows = nullptr; b->d_pk = nullptr; b->d_poff = nullptr; b->d_pid = nullptr; b->d_px = nullptr; b->d_xc = nullptr;
     b->d_prec = nullptr;
@@ -1881,8 +1892,15 @@ static int run_passes(sa_batch_t *b) {
     return SA_ENOMEM;
 }
 
+static int batch_run_body(sa_batch_t *b);
 int sa_batch_run(sa_batch_t *b) {
     if (!b) return SA_EINVAL;
+    b->quiet = false;
+    const int rc = batch_run_body(b);
+    b->quiet = rc == SA_OK;
+    return rc;
+}
+static int batch_run_body(sa_batch_t *b) {
     if (b->expect) return SA_ESTATE;
     HIPCHK(hipSetDevice(b->device));
     sa_plan_t *pl = b->plan;
