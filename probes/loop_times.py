@@ -2,6 +2,18 @@
 steady part), beside the step time.  usage: python probes/loop_times.py [depth] [steps]"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
+def _cpulist(path):
+    out = []
+    for part in open(path).read().strip().split(","):
+        if "-" in part:
+            a, b = part.split("-"); out += list(range(int(a), int(b) + 1))
+        elif part:
+            out.append(int(part))
+    return out
+if os.environ.get("PIN_NODE"):   # PIN_NODE=0|1: run on the CPUs of one NUMA node (set before any thread starts)
+    cpus = set(_cpulist("/sys/devices/system/node/node%s/cpulist" % os.environ["PIN_NODE"])) & os.sched_getaffinity(0)
+    os.sched_setaffinity(0, cpus)
+    print("pinned to node", os.environ["PIN_NODE"], len(cpus), "cpus")
 import numpy as np
 import signalalign_amd as sa
 from signalalign_amd import synth
