@@ -275,6 +275,12 @@ def test_strip_kernels_wide_bands_bit_identical_to_the_ring_kernels(oracle, monk
     assert st.n_ring_regions >= 12 and st.n_strip_regions == st.n_ring_regions
     monkeypatch.setenv("SA_STRIP", "0")
     ring, st2 = _run(pm, p, jobs)
+    for waves in ("1", "2", "4"):          # the ring kernels' workgroup shapes (1-8 cells per thread and diagonal): same bytes
+        monkeypatch.setenv("SA_RING_WAVES", waves)
+        ring_w, _ = _run(pm, p, jobs)
+        for j in range(len(jobs)):
+            assert np.array_equal(ring_w[j], ring[j]), (waves, j)
+    monkeypatch.delenv("SA_RING_WAVES")
     monkeypatch.delenv("SA_STRIP")
     assert st2.n_strip_regions == 0 and st2.n_ring_regions == st.n_ring_regions
     for j in range(len(jobs)):
@@ -329,6 +335,15 @@ def test_ring_kernels_ambiguous_positions_every_read_against_the_oracle(oracle, 
             ek = {(int(r["x"]), int(r["y"]), int(r["path"])): int(r["kmer_id"]) for r in exp}
             assert all(ek.get((int(r["x"]), int(r["y"]), int(r["path"])), int(r["kmer_id"])) == int(r["kmer_id"]) for r in got[j])
         assert worst <= 10
+        # every workgroup shape of the ring kernels (1, 2, 4 waves: one, two, four or eight cell-paths per thread and
+        # diagonal -- the candidate prefix across waves has a vector path for one chunk per wave and a packed-word path for
+        # several) gives the same bytes
+        for waves in ("1", "2", "4"):
+            monkeypatch.setenv("SA_RING_WAVES", waves)
+            again, _ = _run(pm, p, jobs, ambig=amb_p)
+            for j in range(len(jobs)):
+                assert np.array_equal(again[j], got[j]), (waves, j)
+        monkeypatch.delenv("SA_RING_WAVES")
         monkeypatch.setenv("SA_RING", "0")
         old, st2 = _run(pm, p, jobs, ambig=amb_p)
         monkeypatch.delenv("SA_RING")
