@@ -441,15 +441,36 @@ def main():
 
     def stream(n_steps, first):
         flying = []
+        if depth == 1:
+            # one batch at a time on the device (its forward storage takes most of the card): the next batch's reads are
+            # checked, packed, uploaded and planned (sa_batch_create_deferred) while the current one runs; the rest of its
+            # creation -- working buffers sized for the device to itself -- follows when the current one has been destroyed
+            def make(s_):
+                return sa.Batch(pm, params, arrays[(first + s_) % n_sets], ambig=ambig, device=device, deferred=True,
+                                flags=sa.FLAG_DEVICE_TO_ITSELF)
+            nxt = make(0) if n_steps > 0 else None
+            dbg = os.environ.get("SA_BENCH_DEBUG")
+            for s in range(n_steps):
+                cur = nxt
+                t_a = time.perf_counter()
+                cur.start()
+                nxt = make(s + 1) if s + 1 < n_steps else None
+                t_b = time.perf_counter()
+                cur.wait()
+                t_c = time.perf_counter()
+                stc = cur.stats()
+                cells_done[0] += stc.cells_forward + stc.cells_backward
+                cur.n_pairs(0)
+                cur.close()
+                if dbg:
+                    print("[bench] step %d: next batch's first half %.1f ms, then waited %.1f ms, collect %.1f ms; device %.1f ms"
+                          % (s, (t_b - t_a) * 1e3, (t_c - t_b) * 1e3, (time.perf_counter() - t_c) * 1e3, stc.ms_total_device),
+                          file=sys.stderr)
+            return
         for s in range(n_steps):
             cur = sa.Batch(pm, params, arrays[(first + s) % n_sets], ambig=ambig, device=device)
             stc = cur.stats()
             cells_done[0] += stc.cells_forward + stc.cells_backward
-            if depth == 1:
-                cur.run()
-                cur.n_pairs(0)
-                cur.close()
-                continue
             cur.start()
             flying.append(cur)
             if len(flying) >= depth:
@@ -557,7 +578,8 @@ def main():
                 "result_groups": int(st0.n_groups),
                 "step": "one batch of fresh reads through the whole boundary: sa_batch_create (checks, planning, upload) + run + "
                         "results on the host + sa_batch_destroy; %s" % ("%d batches in flight (sa_batch_start / sa_batch_wait)" % depth
-                                                                        if depth > 1 else "one batch at a time"),
+                                                                        if depth > 1 else "one batch on the device at a time, the next one checked, "
+                                                                        "packed, uploaded and planned meanwhile (sa_batch_create_deferred)"),
                 "read_sets_cycled": n_sets,
                 "first_batch_create_s": t_create,
                 "serial_cycle_ms": cycle,

@@ -39,6 +39,9 @@ extern "C" {
                                      (slow kernels; bit-identical posteriors for Gaussian emissions) */
 #define SA_FLAG_FORCE_GENERIC 2u  /* never pick the register-resident fast kernels */
 #define SA_FLAG_RNA 4u            /* event alignment only: k-mers as build_kmer_list(..., rna=true) makes them (U -> T, reversed) */
+#define SA_FLAG_DEVICE_TO_ITSELF 8u /* sa_batch_create_deferred only: every other batch on this device will have been destroyed
+                                     before this one's first use -- its forward storage is sized for the memory they hold too
+                                     (one batch at a time, the next one packed and planned while the current one runs) */
 
 typedef struct sa_model sa_model_t; /* replaces StateMachine3 / StateMachine3_HDP (inc/stateMachine.h:150-190) */
 typedef struct sa_batch sa_batch_t;
@@ -134,6 +137,16 @@ int sa_load_ambig(const char *path, const char **map256);
 int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs,
                     int64_t n_jobs, const char *const *ambig256, int device, unsigned flags);
 int sa_batch_run(sa_batch_t *b);
+/* sa_batch_create in two halves, for a caller that streams batches (sa_batch_start / sa_batch_wait below).  The first half --
+ * input checks, packing and upload of the reads, the planning kernels queued -- runs here; the second -- waiting for the plan,
+ * working buffers, launch lists -- on the batch's first use (sa_batch_run or the thread of sa_batch_start, sa_batch_stats,
+ * sa_batch_job_cells), so the calling thread does not wait for the GPU and can pack the next batch.  Same arguments and
+ * results as sa_batch_create; what differs: `jobs` and `ambig256` must stay valid until that first use has returned (a read
+ * the planning kernels turn down sends the batch to the host planner, which reads them again), and an error found by the
+ * second half is returned by that first use instead.  A batch the planning kernels do not take at all (an ambiguity letter
+ * with repeated options, SA_FLAG_EXACT, ...) is created completely, as by sa_batch_create. */
+int sa_batch_create_deferred(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs,
+                             int64_t n_jobs, const char *const *ambig256, int device, unsigned flags);
 /* The same on a thread of the library's own: sa_batch_start returns at once, sa_batch_wait returns sa_batch_run's code.
  * Lets one caller thread plan the next batch (sa_batch_create is host work) while this one is on the GPU. */
 int sa_batch_start(sa_batch_t *b);

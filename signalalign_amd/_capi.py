@@ -11,6 +11,7 @@ _LIB = None
 
 FLAG_EXACT = 1
 FLAG_FORCE_GENERIC = 2
+FLAG_DEVICE_TO_ITSELF = 8
 
 
 class SaError(RuntimeError):
@@ -75,7 +76,7 @@ PAIR_DTYPE = np.dtype([("prob_e7", "<i8"), ("x", "<i4"), ("y", "<i4"), ("path", 
 
 EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alphabet", "sa_model_table5",
            "sa_model_set_to_hdp_expected_values", "sa_kmer_id", "sa_default_ambig", "sa_load_ambig",
-           "sa_batch_create", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_stats",
+           "sa_batch_create", "sa_batch_create_deferred", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_stats",
            "sa_batch_job_cells", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_plan_describe", "sa_plan_digest",
            "sa_plan_check_path_records", "sa_dplan_compare",
            "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_fasta_subsequence", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_device_memory", "sa_strerror",
@@ -123,6 +124,8 @@ def lib():
     L.sa_default_ambig.argtypes = [C.POINTER(C.c_char_p)]
     L.sa_load_ambig.argtypes = [C.c_char_p, C.POINTER(C.c_char_p)]
     L.sa_batch_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(Params), C.POINTER(Job), C.c_int64,
+                                  C.POINTER(C.c_char_p), C.c_int, C.c_uint]
+    L.sa_batch_create_deferred.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(Params), C.POINTER(Job), C.c_int64,
                                   C.POINTER(C.c_char_p), C.c_int, C.c_uint]
     L.sa_batch_run.argtypes = [C.c_void_p]
     L.sa_batch_n_pairs.argtypes = [C.c_void_p, C.c_int64, ip]
@@ -273,7 +276,9 @@ class JobArray:
 class Batch:
     """sa_batch_t: plan + HBM-resident inputs; run() launches the kernels."""
 
-    def __init__(self, model, params, jobs, ambig=None, device=0, flags=0):
+    def __init__(self, model, params, jobs, ambig=None, device=0, flags=0, deferred=False):
+        """deferred=True: sa_batch_create_deferred (the plan is collected on the batch's first use; the job arrays and the
+        ambiguity table are kept alive by this object)."""
         self._h = C.c_void_p()
         if isinstance(jobs, JobArray):
             self.n_jobs, arr, self._keep = jobs.n, jobs.arr, jobs
@@ -281,8 +286,9 @@ class Batch:
             self.n_jobs = len(jobs)
             arr, self._keep = _make_jobs(jobs)
         amb = ambig if ambig is not None else default_ambig()
-        _chk(lib().sa_batch_create(C.byref(self._h), model._h, C.byref(params), arr, self.n_jobs, amb, device, flags),
-             "sa_batch_create")
+        self._amb, self._model = amb, model
+        fn, name = (lib().sa_batch_create_deferred, "sa_batch_create_deferred") if deferred else (lib().sa_batch_create, "sa_batch_create")
+        _chk(fn(C.byref(self._h), model._h, C.byref(params), arr, self.n_jobs, amb, device, flags), name)
 
     def run(self):
         _chk(lib().sa_batch_run(self._h), "sa_batch_run")

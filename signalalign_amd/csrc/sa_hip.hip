@@ -949,7 +949,23 @@ struct sa_batch {
     int runner_rc;
     sa_batch_stats_t stats;
     hipEvent_t ev[8];
+    // Creation in two halves (sa_batch_create_deferred): what the second half needs.  `pending` is the device plan whose kernels
+    // are queued; the caller's arrays (c_jobs, c_ambig) are only touched again if that plan turns a read down and the host
+    // planner takes over -- which is why a deferred batch asks the caller to keep them until its first run has returned.
+    struct DPlanPending *pending;
+    const sa_model_t *c_m;
+    sa_params_t c_p;
+    const sa_job_t *c_jobs;
+    int64_t c_n;
+    const char *const *c_ambig;
+    long long c_budget;
+    double c_t0;
+    bool c_deferred;
+    bool finished;
+    int finish_rc;
+    std::mutex fin_mu;
 };
+static int batch_finish(sa_batch *b);
 
 static size_t g_sa_pool_idle_bytes(int device);
 int sa_device_count(void) {
@@ -1064,6 +1080,11 @@ struct SaUploader {
     }
 };
 static SaUploader g_uploader;
+// A second one for the second half of a batch's creation (batch_finish_body): with sa_batch_create_deferred that half runs on the
+// batch's runner thread while the caller's thread is inside the NEXT batch's first half, which holds g_uploader for as long as it
+// packs and uploads the reads (60 ms for a 10k-event slice) -- the batch that is ready to run would wait for it.
+static SaUploader g_uploader_tail;
+static thread_local SaUploader *tl_uploader = &g_uploader;   // the one upload() uses on this thread
 SaPool g_sa_pool;
 SaWorkers g_sa_workers;
 static size_t g_sa_pool_idle_bytes(int device) { return g_sa_pool.idle_bytes(SaPool::DEVICE, device); }
@@ -1167,18 +1188,21 @@ template <typename T>
 static int upload(T **dst, const T *src, long long n, long long pad = 0, bool src_pinned = false) {
     // pad: extra zeroed elements behind the data (kernels that clamp an index may read one element past the end)
     size_t bytes = sizeof(T) * (size_t) (n + pad > 0 ? n + pad : 1);
-    HIPCHK(g_sa_pool.get(SaPool::DEVICE, (void **) dst, bytes, g_uploader.device));
-    if (pad > 0) HIPCHK(hipMemsetAsync((char *) *dst + sizeof(T) * (size_t) n, 0, sizeof(T) * (size_t) pad, g_uploader.stream));
-    if (n > 0) return src_pinned ? g_uploader.copy_pinned(*dst, src, sizeof(T) * (size_t) n) : g_uploader.copy(*dst, src, sizeof(T) * (size_t) n);
+    SaUploader &U = *tl_uploader;
+    HIPCHK(g_sa_pool.get(SaPool::DEVICE, (void **) dst, bytes, U.device));
+    if (pad > 0) HIPCHK(hipMemsetAsync((char *) *dst + sizeof(T) * (size_t) n, 0, sizeof(T) * (size_t) pad, U.stream));
+    if (n > 0) return src_pinned ? U.copy_pinned(*dst, src, sizeof(T) * (size_t) n) : U.copy(*dst, src, sizeof(T) * (size_t) n);
     return SA_OK;
 }
 
-static std::atomic<int> g_batches_started(0);   // batches between sa_batch_start and sa_batch_wait (this process)
+static std::atomic<int> g_batches_started(0);
+static void dplan_release_fwd(sa_batch *b, struct DPlanPending *P);   // sa_dplan.inc (below)   // batches between sa_batch_start and sa_batch_wait (this process)
 
 void sa_batch_destroy(sa_batch_t *b) {
     if (!b) return;
     if (b->runner) { b->runner->join(); delete b->runner; b->runner = nullptr; g_batches_started.fetch_sub(1); }
     if (b->device >= 0) (void) hipSetDevice(b->device);
+    if (b->pending) { dplan_release_fwd(b, b->pending); b->pending = nullptr; }   // created, never used
     // the storage goes back to the caching allocators without the implicit synchronisation of hipFree: nothing of this
     // batch may still be in flight (only possible after an error inside a run)
     const bool trace_d = getenv("SA_TRACE") != nullptr;
@@ -1219,9 +1243,10 @@ void sa_batch_destroy(sa_batch_t *b) {
 }
 
 #include "sa_dplan.inc"
+static void dplan_release_fwd(sa_batch *b, DPlanPending *P) { dplan_release(b, P, true); }
 
-int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs, int64_t n_jobs,
-                    const char *const *ambig, int device, unsigned flags) {
+static int batch_create_impl(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs, int64_t n_jobs,
+                             const char *const *ambig, int device, unsigned flags, bool deferred) {
     if (!out || !m || !p) return SA_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -1239,7 +1264,9 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     HIPCHK(hipSetDevice(device));
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    if (trace_c) fprintf(stderr, "[trace] create: memory queried at %.1f ms\n", now_ms_c() - tc0);
     free_b += g_sa_pool.idle_bytes(SaPool::DEVICE, device);   // what destroyed batches left parked is available to this one
+    if (deferred && (flags & SA_FLAG_DEVICE_TO_ITSELF)) free_b += g_sa_pool.live_bytes(SaPool::DEVICE, device);   // ... and what the running ones hold
     // forward storage gets at most 60% of what is free; 24 B per cell-path
     long long budget = (long long) ((double) free_b * 0.60 / 24.0);
     const char *envb = getenv("SA_F_BUDGET_CELLPATHS");  // test hook: force several passes
@@ -1247,6 +1274,8 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
 
     sa_batch *b = new sa_batch();
     b->plan = nullptr;
+    b->pending = nullptr; b->finished = false; b->finish_rc = SA_OK; b->c_deferred = false;
+    b->c_m = m; b->c_p = *p; b->c_jobs = jobs; b->c_n = n_jobs; b->c_ambig = ambig; b->c_budget = budget; b->c_t0 = tc0;
     b->dev_planned = false;
     b->device = device;
     b->flags = flags;
@@ -1286,13 +1315,68 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     }
     for (int i = 0; i < 8; i++)
         if (g_handles.event(&b->ev[i], device) != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
-    // ---- the plan: on the device when the batch allows it (sa_dplan.inc), else on the host ----
-    sa_plan_t *pl = nullptr;
+    // ---- the plan: on the device when the batch allows it (sa_dplan.inc: its first half here), else on the host ----
     {
         std::unique_lock<std::mutex> dp_lock(g_uploader.mu);
         TRY(g_uploader.bind(device));
-        const int rcd = dplan_build(b, m, p, jobs, n_jobs, ambig, flags, budget);
+        const int rcd = dplan_front(b, m, p, jobs, n_jobs, ambig, flags, budget, &b->pending);
         if (rcd < 0) { dp_lock.unlock(); sa_batch_destroy(b); return rcd; }
+    }
+#undef TRY
+    b->c_deferred = deferred && b->pending != nullptr;
+    if (!b->c_deferred) {   // (a batch the device planner does not take is planned on the host right away)
+        const int rc = batch_finish(b);
+        if (rc) { sa_batch_destroy(b); return rc; }
+    }
+    *out = b;
+    return SA_OK;
+}
+
+int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs, int64_t n_jobs,
+                    const char *const *ambig, int device, unsigned flags) {
+    return batch_create_impl(out, m, p, jobs, n_jobs, ambig, device, flags, false);
+}
+int sa_batch_create_deferred(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs, int64_t n_jobs,
+                             const char *const *ambig, int device, unsigned flags) {
+    return batch_create_impl(out, m, p, jobs, n_jobs, ambig, device, flags, true);
+}
+
+// Second half of a batch's creation: the plan (the device planner's results, or the host planner), the remaining uploads, the
+// working buffers and the launch lists.  Runs once, on the batch's first use (run, statistics, accessors) or at the end of
+// sa_batch_create; a failure is remembered and returned to every later caller.
+static int batch_finish_body(sa_batch *b);
+static int batch_finish(sa_batch *b) {
+    std::lock_guard<std::mutex> g(b->fin_mu);
+    if (!b->finished) {
+        b->finish_rc = batch_finish_body(b);
+        b->finished = true;
+    }
+    return b->finish_rc;
+}
+static int batch_finish_body(sa_batch *b) {
+    const sa_model_t *m = b->c_m;
+    const sa_params_t *p = &b->c_p;
+    const sa_job_t *jobs = b->c_jobs;
+    const int64_t n_jobs = b->c_n;
+    const char *const *ambig = b->c_ambig;
+    const unsigned flags = b->flags;
+    const long long budget = b->c_budget;
+    const int device = b->device;
+    const bool trace_c = getenv("SA_TRACE") != nullptr;
+    auto now_ms_c = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double tc0 = b->c_t0;
+    HIPCHK(hipSetDevice(device));
+    // (only a deferred batch: with several batches in flight and creation in one piece the second upload stream measured
+    // 1.5-3 ms per step slower than one)
+    SaUploader *const UPT = b->c_deferred ? &g_uploader_tail : &g_uploader;
+    struct UseTail { SaUploader *prev; UseTail(SaUploader *u) : prev(tl_uploader) { tl_uploader = u; } ~UseTail() { tl_uploader = prev; } } use_tail_(UPT);
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+    sa_plan_t *pl = nullptr;
+    if (b->pending) {
+        DPlanPending *P = b->pending;
+        b->pending = nullptr;
+        const int rcd = dplan_back(b, P);
+        if (rcd < 0) return rcd;
         if (rcd == SA_OK) pl = b->plan;
     }
     if (!pl) {
@@ -1302,7 +1386,7 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
         if (SaPool::enabled() && batches_created.fetch_add(1) >= 2) sa_plan_use_allocator(plan_pinned_alloc, plan_pinned_free);
         int rc = sa_plan_build(&pl, m, p, jobs, n_jobs, ambig, flags | SA_FLAG_DEVICE_XC_INTERNAL, budget);
         sa_plan_use_allocator(nullptr, nullptr);
-        if (rc) { sa_batch_destroy(b); return rc; }
+        if (rc) return rc;
         if (trace_c) fprintf(stderr, "[trace] create: planned at %.1f ms\n", now_ms_c() - tc0);
         b->plan = pl;
     }
@@ -1334,8 +1418,8 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
         if (lim > 900) lim = 900;                   // 64 KB of dynamic LDS
         b->ring_cap = (int) (cap < lim ? cap : lim);
     }
-    std::unique_lock<std::mutex> up_lock(g_uploader.mu);
-    TRY(g_uploader.bind(device));
+    std::unique_lock<std::mutex> up_lock((*UPT).mu);
+    TRY((*UPT).bind(device));
     if (trace_c) fprintf(stderr, "[trace] create: upload ring ready at %.1f ms\n", now_ms_c() - tc0);
     const bool big_pinned = pl->pooled && pl->big_free == plan_pinned_free;   // the big arrays are pinned: no staging
     if (!b->dev_planned) {
@@ -1411,16 +1495,15 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     {   // emission constants, on the device (same stream as the uploads they read)
         if (g_sa_pool.get(SaPool::DEVICE, (void **) &b->d_xc, sizeof(double) * 4 * (size_t) (pl->n_pid > 0 ? pl->n_pid : 1), device) !=
             hipSuccess) {
-            sa_batch_destroy(b);
             return SA_ENOMEM;
         }
         if (pl->n_regions > 0)
-            hipLaunchKernelGGL(k_fill_xc, dim3((unsigned) pl->n_regions), dim3(256), 0, g_uploader.stream, b->d_regions, b->d_poff,
+            hipLaunchKernelGGL(k_fill_xc, dim3((unsigned) pl->n_regions), dim3(256), 0, (*UPT).stream, b->d_regions, b->d_poff,
                                b->d_pid, b->d_tab6, m->hdp ? b->d_hdp_slot : (const int *) nullptr,
                                m->hdp ? (long long) m->hdp->grid_length : 0ll, reinterpret_cast<double4 *>(b->d_xc));
-        if (hipGetLastError() != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
+        if (hipGetLastError() != hipSuccess) return SA_ENODEVICE;
     }
-    TRY(g_uploader.drain());
+    TRY((*UPT).drain());
     up_lock.unlock();
     if (trace_c) fprintf(stderr, "[trace] create: inputs uploaded at %.1f ms\n", now_ms_c() - tc0);
     // working buffers
@@ -1588,13 +1671,12 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
         b->gev.resize(4 * b->groups.size(), nullptr);
         b->cev.resize(2 * b->chunks.size(), nullptr);
         for (auto &e : b->gev)
-            if (g_handles.event(&e, device) != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
+            if (g_handles.event(&e, device) != hipSuccess) return SA_ENODEVICE;
         for (auto &e : b->cev)
-            if (g_handles.event(&e, device) != hipSuccess) { sa_batch_destroy(b); return SA_ENODEVICE; }
+            if (g_handles.event(&e, device) != hipSuccess) return SA_ENODEVICE;
         if (g_sa_pool.get(SaPool::PINNED, (void **) &b->h_seg_off, 8 * (size_t) (pl->n_segs + (long long) b->groups.size() + 1),
                           device) != hipSuccess ||
             g_sa_pool.get(SaPool::PINNED, (void **) &b->h_overflow, 64, device) != hipSuccess) {
-            sa_batch_destroy(b);
             return SA_ENOMEM;
         }
         if (!host_finalize) {
@@ -1603,10 +1685,10 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
         }
     }
     {   // the launch lists (small)
-        std::lock_guard<std::mutex> g_(g_uploader.mu);
-        TRY(g_uploader.bind(device));
+        std::lock_guard<std::mutex> g_((*UPT).mu);
+        TRY((*UPT).bind(device));
         TRY(upload(&b->d_ids, b->ids_flat.data(), (long long) b->ids_flat.size()));
-        TRY(g_uploader.drain());
+        TRY((*UPT).drain());
     }
     if (trace_c) fprintf(stderr, "[trace] create: buffers allocated at %.1f ms\n", now_ms_c() - tc0);
     b->stats.cells_forward = pl->cells_fwd;
@@ -1625,7 +1707,6 @@ int sa_batch_create(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p,
     b->stats.f_bytes = fb;
 #undef TRY
     if (trace_c) fprintf(stderr, "[trace] create: done at %.1f ms\n", now_ms_c() - tc0);
-    *out = b;
     return SA_OK;
 }
 
@@ -1895,6 +1976,7 @@ static int run_passes(sa_batch_t *b) {
 static int batch_run_body(sa_batch_t *b);
 int sa_batch_run(sa_batch_t *b) {
     if (!b) return SA_EINVAL;
+    { const int rcf = batch_finish(b); if (rcf) return rcf; }   // (a deferred batch: the second half of its creation)
     b->quiet = false;
     const int rc = batch_run_body(b);
     b->quiet = rc == SA_OK;
@@ -2094,13 +2176,13 @@ int sa_batch_wait(sa_batch_t *b) {
 }
 
 int sa_batch_n_pairs(const sa_batch_t *b, int64_t job, int64_t *n) {
-    if (!b || !n || job < 0 || job >= b->plan->n_jobs) return SA_EINVAL;
+    if (!b || !n || job < 0 || job >= b->c_n) return SA_EINVAL;
     if (!b->ran) return SA_ESTATE;
     *n = b->job_off[job + 1] - b->job_off[job];
     return SA_OK;
 }
 int sa_batch_pairs(const sa_batch_t *b, int64_t job, sa_pair_t *out, int64_t cap) {
-    if (!b || job < 0 || job >= b->plan->n_jobs) return SA_EINVAL;
+    if (!b || job < 0 || job >= b->c_n) return SA_EINVAL;
     if (!b->ran) return SA_ESTATE;
     long long n = b->job_off[job + 1] - b->job_off[job];
     if (n > cap) return SA_EINVAL;
@@ -2109,11 +2191,13 @@ int sa_batch_pairs(const sa_batch_t *b, int64_t job, sa_pair_t *out, int64_t cap
 }
 int sa_batch_stats(const sa_batch_t *b, sa_batch_stats_t *out) {
     if (!b || !out) return SA_EINVAL;
+    { const int rcf = batch_finish(const_cast<sa_batch_t *>(b)); if (rcf) return rcf; }
     *out = b->stats;
     return SA_OK;
 }
 int sa_batch_job_cells(const sa_batch_t *b, int64_t job, double *cf, double *cb) {
-    if (!b || job < 0 || job >= b->plan->n_jobs) return SA_EINVAL;
+    if (!b || job < 0 || job >= b->c_n) return SA_EINVAL;
+    { const int rcf = batch_finish(const_cast<sa_batch_t *>(b)); if (rcf) return rcf; }
     if (cf) *cf = b->plan->jobs[job].cells_fwd;
     if (cb) *cb = b->plan->jobs[job].cells_bwd;
     return SA_OK;

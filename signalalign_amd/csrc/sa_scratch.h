@@ -178,6 +178,12 @@ struct SaPool {
         for (const Blk &b : idle[kind]) n += b.dev == dev ? b.bytes : 0;
         return n;
     }
+    size_t live_bytes(int kind, int dev) {   // handed out and not yet returned
+        std::lock_guard<std::mutex> g(mu);
+        size_t n = 0;
+        for (const auto &kv : live[kind]) n += kv.second.dev == dev ? kv.second.bytes : 0;
+        return n;
+    }
     void release(int kind) {
         std::vector<Blk> v;
         {

@@ -183,6 +183,52 @@ def test_threshold_zero_and_one(oracle):
         assert np.array_equal(got[0]["prob_e7"], exp["prob_e7"])
 
 
+def test_deferred_creation_same_bytes(oracle):
+    """sa_batch_create_deferred: the first half of the creation on the caller's thread, the second on the batch's first use
+    (run, the thread of start, stats).  Same pairs, byte for byte, as sa_batch_create; two deferred batches alive at once with
+    the second one created while the first runs (the bench's loop for workloads that fill the device); a batch that is created
+    and never used goes away cleanly; a batch the planning kernels do not take (SA_FLAG_EXACT) is created completely at once;
+    a read no planner takes (an anchor outside the matrix) is an error in both modes."""
+    pm, om = _models(oracle, cases.MODEL_6MER)
+    p = sa.default_params()
+    jobs = cases.synthetic_jobs(cases.MODEL_6MER, 5, 900, 300) + cases.realistic_anchor_jobs(cases.MODEL_6MER, 3, 2500, 600)
+    more = cases.synthetic_jobs(cases.MODEL_6MER, 4, 1100, 311)
+    got, st = _run(pm, p, jobs)
+    got2, _ = _run(pm, p, more)
+    a = sa.Batch(pm, p, jobs, deferred=True, flags=sa.FLAG_DEVICE_TO_ITSELF)
+    a.start()
+    b = sa.Batch(pm, p, more, deferred=True, flags=sa.FLAG_DEVICE_TO_ITSELF)     # first half while `a` runs
+    a.wait()
+    sta = a.stats()
+    assert (sta.cells_forward, sta.cells_backward, sta.n_regions, sta.n_strip_regions) == \
+           (st.cells_forward, st.cells_backward, st.n_regions, st.n_strip_regions)
+    for j in range(len(jobs)):
+        assert np.array_equal(a.pairs(j), got[j]), j
+    a.close()
+    assert b.stats().n_regions == len(more)          # statistics before the run: the second half runs here
+    b.run()
+    for j in range(len(more)):
+        assert np.array_equal(b.pairs(j), got2[j]), j
+    b.close()
+    sa.Batch(pm, p, jobs, deferred=True).close()      # created, never used
+    e = sa.Batch(pm, p, more, deferred=True, flags=sa.FLAG_EXACT)   # not a batch for the planning kernels: complete at once
+    e.run()
+    exact, _ = _run(pm, p, more, flags=sa.FLAG_EXACT)
+    for j in range(len(more)):
+        assert np.array_equal(e.pairs(j), exact[j]), j
+    e.close()
+    bad = dict(more[1])
+    bad["ax"] = np.array(list(bad["ax"][:-1]) + [len(bad["ref"]) + 5], dtype=np.int64)   # last anchor beyond the reference
+    for deferred in (False, True):
+        try:
+            c = sa.Batch(pm, p, [more[0], bad], deferred=deferred)
+            c.run()
+            raised = None
+        except sa.SaError as err:
+            raised = err.code
+        assert raised is not None and raised != 0, deferred
+
+
 def test_threshold_zero_default_flags(oracle):
     """Threshold 0 keeps every band cell: with default flags the batch is routed to the reference-ordered kernels (the
     default kernels' candidate filter has no lower bound at log 0) and must list exactly the oracle's rows -- dense anchors
