@@ -467,10 +467,13 @@ def main():
                           % (s, (t_b - t_a) * 1e3, (t_c - t_b) * 1e3, (time.perf_counter() - t_c) * 1e3, stc.ms_total_device),
                           file=sys.stderr)
             return
+        dbg = os.environ.get("SA_BENCH_DEBUG")
         for s in range(n_steps):
+            t_a = time.perf_counter()
             cur = sa.Batch(pm, params, arrays[(first + s) % n_sets], ambig=ambig, device=device)
             stc = cur.stats()
             cells_done[0] += stc.cells_forward + stc.cells_backward
+            t_b = time.perf_counter()
             cur.start()
             flying.append(cur)
             if len(flying) >= depth:
@@ -478,6 +481,11 @@ def main():
                 old.wait()
                 old.n_pairs(0)
                 old.close()
+            if dbg:
+                thr = open("/sys/fs/cgroup/cpu.stat").read().split() if os.path.exists("/sys/fs/cgroup/cpu.stat") else []
+                nthr = thr[thr.index("nr_throttled") + 1] if "nr_throttled" in thr else "?"
+                print("[bench] step %d: create %.1f ms, step %.1f ms, cgroup nr_throttled %s"
+                      % (s, (t_b - t_a) * 1e3, (time.perf_counter() - t_a) * 1e3, nthr), file=sys.stderr)
         for old in flying:
             old.wait()
             old.n_pairs(0)

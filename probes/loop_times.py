@@ -25,7 +25,14 @@ sets = [[synth.make_read(i + q * 2000, 5000, alpha, k, tab) for i in range(2000)
 arrays = [sa.JobArray(js) for js in sets]
 depth = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+def throttled():
+    try:
+        d = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+        return int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0)), int(d.get("usage_usec", 0))
+    except OSError:
+        return 0, 0, 0
 flying = []
+thr_prev = throttled()
 T = {"create": [], "start": [], "wait": [], "collect": []}
 t_begin = None
 for s in range(steps):
@@ -45,6 +52,11 @@ for s in range(steps):
         old.close()
         e = time.perf_counter()
         if s >= 8: T.setdefault("n_pairs", []).append(d2 - d)
+    thr = throttled()
+    if thr[0] != thr_prev[0]:
+        print("step %d: cgroup throttled %d time(s), %.1f ms; the step took %.1f ms (create %.1f, wait %.1f)"
+              % (s, thr[0] - thr_prev[0], (thr[1] - thr_prev[1]) / 1e3, (e - a) * 1e3, (b - a) * 1e3, (d - c) * 1e3))
+    thr_prev = thr
     if s >= 8:
         T["create"].append(b - a); T["start"].append(c - b); T["wait"].append(d - c); T["collect"].append(e - d)
 t_loop = time.perf_counter()
