@@ -139,10 +139,25 @@ struct SaPool {
                 return hipSuccess;
             }
         }
+        // A pinned miss is expensive (hipHostMalloc: 0.25 ms per MB -- 100 ms for a batch's pair buffer) and stalls every thread of
+        // the process that enters the HIP runtime meanwhile; a device miss is cheap by comparison (hipMalloc of 1.4 GB: < 0.1 ms
+        // measured).  Consecutive batches of a stream ask for sizes within a few per cent of each other, sometimes on either side
+        // of a size class: a new pinned block gets a sixteenth of headroom so that it also serves the neighbours' requests.
+        const size_t want = bytes;
+        if (enabled() && kind == PINNED && bytes >= ((size_t) 1 << 20)) bytes = round_up(bytes + bytes / 16);
+        static const bool trace_pool = getenv("SA_TRACE") != nullptr;
+        timespec ts0, ts1;
+        if (trace_pool) clock_gettime(CLOCK_MONOTONIC, &ts0);
         hipError_t e = raw_alloc(kind, out, bytes);
+        if (trace_pool) {
+            clock_gettime(CLOCK_MONOTONIC, &ts1);
+            fprintf(stderr, "[trace] pool: new %s block of %.1f MB (asked %.1f MB): %.1f ms\n", kind == DEVICE ? "device" : "pinned",
+                    bytes / 1048576.0, want / 1048576.0, (ts1.tv_sec - ts0.tv_sec) * 1e3 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-6);
+        }
         if (e != hipSuccess && enabled()) {   // out of memory with blocks parked in the cache: give them back and retry
             (void) hipGetLastError();
             release(kind);
+            bytes = want;
             e = raw_alloc(kind, out, bytes);
         }
         if (e == hipSuccess && enabled()) {
