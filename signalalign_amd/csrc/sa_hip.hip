@@ -1706,6 +1706,17 @@ static int batch_finish_body(sa_batch *b) {
     for (long long r = 0; r < pl->n_regions; r++) fb += 24.0 * (double) pl->regions[r].f_cellpaths;
     b->stats.f_bytes = fb;
 #undef TRY
+    // The pinned result buffer, from an estimate of the result size (measured: 0.9 pairs per event at the default threshold): taken
+    // here and not at the start of the run, so that a stream of batches asks the pinned cache for its blocks in the same order in
+    // every step.  Taken by the runner thread, the third buffer of a three-deep pipeline was first needed whenever three runs
+    // happened to overlap -- sometimes during the caller's warm-up, sometimes in the middle of its timed loop: a 100 ms
+    // hipHostMalloc that also held up every other thread's HIP calls (12.5 against 16-19 ms per step, run to run).
+    if (!(flags & SA_FLAG_EXACT) && !b->expect && b->h_pairs_cap == 0 && pl->params.threshold >= 0.005) {
+        const long long total = (long long) (1.5 * (double) pl->n_ev) + 4096;
+        const long long cap = total + total / 8 + 1024;
+        if (g_sa_pool.get(SaPool::PINNED, (void **) &b->h_pairs, sizeof(sa_pair_t) * (size_t) cap, device) == hipSuccess) b->h_pairs_cap = cap;
+        else { (void) hipGetLastError(); b->h_pairs = nullptr; }   // (the run asks again)
+    }
     if (trace_c) fprintf(stderr, "[trace] create: done at %.1f ms\n", now_ms_c() - tc0);
     return SA_OK;
 }

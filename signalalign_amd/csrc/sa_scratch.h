@@ -153,6 +153,14 @@ struct SaPool {
             clock_gettime(CLOCK_MONOTONIC, &ts1);
             fprintf(stderr, "[trace] pool: new %s block of %.1f MB (asked %.1f MB): %.1f ms\n", kind == DEVICE ? "device" : "pinned",
                     bytes / 1048576.0, want / 1048576.0, (ts1.tv_sec - ts0.tv_sec) * 1e3 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-6);
+            if (kind == PINNED && bytes > ((size_t) 64 << 20)) {
+                std::lock_guard<std::mutex> g(mu);
+                fprintf(stderr, "[trace] pool: pinned idle (MB):");
+                for (const Blk &q : idle[kind]) if (q.bytes > ((size_t) 16 << 20)) fprintf(stderr, " %.0f", q.bytes / 1048576.0);
+                fprintf(stderr, " | live (MB):");
+                for (const auto &kv : live[kind]) if (kv.second.bytes > ((size_t) 16 << 20)) fprintf(stderr, " %.0f", kv.second.bytes / 1048576.0);
+                fprintf(stderr, "\n");
+            }
         }
         if (e != hipSuccess && enabled()) {   // out of memory with blocks parked in the cache: give them back and retry
             (void) hipGetLastError();
