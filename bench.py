@@ -259,6 +259,10 @@ def self_launch(n):
 
 
 def main():
+    # A streaming caller keeps three batches in flight, each with two compute streams, a copy stream and the upload stream: more
+    # hardware queues than the runtime's default of four keep one batch's short kernels from queueing behind another's long
+    # sweeps (12.7-12.9 against 12.6-13.9 ms per step; must be set before the first HIP call; ranks inherit it)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
