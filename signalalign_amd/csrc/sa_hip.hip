@@ -961,6 +961,7 @@ struct sa_batch {
     long long c_budget;
     double c_t0;
     bool c_deferred;
+    char *held_stage;      // (deferred batches: see dplan_back)
     bool finished;
     int finish_rc;
     std::mutex fin_mu;
@@ -1233,6 +1234,7 @@ void sa_batch_destroy(sa_batch_t *b) {
         g_handles.park(b->xstream[i], b->device, 0);
     g_handles.park(b->pair_stream, b->device, 1);
     g_sa_pool.put(SaPool::PINNED, b->h_pairs);
+    g_sa_pool.put(SaPool::PINNED, b->held_stage);
     g_sa_pool.put(SaPool::DEVICE, b->d_pairs_up);
     g_sa_pool.put(SaPool::PINNED, b->h_seg_off);
     g_sa_pool.put(SaPool::PINNED, b->h_overflow);
@@ -1274,7 +1276,7 @@ static int batch_create_impl(sa_batch_t **out, const sa_model_t *m, const sa_par
 
     sa_batch *b = new sa_batch();
     b->plan = nullptr;
-    b->pending = nullptr; b->finished = false; b->finish_rc = SA_OK; b->c_deferred = false;
+    b->pending = nullptr; b->finished = false; b->finish_rc = SA_OK; b->c_deferred = false; b->held_stage = nullptr;
     b->c_m = m; b->c_p = *p; b->c_jobs = jobs; b->c_n = n_jobs; b->c_ambig = ambig; b->c_budget = budget; b->c_t0 = tc0;
     b->dev_planned = false;
     b->device = device;
