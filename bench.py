@@ -279,15 +279,19 @@ def main():
                          "CpG cytosine ambiguous C/E); hdp = configs[3] (HDP emissions); realistic = configs[1] reads with "
                          "the sparse anchors of a real guide alignment; event_align, mea = the steps either side of the "
                          "pair-HMM.")
+    ap.add_argument("--threshold", type=float, default=None, help="posterior threshold (default 0.01; hdp: 0.1, what the "
+                                                                  "reference's own HDP test uses, tests/stateMachineTests.c:912)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernels-only", action="store_true", help="phase 1 only (sa_batch_run on one resident batch): for "
                                                                 "profiler runs that count per-kernel launches")
     ap.add_argument("--cpu-reads-per-thread", type=int, default=30)
     args = ap.parse_args()
     if args.reads is None:
-        args.reads = 12500 if args.workload == "scaling" else 2000
+        args.reads = {"scaling": 12500, "hdp": 5000}.get(args.workload, 2000)   # hdp: BASELINE configs[3] names 5000 reads
     if args.events is None:
         args.events = 10000 if args.workload == "scaling" else 5000
+    if args.threshold is None:
+        args.threshold = 0.1 if args.workload == "hdp" else 0.01
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not under a launcher: become one (nothing in this process has touched or will touch the GPU)
         sys.exit(self_launch(args.gpus))
@@ -343,11 +347,19 @@ def main():
     pm = sa.Model.load(model_path, nhdp)
     if nhdp:
         pm.set_to_hdp_expected_values()
-    params = sa.default_params(threshold=0.01, expansion=50, trace_back=100)
+    params = sa.default_params(threshold=args.threshold, expansion=50, trace_back=100)
+    make_one = lambda i: synth.make_read(int(i), args.events, alpha, k, tab, **read_kw)
+    if nhdp:
+        # events drawn from the densities the aligner itself uses, over windows of the sequence the bundled .nhdp was trained
+        # on (synth.make_read_hdp); the table's level means (after set_to_hdp_expected_values) enter the event normalisation
+        sampler = synth.HdpSampler(synth.parse_nhdp(nhdp))
+        pool = open(os.path.join(ROOT, "tests", "golden", "npReads", "ZymoRef.txt")).read().split()[0].strip()
+        t5 = np.array(pm.table5())
+        make_one = lambda i: synth.make_read_hdp(int(i), args.events, alpha, k, t5, sampler, pool)
     # reads are independent: the global read list is dealt to the ranks (no collective on the data path)
     from signalalign_amd import shard
     mine = shard.shard_indices([args.events] * (world * args.reads), rank, world)
-    jobs = [synth.make_read(int(i), args.events, alpha, k, tab, **read_kw) for i in mine]
+    jobs = [make_one(i) for i in mine]
     def thin_like_a_guide_alignment(job_list, indices):
         # the anchors a real guide alignment leaves: the run structure of the reference's own example cigar (an indel every
         # 10-50 bases), 14 bases trimmed off both ends of every match run as signalMachine -m 14 does
@@ -372,11 +384,11 @@ def main():
         wl_name = ("BASELINE configs[1] reads with the anchor density of a real guide alignment "
                    "(tests/golden/cigars/ecoli_minus_strand.cigar, -m 14: a sixth of the bases)")
     # ---- read sets: every timed step aligns reads the library has not seen in the step before ----
-    n_sets = 2 if args.workload == "scaling" else 3
+    n_sets = 2 if args.workload == "scaling" or args.reads > 4000 else 3
     sets = [jobs]
     for q in range(1, n_sets):
         more = shard.shard_indices([args.events] * (world * args.reads), rank, world)
-        extra = [synth.make_read(int(i) + q * world * args.reads, args.events, alpha, k, tab, **read_kw) for i in more]
+        extra = [make_one(int(i) + q * world * args.reads) for i in more]
         if args.workload == "realistic":
             thin_like_a_guide_alignment(extra, [int(i) + q * world * args.reads for i in more])
         sets.append(extra)
@@ -577,12 +589,12 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%s, %d synthetic %d-event reads per GPU, band=50, threshold 0.01, traceBackDiagonals 100"
-                            % (wl_name, args.reads, args.events),
+                "workload": "%s, %d synthetic %d-event reads per GPU, band=50, threshold %g, traceBackDiagonals 100"
+                            % (wl_name, args.reads, args.events, args.threshold),
                 "reads_per_gpu": args.reads, "events_per_read": args.events,
                 "events_per_s": events_all / dt,
                 "cells_per_event": cells / max(n_events_total, 1),
-                "pairs_rank0": n_pairs,
+                "pairs_rank0": n_pairs, "pairs_per_event": n_pairs / max(n_events_total, 1),
                 "regions_on_register_kernels": "%d/%d" % (st0.n_fast_regions, st0.n_regions),
                 "regions_on_ring_kernels": "%d/%d" % (st0.n_ring_regions - st0.n_strip_regions, st0.n_regions),
                 "regions_on_strip_kernels": "%d/%d" % (st0.n_strip_regions, st0.n_regions),

@@ -41,7 +41,11 @@ extern "C" {
 #define SA_FLAG_RNA 4u            /* event alignment only: k-mers as build_kmer_list(..., rna=true) makes them (U -> T, reversed) */
 #define SA_FLAG_DEVICE_TO_ITSELF 8u /* sa_batch_create_deferred only: every other batch on this device will have been destroyed
                                      before this one's first use -- its forward storage is sized for the memory they hold too
-                                     (one batch at a time, the next one packed and planned while the current one runs) */
+                                     (one batch at a time, the next one packed and planned while the current one runs).
+                                     The promise is the caller's: if other batches still hold their storage at that first use
+                                     (sa_batch_run / sa_batch_start, but also sa_batch_stats and sa_batch_job_cells, which
+                                     complete the creation too), the working buffers may not fit and that call returns
+                                     SA_ENOMEM; the batch can then only be destroyed */
 
 typedef struct sa_model sa_model_t; /* replaces StateMachine3 / StateMachine3_HDP (inc/stateMachine.h:150-190) */
 typedef struct sa_batch sa_batch_t;
@@ -240,8 +244,15 @@ int sa_fasta_subsequence(const char *fasta_path, const char *name, int64_t start
 
 /* Batches take their device and pinned-host storage from a caching allocator: what a destroyed batch held is kept and
  * handed to the next one (a pipeline that sees every read once creates and destroys a batch per few thousand reads;
- * allocation and release of its 25 GB cost more than its kernels).  sa_pool_release() returns everything that is
- * parked; SA_POOL=0 in the environment disables the cache, SA_POOL_LIMIT_GB bounds it (default 96 device / 8 pinned). */
+ * allocation and release of its 25 GB cost more than its kernels).  What may stay PARKED between batches is bounded:
+ * by default 90 % of the device's memory and 32 GB of pinned host memory (parked device blocks are handed back to the
+ * runtime whenever an allocation of the process fails, so the cache never causes an out-of-memory by itself).
+ * An embedding caller that shares the device or the host with other code sets its own bounds:
+ *   sa_pool_configure(device_limit_bytes, pinned_limit_bytes)   a negative value leaves that bound as it is; 0 keeps nothing
+ *       parked; blocks above a lowered bound are freed at once.  Wins over the environment.
+ *   sa_pool_release()                                           returns everything that is parked right now.
+ * Environment (read when no limit was configured): SA_POOL=0 disables the cache, SA_POOL_LIMIT_GB bounds both kinds. */
+int sa_pool_configure(int64_t device_limit_bytes, int64_t pinned_limit_bytes);
 void sa_pool_release(void);
 
 /* ---- maximum-expected-accuracy path over a read's posteriors ----------------------------------

@@ -15,8 +15,15 @@
  *   tests/stateMachineTests.c:441-565          test_sm3_diagonalDPCalculations (14 pairs, set, totals)
  *   tests/stateMachineTests.c:567-698          test_sm3_5merDiagonalDPCalculations (7 pairs)
  *   tests/nanoporeHdpTests.c:102-108           test_kmer_id
- * The whole-read pair-count tests (1076 / 3441 / 12784 ...) need lastz anchors and reference blobs
- * that are missing from the tree; they are NOT reproduced.
+ * and by its whole-read known answers on ZymoC_ch_1_file1.npRead x ZymoRef.txt (tests/stateMachineTests.c:842-983), with
+ * the anchors of the reference's own lastz (built from the vendored sources by oracle/build_lastz.sh; only its cigar output
+ * is committed, tests/golden/cigars/zymoC_lastz_anchors.json):
+ *   :855-868  un-banded, scaled R7.3 model                      1076 pairs
+ *   :851-852  banded, scaled and descaled model                 1076 / 1076
+ *   :920-970  every C read as C / E / O, and as the code L      1076 x 3 / 7349
+ *   :902-918  HDP emissions at threshold 0.1                    1217
+ * Still unpinned: the 3441 / 12784 / 13606 / 3420 counts (their E. coli reference blobs are missing from the tree,
+ * .MISSING_LARGE_BLOBS) and the event-alignment function (its reference tests read fast5 files).  See DESIGN.md section 2.
  *
  * Layout of a DP row (one anti-diagonal xay = x + y): cells in ascending xmy = x - y, two apart;
  * cell i sits at x = (xay + xmyL + 2i)/2; a cell holds P(x) paths (k-mer variants of ambiguous

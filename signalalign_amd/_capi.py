@@ -79,7 +79,7 @@ EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alp
            "sa_batch_create", "sa_batch_create_deferred", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_stats",
            "sa_batch_job_cells", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_plan_describe", "sa_plan_digest",
            "sa_plan_check_path_records", "sa_dplan_compare",
-           "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_fasta_subsequence", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_device_memory", "sa_strerror",
+           "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_pool_configure", "sa_fasta_subsequence", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_device_memory", "sa_strerror",
            "sa_version", "sa_free"]
 
 
@@ -128,6 +128,11 @@ def lib():
     L.sa_batch_create_deferred.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(Params), C.POINTER(Job), C.c_int64,
                                   C.POINTER(C.c_char_p), C.c_int, C.c_uint]
     L.sa_batch_run.argtypes = [C.c_void_p]
+    L.sa_plan_check_path_records.restype = C.c_int64
+    L.sa_plan_check_path_records.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Job), C.POINTER(C.c_char_p), ip]
+    L.sa_dplan_compare.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Job), C.c_int64, C.POINTER(C.c_char_p), C.c_int,
+                                   C.c_uint]
+    L.sa_pool_configure.argtypes = [C.c_int64, C.c_int64]
     L.sa_batch_n_pairs.argtypes = [C.c_void_p, C.c_int64, ip]
     L.sa_batch_pairs.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
     L.sa_batch_stats.argtypes = [C.c_void_p, C.POINTER(BatchStats)]
@@ -548,9 +553,7 @@ def plan_check_path_records(model, params, job, ambig=None):
     arr, keep = _make_jobs([job])
     amb = ambig if ambig is not None else default_ambig()
     n = C.c_int64(0)
-    L = lib()
-    L.sa_plan_check_path_records.restype = C.c_int64
-    bad = L.sa_plan_check_path_records(model._h, C.byref(params), arr, amb, C.byref(n))
+    bad = lib().sa_plan_check_path_records(model._h, C.byref(params), arr, amb, C.byref(n))
     if bad < 0:
         _chk(int(bad), "sa_plan_check_path_records")
     return int(bad), int(n.value)
@@ -565,6 +568,11 @@ def dplan_compare(model, params, jobs, ambig=None, device=0, flags=0):
     if rc < 0:
         _chk(rc, "sa_dplan_compare")
     return rc
+
+
+def pool_configure(device_limit_bytes=-1, pinned_limit_bytes=-1):
+    """Bounds of what the caching allocators may keep parked between batches (sa_pool_configure); -1 leaves a bound as it is."""
+    _chk(lib().sa_pool_configure(int(device_limit_bytes), int(pinned_limit_bytes)), "sa_pool_configure")
 
 
 def device_memory(device=0):

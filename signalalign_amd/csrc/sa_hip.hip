@@ -66,6 +66,7 @@ struct DevPlan {
     const sa_seg_t *segs;
     const sa_ck_t *cks;
     double *F;
+    double *E;        // HDP models: emission plane of the register-kernel regions (k_emit_hdp), max_chunk_cellpaths doubles
     double *vbuf;
     sa_cand_t *cands;
     int *cand_count;
@@ -906,7 +907,7 @@ struct sa_batch {
     sa_region_t *d_regions; sa_row_t *d_rows; int *d_pk; int *d_poff; int *d_pid; int *d_px; double *d_xc; double *d_ev;
     sa_prec_t *d_prec;
     sa_seg_t *d_segs; sa_ck_t *d_cks;
-    double *d_F; double *d_vbuf; sa_cand_t *d_cands; int *d_cand_count; int *d_overflow; double *d_totals;
+    double *d_F; double *d_E; double *d_vbuf; sa_cand_t *d_cands; int *d_cand_count; int *d_overflow; double *d_totals;
     double *d_bscratch;
     double *d_gsum, *d_gmc;  // expectation mode only
     bool expect;
@@ -994,7 +995,7 @@ static DevPlan make_devplan(const sa_batch *b) {
     memset(&P, 0, sizeof(P));
     P.regions = b->d_regions; P.rows = b->d_rows; P.pk = b->d_pk; P.poff = b->d_poff; P.pid = b->d_pid; P.px = b->d_px; P.xc = b->d_xc; P.ev = b->d_ev;
     P.prec = b->d_prec;
-    P.segs = b->d_segs; P.cks = b->d_cks; P.F = b->d_F; P.vbuf = b->d_vbuf; P.cands = b->d_cands;
+    P.segs = b->d_segs; P.cks = b->d_cks; P.F = b->d_F; P.E = b->d_E; P.vbuf = b->d_vbuf; P.cands = b->d_cands;
     P.cand_count = b->d_cand_count; P.overflow = b->h_overflow; P.totals = b->d_totals; P.bscratch = b->d_bscratch;
     P.gsum = b->d_gsum; P.gmc = b->d_gmc;
     P.m.t_mm = m->t_mm; P.m.t_mx = m->t_mx; P.m.t_my = m->t_my; P.m.t_xm = m->t_xm; P.m.t_xx = m->t_xx;
@@ -1178,6 +1179,14 @@ static void *plan_pinned_alloc(size_t bytes) {
 }
 static void plan_pinned_free(void *p, size_t bytes) { (void) bytes; g_sa_pool.put(SaPool::PINNED, p); }
 
+extern "C" int sa_pool_configure(int64_t device_limit_bytes, int64_t pinned_limit_bytes) {
+    if (device_limit_bytes >= 0) SaPool::configured(SaPool::DEVICE).store((long long) device_limit_bytes);
+    if (pinned_limit_bytes >= 0) SaPool::configured(SaPool::PINNED).store((long long) pinned_limit_bytes);
+    g_sa_pool.trim(SaPool::DEVICE);
+    g_sa_pool.trim(SaPool::PINNED);
+    return SA_OK;
+}
+
 extern "C" void sa_pool_release(void) {
     g_sa_pool.release(SaPool::DEVICE);
     g_sa_pool.release(SaPool::PINNED);
@@ -1218,7 +1227,7 @@ void sa_batch_destroy(sa_batch_t *b) {
         if (b->pair_stream) (void) hipStreamSynchronize(b->pair_stream);
     }
     const double td1 = now_ms_d();
-    void *ptrs[] = {b->d_regions, b->d_rows, b->d_pk, b->d_poff, b->d_pid, b->d_px, b->d_xc, b->d_prec, b->d_ev, b->d_segs, b->d_cks, b->d_F,
+    void *ptrs[] = {b->d_regions, b->d_rows, b->d_pk, b->d_poff, b->d_pid, b->d_px, b->d_xc, b->d_prec, b->d_ev, b->d_segs, b->d_cks, b->d_F, b->d_E,
                     b->d_vbuf, b->d_cands, b->d_cand_count, b->d_overflow, b->d_totals, b->d_bscratch, b->d_tab6,
                     b->d_hdp_slot, b->d_hdp_y, b->d_hdp_slope, b->d_hdp_grid, b->d_hdp_tab, b->d_prob, b->d_seg_pass, b->d_seg_off,
                     b->d_out, b->d_ids, b->d_gsum, b->d_gmc, b->d_seam, b->d_ckxy};
@@ -1269,8 +1278,8 @@ static int batch_create_impl(sa_batch_t **out, const sa_model_t *m, const sa_par
     if (trace_c) fprintf(stderr, "[trace] create: memory queried at %.1f ms\n", now_ms_c() - tc0);
     free_b += g_sa_pool.idle_bytes(SaPool::DEVICE, device);   // what destroyed batches left parked is available to this one
     if (deferred && (flags & SA_FLAG_DEVICE_TO_ITSELF)) free_b += g_sa_pool.live_bytes(SaPool::DEVICE, device);   // ... and what the running ones hold
-    // forward storage gets at most 60% of what is free; 24 B per cell-path
-    long long budget = (long long) ((double) free_b * 0.60 / 24.0);
+    // forward storage gets at most 60% of what is free; 24 B per cell-path (HDP models: 8 B more, the emission plane)
+    long long budget = (long long) ((double) free_b * 0.60 / (m->hdp ? 32.0 : 24.0));
     const char *envb = getenv("SA_F_BUDGET_CELLPATHS");  // test hook: force several passes
     if (envb && atoll(envb) > 0) budget = atoll(envb);
 
@@ -1292,7 +1301,7 @@ static int batch_create_impl(sa_batch_t **out, const sa_model_t *m, const sa_par
     b->runner = nullptr; b->runner_rc = SA_OK;
     b->d_regions = nullptr; b->d_rows = nullptr; b->d_pk = nullptr; b->d_poff = nullptr; b->d_pid = nullptr; b->d_px = nullptr; b->d_xc = nullptr;
     b->d_prec = nullptr;
-    b->d_ev = nullptr; b->d_segs = nullptr; b->d_cks = nullptr; b->d_F = nullptr; b->d_vbuf = nullptr;
+    b->d_ev = nullptr; b->d_segs = nullptr; b->d_cks = nullptr; b->d_F = nullptr; b->d_E = nullptr; b->d_vbuf = nullptr;
     b->d_cands = nullptr; b->d_cand_count = nullptr; b->d_overflow = nullptr; b->d_totals = nullptr;
     b->d_seam = nullptr; b->d_ckxy = nullptr; b->seam_cap = 0; b->seam_cap_bwd = 0; b->seam_bwd_off = 0; b->strip_on = false;
     b->d_bscratch = nullptr; b->d_tab6 = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr;
@@ -1352,6 +1361,13 @@ static int batch_finish(sa_batch *b) {
     if (!b->finished) {
         b->finish_rc = batch_finish_body(b);
         b->finished = true;
+        if (b->finish_rc != SA_OK) {
+            // Memsets, uploads and k_fill_xc of this batch may still be queued on the upload stream it used; sa_batch_destroy
+            // only waits for the batch's own streams before its blocks go back to the caching allocator, where a batch being
+            // created on the other uploader could receive them while that work still writes.  Drain the stream here.
+            SaUploader *const U = b->c_deferred ? &g_uploader_tail : &g_uploader;
+            if (U->stream && U->device == b->device) (void) sa_sync_stream(U->stream, b->device);
+        }
     }
     return b->finish_rc;
 }
@@ -1514,6 +1530,7 @@ static int batch_finish_body(sa_batch *b) {
         return SA_OK;
     };
     TRY(dalloc((void **) &b->d_F, 24 * pl->max_chunk_cellpaths));
+    if (m->hdp && pl->n_fast_regions > 0) TRY(dalloc((void **) &b->d_E, 8 * pl->max_chunk_cellpaths));
     TRY(dalloc((void **) &b->d_vbuf, 8 * pl->n_vbuf));
     TRY(dalloc((void **) &b->d_cands, (long long) sizeof(sa_cand_t) * pl->n_cand));
     TRY(dalloc((void **) &b->d_prob, 8 * pl->n_cand));
@@ -1705,7 +1722,8 @@ static int batch_finish_body(sa_batch *b) {
     b->stats.n_chunks = pl->n_chunks;
     b->stats.n_groups = (int64_t) b->groups.size();
     double fb = 0;
-    for (long long r = 0; r < pl->n_regions; r++) fb += 24.0 * (double) pl->regions[r].f_cellpaths;
+    for (long long r = 0; r < pl->n_regions; r++)   // (HDP register-kernel regions: 8 B more per cell, the emission plane)
+        fb += (m->hdp && pl->regions[r].kind == SA_KIND_FAST ? 32.0 : 24.0) * (double) pl->regions[r].f_cellpaths;
     b->stats.f_bytes = fb;
 #undef TRY
     // The pinned result buffer, from an estimate of the result size (measured: 0.9 pairs per event at the default threshold): taken
@@ -1746,7 +1764,7 @@ int sa_dplan_compare(const sa_model_t *m, const sa_params_t *p, const sa_job_t *
     b->h_pairs = nullptr; b->d_pairs_up = nullptr; b->h_seg_off = nullptr; b->h_overflow = nullptr;
     for (int i = 0; i < 8; i++) b->ev[i] = nullptr;
     b->d_regions = nullptr; b->d_rows = nullptr; b->d_pk = nullptr; b->d_poff = nullptr; b->d_pid = nullptr; b->d_px = nullptr; b->d_xc = nullptr;
-    b->d_prec = nullptr; b->d_ev = nullptr; b->d_segs = nullptr; b->d_cks = nullptr; b->d_F = nullptr; b->d_vbuf = nullptr;
+    b->d_prec = nullptr; b->d_ev = nullptr; b->d_segs = nullptr; b->d_cks = nullptr; b->d_F = nullptr; b->d_E = nullptr; b->d_vbuf = nullptr;
     b->d_cands = nullptr; b->d_cand_count = nullptr; b->d_overflow = nullptr; b->d_totals = nullptr; b->d_bscratch = nullptr;
     b->d_tab6 = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr; b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr;
     b->d_hdp_tab = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr; b->d_seg_off = nullptr; b->d_out = nullptr;
@@ -1902,6 +1920,7 @@ static int enqueue_pass(sa_batch *b, bool finalize, AfterGroup after_group) {
                 HIPCHK(hipStreamWaitEvent(s0, b->ev[1 + q], 0));
             }
         }
+        if (C.nfr && P.m.hdp) launch_emit_hdp(P, b->d_ids + C.ids_fr, C.nfr, pl->regions[b->ids_flat[(size_t) C.ids_fr]].N, s0);
         if (C.nfr) launch_fwd_fast(P, b->d_ids + C.ids_fr, C.nfr, s0, b->wide_cap);
         HIPCHK(hipEventRecord(b->cev[2 * c + 1], s0));
         if (C.g1 - C.g0 > 1) HIPCHK(hipStreamWaitEvent(s1, b->cev[2 * c + 1], 0));

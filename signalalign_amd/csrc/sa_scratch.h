@@ -90,7 +90,14 @@ struct SaPool {
         static const bool on = !(getenv("SA_POOL") && atoi(getenv("SA_POOL")) == 0);
         return on;
     }
+    // sa_pool_configure(): limits set by the embedding caller (-1: not set); they win over the environment and the defaults
+    static std::atomic<long long> &configured(int kind) {
+        static std::atomic<long long> lim[2] = {{-1}, {-1}};
+        return lim[kind];
+    }
     static size_t limit(int kind) {
+        const long long c = configured(kind).load();
+        if (c >= 0) return (size_t) c;
         const char *e = getenv("SA_POOL_LIMIT_GB");
         if (e) return (size_t) (atof(e) * 1073741824.0);
         if (kind != DEVICE) return (size_t) 32 << 30;   // (pinning costs 0.25 ms per MB: three HDP batches of 4.3 GB of pairs stay cached)
@@ -194,6 +201,23 @@ struct SaPool {
         }
         (void) known;
         raw_free(kind, p);
+    }
+    // frees parked blocks (largest first) until what is held fits the current limit
+    void trim(int kind) {
+        std::vector<void *> drop;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            const size_t lim = limit(kind);
+            while (held[kind] > lim && !idle[kind].empty()) {
+                size_t big = 0;
+                for (size_t i = 1; i < idle[kind].size(); i++)
+                    if (idle[kind][i].bytes > idle[kind][big].bytes) big = i;
+                held[kind] -= idle[kind][big].bytes;
+                drop.push_back(idle[kind][big].p);
+                idle[kind].erase(idle[kind].begin() + (long) big);
+            }
+        }
+        for (void *q : drop) raw_free(kind, q);
     }
     size_t idle_bytes(int kind, int dev) {
         std::lock_guard<std::mutex> g(mu);

@@ -311,6 +311,7 @@ static int estimate_strand(const strand_model_t *sm, const int64_t *strand_map, 
 }
 
 /* everything of impl/signalMachine.c:main between option parsing and performSignalAlignment, for one read */
+static int validate_read(const run_t *R, read_t *rd);
 static int prepare_read(const run_t *R, read_t *rd, int fatal) {
     if (rd->cigar_path == NULL) return fail(rd, fatal, "[signalMachine]ERROR: Need to provide input guide alignments, exiting", NULL);
     if (sa_cigar_load(rd->cigar_path, &rd->pA) != SA_OK)
@@ -428,18 +429,29 @@ static int prepare_read(const run_t *R, read_t *rd, int fatal) {
     }
     free(gx);
     free(gy);
-    if (!fatal) {
-        /* batch mode: the reads of a slice share one GPU batch, and the planner rejects a whole batch for one bad job
-         * (a reference window with a letter outside the alphabet, anchors that give an invalid diagonal).  The reference
-         * runs one process per read, so only that read may fail: plan every job alone on the host first (integer
-         * geometry only, no GPU) and drop the offender here. */
-        for (int s = 0; s < (R->two_d ? 2 : 1); s++) {
-            int rc = sa_plan_describe(s == 0 ? R->smt.model : R->smc.model, &R->p, &rd->jobs[s], R->ambig, 0, NULL, NULL, 0,
-                                      NULL, 0, NULL, 0);
-            if (rc != SA_OK) return fail(rd, 0, "alignment job rejected: %s", sa_strerror(rc));
-        }
+    /* batch mode: the reads of a slice share one GPU batch, and the planner rejects a whole batch for one bad job (a
+     * reference window with a letter outside the alphabet, anchors that give an invalid diagonal).  The reference runs one
+     * process per read, so only that read may fail.  Alignment runs find the offender when -- and only when -- a batch is
+     * turned down (validate_reads below); the expectation routine writes files strand by strand and cannot be re-run, so
+     * its jobs are planned alone on the host here (integer geometry only, no GPU). */
+    if (!fatal && R->expect_mode) return validate_read(R, rd);
+    return 0;
+}
+
+/* plans every job of the read alone on the host; marks the read failed when the planner rejects one */
+static int validate_read(const run_t *R, read_t *rd) {
+    for (int s = 0; s < (R->two_d ? 2 : 1); s++) {
+        int rc = sa_plan_describe(s == 0 ? R->smt.model : R->smc.model, &R->p, &rd->jobs[s], R->ambig, 0, NULL, NULL, 0, NULL, 0,
+                                  NULL, 0);
+        if (rc != SA_OK) return fail(rd, 0, "alignment job rejected: %s", sa_strerror(rc));
     }
     return 0;
+}
+
+typedef struct { const run_t *R; read_t *reads; const int64_t *who; } validate_ctx_t;
+static void validate_one(int64_t j, void *ctx) {
+    validate_ctx_t *v = ctx;
+    (void) validate_read(v->R, &v->reads[v->who[j]]);
 }
 
 static void set_hdp_expected(strand_model_t *sm) { /* stateMachine3_setModelToHdpExpectedValues, once per run */
@@ -699,6 +711,7 @@ static int64_t run_slice(run_t *Rp, read_t *reads, int64_t n_reads, int batch_mo
     int64_t *n_mea_s[2] = {NULL, NULL};
     sa_mea_pair_t ***mea = mea_s;
     int64_t **n_mea = n_mea_s;
+    int validated = !batch_mode;   /* a single-read run has nobody to isolate a bad job from */
     for (int s = 0; s < n_strands; s++) {
         pairs[s] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(sa_pair_t *));
         n_pairs[s] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(int64_t));
@@ -721,6 +734,27 @@ static int64_t run_slice(run_t *Rp, read_t *reads, int64_t n_reads, int batch_mo
             }
             if (rc == SA_OK) rc = sa_batch_mea(b, 0, mea[s], n_mea[s], NULL, NULL, NULL);
             sa_batch_destroy(b);
+        }
+        if (!validated && (rc == SA_EALPHABET || rc == SA_EBAND || rc == SA_EINVAL)) {
+            /* the planner turned the batch down: find the reads whose jobs it rejects (each planned alone on the host, all
+             * host threads), let them fail alone as the reference's one-process-per-read runs would, and start over */
+            validated = 1;
+            validate_ctx_t vc = {&R, reads, who};
+            parallel_for(n_ok, validate_one, &vc);
+            int64_t k2 = 0;
+            for (int64_t j = 0; j < n_ok; j++)
+                if (!reads[who[j]].failed) who[k2++] = who[j];
+            if (k2 < n_ok) {
+                for (int q = 0; q <= s; q++) {
+                    for (int64_t j = 0; j < n_ok; j++) { sa_free(pairs[q][j]); if (R.mea && mea[q]) sa_free(mea[q][j]); }
+                    free(pairs[q]); free(n_pairs[q]);
+                    if (R.mea) { free(mea[q]); free(n_mea[q]); mea[q] = NULL; n_mea[q] = NULL; }
+                    pairs[q] = NULL; n_pairs[q] = NULL;
+                }
+                n_ok = k2;
+                s = -1;   /* both strands again, without the offenders */
+                continue;
+            }
         }
         if (rc != SA_OK) {
             fprintf(stderr, "signalMachine: alignment failed: %s\n", sa_strerror(rc));

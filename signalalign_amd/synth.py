@@ -107,5 +107,116 @@ def make_read(index, n_events, alphabet, k, table5, trim=14, cpg_ambiguous=False
                 scale=scale, shift=shift, var=var, event_map=emap)
 
 
+def parse_nhdp(path):
+    """The slice of a serialised .nhdp (impl/hdp.c:2919-3051 writes it) the HDP read generator needs: the grid, each
+    process's parent, which processes saw data (every named process and its ancestors) and their posterior predictive
+    values on the grid.  Data parsing only."""
+    with open(path) as f:
+        rd = f.readline
+        n_alpha, alphabet, k = int(rd()), rd().split()[0], int(rd())
+        splines, has_data, sample_gamma = int(rd()) != 0, int(rd()) != 0, int(rd()) != 0
+        num_dps = int(rd())
+        dp_ids = []
+        if has_data:
+            rd()
+            dp_ids = [int(t) for t in rd().split()]
+        rd()
+        g0, g1, gl = rd().split()
+        rd()
+        if sample_gamma:
+            for _ in range(4):
+                rd()
+        parent = np.array([-1 if t.startswith("-") else int(t.split()[0]) for t in (rd() for _ in range(num_dps))], dtype=np.int64)
+        observed = np.zeros(num_dps, dtype=bool)
+        for a in dp_ids:
+            while a >= 0 and not observed[a]:
+                observed[a] = True
+                a = parent[a]
+        post = {}
+        if has_data:
+            for i in range(num_dps):
+                line = rd()
+                if observed[i]:
+                    post[i] = np.array(line.split(), dtype=np.float64)
+    return dict(alphabet=alphabet, k=k, grid=np.linspace(float(g0), float(g1), int(gl)), parent=parent, observed=observed,
+                post=post)
+
+
+class HdpSampler:
+    """Draws normalised events from the posterior predictive density an HDP k-mer resolves to (its own process when it
+    saw data, else its nearest ancestor that did: impl/hdp.c:2600-2602), by inverse CDF over the grid (trapezoids)."""
+
+    def __init__(self, nhdp):
+        self.h = nhdp
+        self.cdf = {}
+
+    def resolve(self, kid):
+        a = int(kid)
+        while a >= 0 and not self.h["observed"][a]:
+            a = int(self.h["parent"][a])
+        return a
+
+    def draw(self, rng, kids):
+        g = self.h["grid"]
+        out = np.empty(len(kids))
+        res = np.array([self.resolve(i) for i in kids])
+        for r in np.unique(res):
+            if r not in self.cdf:
+                d = np.maximum(self.h["post"][r], 0.0)
+                c = np.concatenate([[0.0], np.cumsum(0.5 * (d[1:] + d[:-1]) * np.diff(g))])
+                self.cdf[r] = c / c[-1]
+            sel = np.nonzero(res == r)[0]
+            out[sel] = np.interp(rng.uniform(size=len(sel)), self.cdf[r], g)
+        return out
+
+
+def make_read_hdp(index, n_events, alphabet, k, table5, sampler, ref_pool, trim=14):
+    """A read for the HDP workload (BASELINE configs[3]).  The bundled .nhdp saw the k-mers of ONE real read (351 leaf
+    processes; every other k-mer resolves to the root's broad density and cannot be told from its neighbours), so the
+    reference is assembled from windows of the sequence that read came from (`ref_pool`: tests/golden/npReads/ZymoRef.txt)
+    and every event is drawn from the density the aligner itself uses for its k-mer; table5 is the model's table after
+    set_to_hdp_expected_values (its level means enter the event normalisation, impl/stateMachine.c:541-545)."""
+    rng = np.random.Generator(np.random.PCG64(SEED0 + 0x48445000 + int(index)))
+    n_kmers = max(int(round(n_events / 1.67)), 8)
+    for attempt in range(4):
+        counts = rng.choice(len(EVENTS_PER_KMER_P), size=n_kmers, p=EVENTS_PER_KMER_P / EVENTS_PER_KMER_P.sum())
+        counts[0] = max(counts[0], 1)
+        total = int(counts.sum())
+        if abs(total - n_events) <= max(0.01 * n_events, 2) or attempt == 3:
+            break
+        n_kmers = max(int(round(n_kmers * n_events / max(total, 1))), 8)
+    L = n_kmers + k - 1
+    parts, have = [], 0
+    while have < L:
+        w = int(rng.integers(150, 600))
+        s0 = int(rng.integers(0, max(len(ref_pool) - w, 1)))
+        parts.append(ref_pool[s0:s0 + w])
+        have += len(parts[-1])
+    read = "".join(parts)[:L]
+    alpha = "".join(sorted(alphabet))
+    digit = np.array([alpha.index(c) for c in read], dtype=np.int64)
+    kid = np.zeros(n_kmers, dtype=np.int64)
+    for i in range(k):
+        kid = kid * len(alpha) + digit[i:i + n_kmers]
+    scale, shift, var = rng.uniform(0.95, 1.05), rng.uniform(-3.0, 3.0), rng.uniform(0.9, 1.3)
+    owner = np.repeat(np.arange(n_kmers), counts)
+    E = len(owner)
+    mu = table5[5 * kid[owner]]
+    en = sampler.draw(rng, kid[owner])
+    means = var * en - (var - scale) * mu + shift    # inverse of e' = (e + var mu - scale mu - shift) / var
+    noise = np.full(E, 1.0)
+    dur = np.full(E, 0.00127)
+    start = np.cumsum(dur) - dur
+    events4 = np.ascontiguousarray(np.stack([means, noise, dur, start], axis=1))
+    first = np.cumsum(counts) - counts
+    idx = np.maximum.accumulate(np.where(counts > 0, np.arange(n_kmers), 0))
+    emap = np.full(L, E - 1, dtype=np.int64)
+    emap[:n_kmers] = np.minimum(first[idx], E - 1)
+    ax, ay = single_match_anchors(emap, L, trim)
+    lo, hi = int(emap[0]), int(emap[L - 1])
+    return dict(ref=read, read=read, events4=events4, events=np.ascontiguousarray(events4[lo:hi]), ax=ax, ay=ay,
+                scale=scale, shift=shift, var=var, event_map=emap)
+
+
 def make_jobs(n_reads, n_events, alphabet, k, table5, first_index=0, **kw):
     return [make_read(first_index + i, n_events, alphabet, k, table5, **kw) for i in range(n_reads)]

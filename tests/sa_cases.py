@@ -103,3 +103,57 @@ def same_order(got, exp):
     kg = [(int(r["x"]), int(r["y"]), int(r["path"])) for r in got]
     se, sg = set(ke), set(kg)
     return [k for k in ke if k in sg] == [k for k in kg if k in se]
+
+
+_HDP_CACHE = {}
+
+
+def hdp_jobs(n_reads, n_events, first_index=0, table5=None):
+    """Reads of the HDP workload (BASELINE configs[3]): reference assembled from windows of the sequence the bundled .nhdp was
+    trained on, events drawn from the density the aligner itself uses for each k-mer (synth.make_read_hdp).  table5: the
+    model's table after set_to_hdp_expected_values (sa.Model.table5() or the oracle's match_table())."""
+    if "sampler" not in _HDP_CACHE:
+        _HDP_CACHE["sampler"] = synth.HdpSampler(synth.parse_nhdp(NHDP))
+        _HDP_CACHE["pool"] = open(os.path.join(GOLDEN, "npReads", "ZymoRef.txt")).read().split()[0].strip()
+    alpha, k, t10, tab = synth.parse_model_table(MODEL_R73)
+    t5 = tab if table5 is None else np.asarray(table5)
+    return [synth.make_read_hdp(first_index + i, n_events, alpha, k, t5, _HDP_CACHE["sampler"], _HDP_CACHE["pool"])
+            for i in range(n_reads)]
+
+
+def events_for_sequence(seq, model_path, seed):
+    """Synthetic events for a given nucleotide sequence (as synth.make_read draws them for a random one): 0-7 events per
+    k-mer, means ~ N(mu_k, sd_k).  Returns (events4, event_map) with event_map[i] = first event of the k-mer at base i."""
+    alpha, k, t10, tab = synth.parse_model_table(model_path)
+    alpha = "".join(sorted(alpha))
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n_kmers = len(seq) - k + 1
+    digit = np.array([alpha.index(c) for c in seq], dtype=np.int64)
+    kid = np.zeros(n_kmers, dtype=np.int64)
+    for i in range(k):
+        kid = kid * len(alpha) + digit[i:i + n_kmers]
+    p = synth.EVENTS_PER_KMER_P / synth.EVENTS_PER_KMER_P.sum()
+    counts = rng.choice(len(p), size=n_kmers, p=p)
+    counts[0] = max(counts[0], 1)
+    owner = np.repeat(np.arange(n_kmers), counts)
+    E = len(owner)
+    means = rng.normal(tab[5 * kid[owner]], tab[5 * kid[owner] + 1])
+    noise = np.abs(rng.normal(tab[5 * kid[owner] + 2], tab[5 * kid[owner] + 3])) + 1e-3
+    dur = np.full(E, 0.00127)
+    events4 = np.ascontiguousarray(np.stack([means, noise, dur, np.cumsum(dur) - dur], axis=1))
+    first = np.cumsum(counts) - counts
+    idx = np.maximum.accumulate(np.where(counts > 0, np.arange(n_kmers), 0))
+    emap = np.full(len(seq), E - 1, dtype=np.int64)
+    emap[:n_kmers] = np.minimum(first[idx], E - 1)
+    return events4, emap
+
+
+def write_npread_1d(path, read, event_map, events4):
+    """A 1-D .npRead as nanopore_loadNanoporeReadFromFile reads it (impl/nanopore.c:145-521; layout of the bundled
+    tests/test_npReads/r9p4_oneD.npRead): header, empty 2-D read, template read, template strand event map, three empty
+    complement lines, the template events, empty lines."""
+    with open(path, "w") as f:
+        f.write("0 %d 0 %d 0 1 1 1 1 1 0 1 1 1 1 1 0 0\n" % (len(events4), len(read)))
+        f.write("\n%s\n%s\n\n\n\n" % (read, " ".join(str(int(v)) for v in event_map)))
+        f.write(" ".join(repr(float(v)) for v in np.asarray(events4).reshape(-1)) + "\n")
+        f.write("\n\n\n\n\n\n\n")

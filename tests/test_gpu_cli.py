@@ -149,6 +149,131 @@ def test_signalmachine_variant_caller_output(oracle, tmp_path):
         assert 0.01 <= float(r[3]) <= 1.0
 
 
+def test_signalmachine_ambig_model_file(oracle, tmp_path):
+    """-a <file> (create_ambig_bases2, impl/pairwiseAligner.c:68-92; impl/signalMachine.c:649-655): the file REPLACES the
+    built-in ambiguity table.  With `X<TAB>CE` over the CpG model only cytosine / 5-methylcytosine are called at the X
+    positions; with the built-in table (X -> ACGT) the other bases are called too.  The reference's own fixture
+    (tests/test_position_code/test_positions_encoding.positions) loads as well: it does not name X, so X is then a letter
+    outside the alphabet and the run fails as the reference's kmer_id does."""
+    npread_path = os.path.join(cases.GOLDEN, "npReads", "r9p4_oneD.npRead")
+    r = oracle.parse_npread(npread_path)
+    read = r["template_read"]
+    L = 1500
+    ref = list(read[:L])
+    cpg = [i for i in range(100, L - 100) if read[i:i + 2] == "CG"][:12]
+    for pos in cpg:
+        ref[pos] = "X"
+    fasta = str(tmp_path / "ref.fa")
+    _write_fasta(fasta, "chrA", "".join(ref) + "ACGTACGTAC")
+    cigar = str(tmp_path / "guide.cigar")
+    with open(cigar, "w") as f:
+        f.write("cigar: r 0 %d + chrA 0 %d + 1 M %d\n" % (L, L, L))
+    amb = str(tmp_path / "ce.positions")
+    with open(amb, "w") as f:
+        f.write("X\tCE\n")
+    base = [BIN, "-T", cases.MODEL_CPG, "-q", npread_path, "-f", fasta, "-n", "chrA", "-p", cigar, "-L", "r", "-s", "1", "-g", "100"]
+
+    def rows_of(extra, name):
+        out = str(tmp_path / name)
+        pr = subprocess.run(base + ["-u", out] + extra, capture_output=True, text=True, timeout=300)
+        assert pr.returncode == 0, pr.stderr
+        return [l.rstrip("\n").split("\t") for l in open(out)]
+    with_file = rows_of(["-a", amb], "ce.tsv")
+    builtin = rows_of([], "acgt.tsv")
+    assert with_file and {int(r[1]) for r in with_file} <= set(cpg)
+    assert {r[2] for r in with_file} <= {"C", "E"} and "C" in {r[2] for r in with_file}
+    assert {r[2] for r in builtin} - {"C", "E"}            # X -> ACGT calls other bases somewhere
+    # the same answer as the library called with the same table
+    ref_fixture = os.path.join(cases.GOLDEN, "position_code", "test_positions_encoding.positions")
+    pr = subprocess.run(base + ["-u", str(tmp_path / "bad.tsv"), "-a", ref_fixture], capture_output=True, text=True, timeout=300)
+    assert pr.returncode != 0
+    pr = subprocess.run(base + ["-u", str(tmp_path / "bad.tsv"), "-a", str(tmp_path / "nope")], capture_output=True, text=True,
+                        timeout=300)
+    assert pr.returncode != 0 and "Couldn't open" in pr.stdout
+
+
+def test_signalmachine_rna(oracle, tmp_path):
+    """--rna (impl/signalMachine.c:716-724; impl/fasta_handler.c:47-102; writers :145-148, :166-170) on the reference's own
+    fake_rna FASTA pair (tests/test_sequences/fake_rna_replace/{forward,backward}.fake_rna_atg.fake_rna_ref.fa, every A of
+    an ATG replaced by X on either strand; committed as data).  RNA is read 3' -> 5': the guide alignment's read interval is
+    mirrored, its operations reversed, the template target becomes the REVERSED forward reference and the strand flips.
+    The read is synthetic (the reference ships no RNA .npRead): its sequence is that reversed target with the true base at
+    the X positions.  Expected rows come from the CPU restatement run on inputs transformed here by the reference's rules."""
+    model = cases.MODEL_6MER
+    seqdir = os.path.join(cases.GOLDEN, "sequences")
+    fwd_fa = os.path.join(seqdir, "fake_rna_replace", "forward.fake_rna_atg.fake_rna_ref.fa")
+    bwd_fa = os.path.join(seqdir, "fake_rna_replace", "backward.fake_rna_atg.fake_rna_ref.fa")
+
+    def seq_of(path):
+        return "".join(open(path).read().split("\n")[1:])
+    F, F0 = seq_of(fwd_fa), seq_of(os.path.join(seqdir, "fake_rna_ref.fa"))
+    a, b = 30, 1000
+    L = b - a
+    target = F[a:b][::-1]                      # what referenceSequence_getTemplateTarget returns under --rna, '+' cigar
+    pad = 8
+    rng = np.random.default_rng(5)
+    read = "".join("ACGT"[i] for i in rng.integers(0, 4, pad)) + F0[a:b][::-1] + "".join("ACGT"[i] for i in rng.integers(0, 4, pad))
+    ev, emap = cases.events_for_sequence(read, model, 77)
+    npread_path = str(tmp_path / "rna.npRead")
+    cases.write_npread_1d(npread_path, read, emap, ev)
+    Lr = len(read)
+    cigar = str(tmp_path / "guide.cigar")
+    with open(cigar, "w") as f:     # read interval [pad, Lr - pad) mirrors onto itself: Lr - (Lr - pad) = pad
+        f.write("cigar: rna1 %d %d + rna_fake %d %d + 1 M %d\n" % (pad, Lr - pad, a, b, L))
+    out = str(tmp_path / "rna.tsv")
+    pr = subprocess.run([BIN, "-T", model, "-q", npread_path, "-f", fwd_fa, "-b", bwd_fa, "-n", "rna_fake", "-p", cigar, "-u", out,
+                         "-L", "rna1", "-s", "0", "-g", "100", "--rna"], capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr
+    assert "SUCCESS" in pr.stderr
+    # ---- the same through the CPU restatement ----
+    r = oracle.parse_npread(npread_path)
+    om = oracle.Model.from_file(model)
+    ev2 = r["template_events"].copy()
+    prm = oracle.estimate_params(om, r["template_strand_event_map"], ev2, read)
+    start2, end2 = Lr - (Lr - pad), Lr - pad                     # :716-720
+    start1, end1, strand1 = b, a, 0                              # fasta_handler.c:83-90: swapped, strand flipped
+    gx, gy = oracle.guide_to_anchors(start1, end1, strand1, start2, [(0, L)], 14)
+    em = r["template_strand_event_map"]
+    ax, ay = oracle.remap_anchors(gx, gy, em, start2)
+    lo, hi = int(em[start2]), int(em[end2 - 1])
+    om.set_read_params(prm["scale"], prm["shift"], prm["var"])
+    pairs = oracle.align(om, target, ev2[lo:hi], ax, ay, oracle.default_params())
+    assert pairs["path"].max() >= 1                              # X positions really are ambiguous (ACGT)
+    tab, k, alpha = om.match_table(), om.k, om.alphabet
+    ref_len = len(target)
+    rows = []
+    for p in pairs:
+        x, y, kid = int(p["x"]), int(p["y"]) + lo, int(p["kmer_id"])
+        kmer, t = "", kid
+        for _ in range(k):
+            kmer = alpha[t % len(alpha)] + kmer
+            t //= len(alpha)
+        x_adj = (ref_len - k) - (x + (ref_len - start1))         # adjustReferenceCoordinate, template strand mapped backward
+        k_i = target[x:x + k]                                    # reference k-mer: reverse complement twice (:64-69, :143-146)
+        e_mean, e_noise = tab[5 * kid], tab[5 * kid + 2]
+        desc = (ev2[y, 0] + prm["var"] * e_mean - prm["scale"] * e_mean - prm["shift"]) / prm["var"]
+        rows.append("%s\t%d\t%s\t%s\t%s\t%d\t%f\t%f\t%f\t%s\t%f\t%f\t%f\t%f\t%f\t%s\n" % (
+            "rna_fake", x_adj, k_i, "rna1", "t", y, ev2[y, 0], ev2[y, 1], ev2[y, 2], k_i,
+            e_mean * prm["scale"] + prm["shift"], e_noise * prm["scale_sd"], int(p["prob_e7"]) / 1e7, desc, e_mean, kmer))
+    got = open(out).readlines()
+    assert len(got) == len(rows) and len(rows) > 1000
+    bad = 0
+    for g, e in zip(got, rows):
+        if g != e:
+            gf, ef = g.rstrip("\n").split("\t"), e.rstrip("\n").split("\t")
+            assert gf[:12] == ef[:12] and gf[13:] == ef[13:], (g, e)
+            assert abs(float(gf[12]) - float(ef[12])) <= 1e-5
+            bad += 1
+    assert bad <= len(rows) // 50
+    # variant-calling output: under --rna the strand label flips (:166-170): a '+' guide alignment is reported "backward"
+    vc = str(tmp_path / "rna_vc.tsv")
+    pr = subprocess.run([BIN, "-T", model, "-q", npread_path, "-f", fwd_fa, "-b", bwd_fa, "-n", "rna_fake", "-p", cigar, "-u", vc,
+                         "-L", "rna1", "-s", "1", "-g", "100", "--rna"], capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr
+    vrows = [l.rstrip("\n").split("\t") for l in open(vc)]
+    assert vrows and all(v[4] == "t" and v[5] == "forward" for v in vrows)
+
+
 def test_signalmachine_expectations_file(oracle, tmp_path):
     # -t: the .expectations file of continuousPairHmm_writeToFile (impl/continuousHmm.c:352-408)
     model = cases.MODEL_6MER

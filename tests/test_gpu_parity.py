@@ -145,6 +145,38 @@ def test_hdp_emissions(oracle):
         cases.compare_pairs(got[j], exp, TOL_E7, p.threshold)
 
 
+@pytest.mark.parametrize("threshold", [0.1, 0.01])
+def test_hdp_emission_plane_reads_of_the_hdp_workload(oracle, threshold):
+    """The HDP workload's reads (events drawn from the model's own densities): the emission plane (k_emit_hdp) feeds the
+    register sections and, for the read whose anchors are thinned to a sixth, the in-kernel memory-resident stretches (bands
+    wider than a wave); a read shorter than one tile of the emission kernel; several forward-storage passes."""
+    pm, om = _models(oracle, cases.MODEL_R73, cases.NHDP)
+    pm.set_to_hdp_expected_values()
+    om.set_to_hdp_expected_values()
+    p = sa.default_params(threshold=threshold)
+    op = cases.oracle_params(oracle, p)
+    jobs = cases.hdp_jobs(3, 1300, 7, table5=pm.table5()) + cases.hdp_jobs(1, 40, 99, table5=pm.table5())
+    sparse = dict(jobs[1])
+    keep = np.zeros(len(sparse["ax"]), dtype=bool)
+    keep[::41] = True
+    sparse["ax"], sparse["ay"] = sparse["ax"][keep], sparse["ay"][keep]
+    jobs.append(sparse)
+    got, st = _run(pm, p, jobs)
+    assert st.n_fast_regions == st.n_regions
+    exp = [cases.oracle_pairs(oracle, om, job, op) for job in jobs]
+    for j in range(len(jobs)):
+        assert len(exp[j]) > (0.02 if threshold >= 0.1 else 3.0) * len(jobs[j]["events"])
+        cases.compare_pairs(got[j], exp[j], TOL_E7, p.threshold)
+    os.environ["SA_F_BUDGET_CELLPATHS"] = "150000"
+    try:
+        got2, st2 = _run(pm, p, jobs)
+    finally:
+        del os.environ["SA_F_BUDGET_CELLPATHS"]
+    assert st2.n_chunks >= 2
+    for j in range(len(jobs)):
+        assert np.array_equal(got2[j], got[j])
+
+
 def test_edge_cases(oracle):
     pm, om = _models(oracle, cases.MODEL_5MER)
     p = sa.default_params()
