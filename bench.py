@@ -348,18 +348,17 @@ def main():
     if nhdp:
         pm.set_to_hdp_expected_values()
     params = sa.default_params(threshold=args.threshold, expansion=50, trace_back=100)
-    make_one = lambda i: synth.make_read(int(i), args.events, alpha, k, tab, **read_kw)
+    spec = dict(kind="gauss", model=model_path, events=args.events, kw=read_kw)
     if nhdp:
         # events drawn from the densities the aligner itself uses, over windows of the sequence the bundled .nhdp was trained
         # on (synth.make_read_hdp); the table's level means (after set_to_hdp_expected_values) enter the event normalisation
-        sampler = synth.HdpSampler(synth.parse_nhdp(nhdp))
-        pool = open(os.path.join(ROOT, "tests", "golden", "npReads", "ZymoRef.txt")).read().split()[0].strip()
-        t5 = np.array(pm.table5())
-        make_one = lambda i: synth.make_read_hdp(int(i), args.events, alpha, k, t5, sampler, pool)
+        spec = dict(kind="hdp", model=model_path, nhdp=nhdp, events=args.events, table5=np.array(pm.table5()),
+                    ref_pool=os.path.join(ROOT, "tests", "golden", "npReads", "ZymoRef.txt"))
+    make_many = lambda idx: synth.make_reads_parallel(spec, idx)   # spawned numpy-only workers; identical to the serial loop
     # reads are independent: the global read list is dealt to the ranks (no collective on the data path)
     from signalalign_amd import shard
     mine = shard.shard_indices([args.events] * (world * args.reads), rank, world)
-    jobs = [make_one(i) for i in mine]
+    jobs = make_many(mine)
     def thin_like_a_guide_alignment(job_list, indices):
         # the anchors a real guide alignment leaves: the run structure of the reference's own example cigar (an indel every
         # 10-50 bases), 14 bases trimmed off both ends of every match run as signalMachine -m 14 does
@@ -384,11 +383,11 @@ def main():
         wl_name = ("BASELINE configs[1] reads with the anchor density of a real guide alignment "
                    "(tests/golden/cigars/ecoli_minus_strand.cigar, -m 14: a sixth of the bases)")
     # ---- read sets: every timed step aligns reads the library has not seen in the step before ----
-    n_sets = 2 if args.workload == "scaling" or args.reads > 4000 else 3
+    n_sets = 1 if args.kernels_only else (2 if args.workload == "scaling" or args.reads > 4000 else 3)
     sets = [jobs]
     for q in range(1, n_sets):
         more = shard.shard_indices([args.events] * (world * args.reads), rank, world)
-        extra = [make_one(int(i) + q * world * args.reads) for i in more]
+        extra = make_many([int(i) + q * world * args.reads for i in more])
         if args.workload == "realistic":
             thin_like_a_guide_alignment(extra, [int(i) + q * world * args.reads for i in more])
         sets.append(extra)

@@ -926,6 +926,7 @@ struct sa_batch {
     int *d_ids;  // region / segment id lists per launch
     long long cand_alloc;
     long long out_alloc;
+    int cand_factor;               // candidate capacity relative to the planner's 2 per posterior diagonal (overflow re-runs)
     // launch lists (host): a chunk is one forward-storage pass; its traceback segments are cut into groups of
     // consecutive reads so that the result copy of one group overlaps the backward kernels of the next
     std::vector<sa_launch_chunk> chunks;
@@ -1205,6 +1206,24 @@ static int upload(T **dst, const T *src, long long n, long long pad = 0, bool sr
     return SA_OK;
 }
 
+// What the last overflow taught: batches of one stream resemble each other, so the next batch of the same model and threshold
+// starts with the candidate capacity the previous one had to grow to (a re-run of the whole pass costs a batch's kernel
+// time again: the HDP workload at threshold 0.1 ran 73 instead of 37 ms per batch until it stopped overflowing every time).
+struct SaCandMemo { std::mutex mu; const sa_model_t *model = nullptr; double threshold = 0.0; int factor = 1; };
+static SaCandMemo g_cand_memo;
+static int cand_memo_factor(const sa_model_t *m, double threshold) {
+    std::lock_guard<std::mutex> g(g_cand_memo.mu);
+    return (g_cand_memo.model == m && g_cand_memo.threshold == threshold) ? g_cand_memo.factor : 1;
+}
+static void cand_memo_note(const sa_model_t *m, double threshold, int factor) {
+    std::lock_guard<std::mutex> g(g_cand_memo.mu);
+    if (g_cand_memo.model == m && g_cand_memo.threshold == threshold) {
+        if (factor > g_cand_memo.factor) g_cand_memo.factor = factor;
+    } else {
+        g_cand_memo.model = m; g_cand_memo.threshold = threshold; g_cand_memo.factor = factor;
+    }
+}
+
 static std::atomic<int> g_batches_started(0);
 static void dplan_release_fwd(sa_batch *b, struct DPlanPending *P);   // sa_dplan.inc (below)   // batches between sa_batch_start and sa_batch_wait (this process)
 
@@ -1307,7 +1326,7 @@ static int batch_create_impl(sa_batch_t **out, const sa_model_t *m, const sa_par
     b->d_bscratch = nullptr; b->d_tab6 = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr;
     b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr; b->d_hdp_tab = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr;
     b->d_seg_off = nullptr; b->d_out = nullptr; b->d_ids = nullptr; b->d_gsum = nullptr; b->d_gmc = nullptr;
-    b->cand_alloc = 0; b->out_alloc = 0;
+    b->cand_alloc = 0; b->out_alloc = 0; b->cand_factor = 1;
     b->h_pairs = nullptr; b->h_pairs_cap = 0; b->n_pairs_total = 0;
     b->d_pairs_up = nullptr; b->d_pairs_up_cap = 0;
     memset(&b->stats, 0, sizeof(b->stats));
@@ -1409,6 +1428,7 @@ static int batch_finish_body(sa_batch *b) {
         b->plan = pl;
     }
     if (trace_c) fprintf(stderr, "[trace] create: planned (%s) at %.1f ms\n", b->dev_planned ? "device" : "host", now_ms_c() - tc0);
+
     b->expect = (flags & SA_FLAG_EXPECT_INTERNAL) != 0;
     b->relax = !(flags & SA_FLAG_EXACT) && !b->expect && m->hdp == nullptr;
     b->ring_cap = 0;
@@ -1439,6 +1459,15 @@ static int batch_finish_body(sa_batch *b) {
     std::unique_lock<std::mutex> up_lock((*UPT).mu);
     TRY((*UPT).bind(device));
     if (trace_c) fprintf(stderr, "[trace] create: upload ring ready at %.1f ms\n", now_ms_c() - tc0);
+    {   // candidate capacity an earlier batch of this stream had to grow to
+        const int f = pl->params.threshold > 0.0 ? cand_memo_factor(m, pl->params.threshold) : 1;
+        if (f > 1) {
+            sa_plan_grow_candidates(pl, f);
+            b->cand_factor = f;
+            if (b->dev_planned && pl->n_segs > 0)   // its segments are in HBM already: the copy is stream-ordered behind the planner
+                TRY((*UPT).copy(b->d_segs, pl->segs, sizeof(sa_seg_t) * (size_t) pl->n_segs));
+        }
+    }
     const bool big_pinned = pl->pooled && pl->big_free == plan_pinned_free;   // the big arrays are pinned: no staging
     if (!b->dev_planned) {
         TRY(upload(&b->d_regions, pl->regions, pl->n_regions));
@@ -1972,6 +2001,8 @@ static int grow_after_overflow(sa_batch *b) {
     sa_plan_t *pl = b->plan;
     // a traceback segment produced more candidates than planned: enlarge and redo the pass
     sa_plan_grow_candidates(pl, 4);
+    b->cand_factor = (b->cand_factor > 0 ? b->cand_factor : 1) * 4;
+    cand_memo_note(pl->model, pl->params.threshold, b->cand_factor);
     g_sa_pool.put(SaPool::DEVICE, b->d_cands);
     g_sa_pool.put(SaPool::DEVICE, b->d_prob);
     b->d_cands = nullptr;

@@ -150,24 +150,35 @@ class HdpSampler:
         self.h = nhdp
         self.cdf = {}
 
-    def resolve(self, kid):
-        a = int(kid)
-        while a >= 0 and not self.h["observed"][a]:
-            a = int(self.h["parent"][a])
-        return a
+    def resolve(self, kids):
+        if not hasattr(self, "_res"):
+            obs, par = self.h["observed"], self.h["parent"]
+            res = np.arange(len(par), dtype=np.int64)
+            for _ in range(64):                      # depth of the tree at most
+                todo = (res >= 0) & ~obs[np.maximum(res, 0)]
+                if not todo.any():
+                    break
+                res[todo] = par[res[todo]]
+            self._res = res
+        return self._res[np.asarray(kids, dtype=np.int64)]
 
     def draw(self, rng, kids):
         g = self.h["grid"]
-        out = np.empty(len(kids))
-        res = np.array([self.resolve(i) for i in kids])
-        for r in np.unique(res):
-            if r not in self.cdf:
-                d = np.maximum(self.h["post"][r], 0.0)
-                c = np.concatenate([[0.0], np.cumsum(0.5 * (d[1:] + d[:-1]) * np.diff(g))])
-                self.cdf[r] = c / c[-1]
-            sel = np.nonzero(res == r)[0]
-            out[sel] = np.interp(rng.uniform(size=len(sel)), self.cdf[r], g)
-        return out
+        if not hasattr(self, "_cdf"):
+            ids = sorted(self.h["post"])
+            self._row = np.full(len(self.h["parent"]), -1, dtype=np.int64)
+            self._row[ids] = np.arange(len(ids))
+            d = np.maximum(np.stack([self.h["post"][i] for i in ids]), 0.0)
+            c = np.concatenate([np.zeros((len(ids), 1)), np.cumsum(0.5 * (d[:, 1:] + d[:, :-1]) * np.diff(g), axis=1)], axis=1)
+            self._cdf = c / c[:, -1:]
+        rows = self._cdf[self._row[self.resolve(kids)]]           # one CDF row per event
+        u = rng.uniform(size=len(rows))
+        hi = np.clip((rows < u[:, None]).sum(axis=1), 1, len(g) - 1)   # first grid point with cdf >= u
+        lo = hi - 1
+        ar = np.arange(len(rows))
+        c0, c1 = rows[ar, lo], rows[ar, hi]
+        t = np.where(c1 > c0, (u - c0) / np.where(c1 > c0, c1 - c0, 1.0), 0.0)
+        return g[lo] + t * (g[hi] - g[lo])
 
 
 def make_read_hdp(index, n_events, alphabet, k, table5, sampler, ref_pool, trim=14):
@@ -220,3 +231,50 @@ def make_read_hdp(index, n_events, alphabet, k, table5, sampler, ref_pool, trim=
 
 def make_jobs(n_reads, n_events, alphabet, k, table5, first_index=0, **kw):
     return [make_read(first_index + i, n_events, alphabet, k, table5, **kw) for i in range(n_reads)]
+
+
+# ---- generating thousands of reads on several cores (bench.py, the full-size tests) -------------------------------------
+_WORKER = {}
+
+
+def _reads_chunk(task):
+    """Worker (its own process, numpy only -- it never touches the GPU): reads `indices` of the workload `spec` names."""
+    spec, indices = task
+    key = (spec["kind"], spec["model"], spec.get("nhdp"))
+    if _WORKER.get("key") != key:
+        alpha, k, t10, tab = parse_model_table(spec["model"])
+        _WORKER.clear()
+        _WORKER.update(key=key, alpha=alpha, k=k, tab=tab)
+        if spec["kind"] == "hdp":
+            _WORKER["sampler"] = HdpSampler(parse_nhdp(spec["nhdp"]))
+            _WORKER["pool"] = open(spec["ref_pool"]).read().split()[0].strip()
+    w = _WORKER
+    if spec["kind"] == "hdp":
+        t5 = np.asarray(spec["table5"])
+        return [make_read_hdp(int(i), spec["events"], w["alpha"], w["k"], t5, w["sampler"], w["pool"]) for i in indices]
+    return [make_read(int(i), spec["events"], w["alpha"], w["k"], w["tab"], **spec.get("kw", {})) for i in indices]
+
+
+def make_reads_parallel(spec, indices, workers=None):
+    """make_read / make_read_hdp for every index, in `workers` spawned processes (default: up to 8, the CPU quota allowing);
+    the result is identical to the serial loop (every read is seeded by its index)."""
+    import os
+    indices = [int(i) for i in indices]
+    if workers is None:
+        workers = min(8, max(1, len(os.sched_getaffinity(0)) - 2))
+        if os.environ.get("SA_SYNTH_WORKERS"):
+            workers = int(os.environ["SA_SYNTH_WORKERS"])
+        # under a profiler every child process would load the profiler's preloaded tool (and with it the GPU runtime): serial
+        if any("rocprof" in v.lower() for v in (os.environ.get("LD_PRELOAD", ""), os.environ.get("ROCP_TOOL_LIBRARIES", ""),
+                                                os.environ.get("ROCPROFILER_REGISTER_LIBRARY", ""))) or \
+                any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+            workers = 1
+    if workers <= 1 or len(indices) < 256:
+        return _reads_chunk((spec, indices))
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    step = max(64, (len(indices) + 4 * workers - 1) // (4 * workers))
+    tasks = [(spec, indices[a:a + step]) for a in range(0, len(indices), step)]
+    with ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as ex:
+        parts = list(ex.map(_reads_chunk, tasks))
+    return [r for part in parts for r in part]

@@ -151,8 +151,9 @@ def test_signalmachine_variant_caller_output(oracle, tmp_path):
 
 def test_signalmachine_ambig_model_file(oracle, tmp_path):
     """-a <file> (create_ambig_bases2, impl/pairwiseAligner.c:68-92; impl/signalMachine.c:649-655): the file REPLACES the
-    built-in ambiguity table.  With `X<TAB>CE` over the CpG model only cytosine / 5-methylcytosine are called at the X
-    positions; with the built-in table (X -> ACGT) the other bases are called too.  The reference's own fixture
+    built-in ambiguity table.  With `X<TAB>AT` only A or T can be called at the X positions (which really hold a C: the
+    built-in table, X -> ACGT, calls C there); with `X<TAB>CE` over the CpG model only cytosine / 5-methylcytosine.  The
+    reference's own fixture
     (tests/test_position_code/test_positions_encoding.positions) loads as well: it does not name X, so X is then a letter
     outside the alphabet and the run fails as the reference's kmer_id does."""
     npread_path = os.path.join(cases.GOLDEN, "npReads", "r9p4_oneD.npRead")
@@ -171,6 +172,9 @@ def test_signalmachine_ambig_model_file(oracle, tmp_path):
     amb = str(tmp_path / "ce.positions")
     with open(amb, "w") as f:
         f.write("X\tCE\n")
+    amb_at = str(tmp_path / "at.positions")
+    with open(amb_at, "w") as f:
+        f.write("X\tAT\nR\tAG\n")
     base = [BIN, "-T", cases.MODEL_CPG, "-q", npread_path, "-f", fasta, "-n", "chrA", "-p", cigar, "-L", "r", "-s", "1", "-g", "100"]
 
     def rows_of(extra, name):
@@ -182,7 +186,9 @@ def test_signalmachine_ambig_model_file(oracle, tmp_path):
     builtin = rows_of([], "acgt.tsv")
     assert with_file and {int(r[1]) for r in with_file} <= set(cpg)
     assert {r[2] for r in with_file} <= {"C", "E"} and "C" in {r[2] for r in with_file}
-    assert {r[2] for r in builtin} - {"C", "E"}            # X -> ACGT calls other bases somewhere
+    assert {r[2] for r in builtin} <= set("ACGT") and "C" in {r[2] for r in builtin}
+    only_at = rows_of(["-a", amb_at], "at.tsv")
+    assert only_at and {r[2] for r in only_at} <= {"A", "T"} and {int(r[1]) for r in only_at} <= set(cpg)
     # the same answer as the library called with the same table
     ref_fixture = os.path.join(cases.GOLDEN, "position_code", "test_positions_encoding.positions")
     pr = subprocess.run(base + ["-u", str(tmp_path / "bad.tsv"), "-a", ref_fixture], capture_output=True, text=True, timeout=300)
