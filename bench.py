@@ -242,6 +242,67 @@ def bench_mea(args):
     print(json.dumps(res))
 
 
+def bench_expectations(args):
+    """The expectation pass (getExpectationsUsingAnchors, impl/pairwiseAligner.c:2164-2184: the inner loop of trainModels.py's
+    EM): one step = one sa_expect_batch call over the headline workload's reads -- planning, upload, forward sweep storing all
+    three states, backward sweep with the transition expectations fused in (k_bwd_fast_expect), fold, host rescale.  Cells are
+    counted as for the alignment (forward + backward cell updates)."""
+    import signalalign_amd as sa
+    from signalalign_amd import synth
+    from oracle import sa_oracle_py as oracle
+    from concurrent.futures import ThreadPoolExecutor
+    alpha, k, t10, tab = synth.parse_model_table(MODEL)
+    pm = sa.Model.load(MODEL)
+    params = sa.default_params(threshold=args.threshold, expansion=50, trace_back=100)
+    jobs = job_list = synth.make_reads_parallel(dict(kind="gauss", model=MODEL, events=args.events, kw={}), range(args.reads))
+    b = sa.Batch(pm, params, jobs)
+    st = b.stats()
+    cells = st.cells_forward + st.cells_backward
+    b.close()
+    jobs = sa.JobArray(jobs)   # marshalled once: a C caller holds sa_job_t arrays anyway
+    for _ in range(max(1, args.warmup)):
+        sa.expect_batch(pm, params, jobs)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trans, lik, _ = sa.expect_batch(pm, params, jobs)
+    dt = (time.perf_counter() - t0) / args.steps
+    tg0 = time.perf_counter()
+    for _ in range(max(1, args.steps // 4)):
+        sa.expect_batch(pm, params, jobs, flags=sa.FLAG_FORCE_GENERIC)
+    dtg = (time.perf_counter() - tg0) / max(1, args.steps // 4)
+    res = {"metric": "dp_cell_updates_per_s", "value": cells / dt, "unit": "cell_updates/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "expectation pass (sa_expect_batch) over BASELINE configs[1]'s reads: %d synthetic %d-event reads, "
+                                  "band=50" % (args.reads, args.events),
+                      "step": "one sa_expect_batch call: create (host planner) + forward (all three states stored) + backward with "
+                              "fused transition expectations + fold + host rescale + destroy",
+                      "memory_resident_kernels_ms_per_step": dtg * 1e3, "memory_resident_kernels_value": cells / dtg,
+                      "mean_match_to_match_expectation": float(trans[:, 0].mean()), "mean_log_likelihood": float(lik.mean())},
+           # 48 B per cell update: the forward sweep writes and the backward sweep reads all three states of every cell
+           "roofline": {"bound": "issue", "bound_of_the_formula": "hbm", "kernel": "k_bwd_fast_expect", "achieved": None,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                        "note": "whole-call rate; the per-kernel split is in profiles/ (rocprofv3 --kernel-trace --stats)"}}
+    if not args.no_cpu_baseline:
+        info = host_cpu_info()
+        cores = max(1, min(len(info["allowed"]), int(info["cgroup_cpu_quota"] or 64), 16))
+        om_p = oracle.default_params()
+        sample = job_list[:cores * 4]
+
+        def one(j):
+            m_ = oracle.Model(alpha, k, t10, tab)
+            m_.set_read_params(j["scale"], j["shift"], j["var"])
+            return oracle.expectations(m_, j["ref"], j["events"], j["ax"], j["ay"], om_p)[1]
+        t1 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(one, sample))
+        dtc = time.perf_counter() - t1
+        res["cpu_baseline"] = {"value": cells / len(job_list) * len(sample) / dtc, "unit": "cell_updates/s", "cores": cores,
+                               "kind": "port", "sample": "%d reads, oracle/sa_oracle.c:sao_expectations, %d threads, %.1f s wall"
+                                                         % (len(sample), cores, dtc)}
+    print(json.dumps(res))
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start N ranks, one per GPU, as children of this process --
     which itself never touches the GPU (no HIP call, no torch.cuda call before or after) -- through
@@ -258,79 +319,13 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
-def main():
-    # A streaming caller keeps three batches in flight, each with two compute streams, a copy stream and the upload stream: more
-    # hardware queues than the runtime's default of four keep one batch's short kernels from queueing behind another's long
-    # sweeps (12.7-12.9 against 12.6-13.9 ms per step; must be set before the first HIP call; ranks inherit it)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--in-flight", type=int, default=3, help="batches in flight in the timed pipeline (create of the next "
-                                                            "overlaps the runs of the previous ones)")
-    ap.add_argument("--reads", type=int, default=None, help="reads per GPU (default: 2000 = BASELINE configs[1]; "
-                                                             "scaling: 12500 = configs[4]'s 100k reads / 8 GPUs)")
-    ap.add_argument("--events", type=int, default=None, help="events per read (default 5000; scaling: 10000)")
-    ap.add_argument("--workload", choices=["gaussian", "scaling", "cpg", "hdp", "realistic", "event_align", "mea"],
-                    default="gaussian",
-                    help="gaussian = BASELINE configs[1] (the headline); scaling = configs[4]'s per-GPU slice (12500 "
-                         "10k-event reads per GPU, several forward-storage passes); cpg = configs[2] (ACEGT model, every "
-                         "CpG cytosine ambiguous C/E); hdp = configs[3] (HDP emissions); realistic = configs[1] reads with "
-                         "the sparse anchors of a real guide alignment; event_align, mea = the steps either side of the "
-                         "pair-HMM.")
-    ap.add_argument("--threshold", type=float, default=None, help="posterior threshold (default 0.01; hdp: 0.1, what the "
-                                                                  "reference's own HDP test uses, tests/stateMachineTests.c:912)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kernels-only", action="store_true", help="phase 1 only (sa_batch_run on one resident batch): for "
-                                                                "profiler runs that count per-kernel launches")
-    ap.add_argument("--cpu-reads-per-thread", type=int, default=30)
-    args = ap.parse_args()
-    if args.reads is None:
-        args.reads = {"scaling": 12500, "hdp": 5000}.get(args.workload, 2000)   # hdp: BASELINE configs[3] names 5000 reads
-    if args.events is None:
-        args.events = 10000 if args.workload == "scaling" else 5000
-    if args.threshold is None:
-        args.threshold = 0.1 if args.workload == "hdp" else 0.01
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # not under a launcher: become one (nothing in this process has touched or will touch the GPU)
-        sys.exit(self_launch(args.gpus))
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    device = 0
-    backend = os.environ.get("SA_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N > 1 path on a box with one GPU
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        device = local_rank % max(torch.cuda.device_count(), 1)  # identity on a full node
-        torch.cuda.set_device(device)
-        dist.init_process_group(backend=backend)  # RCCL; only used for the barrier and the max-over-ranks
-    if world > 1:
-        # Ranks of one node share the host (and, in a container, one CPU quota): the library sizes its host fan-out for a process
-        # that has the machine to itself, so every rank gets its share here.  (SA_HOST_THREADS / SA_PLAN_THREADS: DESIGN.md.)
-        info = host_cpu_info()
-        cpus = int(info["cgroup_cpu_quota"]) if info["cgroup_cpu_quota"] else len(info["allowed"])
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-        share = max(2, min(16, cpus // max(local_world, 1) - 2))
-        os.environ.setdefault("SA_HOST_THREADS", str(share))
-        os.environ.setdefault("SA_PLAN_THREADS", str(share))
+def measure(args, ctx, compact=False):
+    """One workload through phase 1 (kernels on a resident batch) and phase 2 (fresh batches through the whole boundary);
+    returns the result record on rank 0, None elsewhere.  compact: a secondary workload of the default run -- few steps, no
+    serial-cycle samples, no CPU baseline."""
     import signalalign_amd as sa
     from signalalign_amd import synth
-
-    if args.workload in ("mea", "event_align"):
-        # the two "next" rows are single-GPU side benchmarks: under a multi-rank launch only rank 0 runs them
-        if world > 1:
-            dist.barrier()
-            if rank != 0:
-                dist.destroy_process_group()
-                return
-        res = bench_mea(args) if args.workload == "mea" else bench_event_align(args)
-        if world > 1:
-            dist.destroy_process_group()
-        return res
+    dist, rank, world, device, backend = ctx["dist"], ctx["rank"], ctx["world"], ctx["device"], ctx["backend"]
     gold = os.path.join(ROOT, "tests", "golden", "models")
     model_path, nhdp, ambig, read_kw, wl_name = MODEL, None, None, {}, "BASELINE configs[1]: R9.4 6-mer template Gaussian HMM"
     if args.workload == "cpg":
@@ -383,7 +378,7 @@ def main():
         wl_name = ("BASELINE configs[1] reads with the anchor density of a real guide alignment "
                    "(tests/golden/cigars/ecoli_minus_strand.cigar, -m 14: a sixth of the bases)")
     # ---- read sets: every timed step aligns reads the library has not seen in the step before ----
-    n_sets = 1 if args.kernels_only else (2 if args.workload == "scaling" or args.reads > 4000 else 3)
+    n_sets = 1 if args.kernels_only else (2 if args.workload == "scaling" or args.reads > 4000 or compact else 3)
     sets = [jobs]
     for q in range(1, n_sets):
         more = shard.shard_indices([args.events] * (world * args.reads), rank, world)
@@ -391,6 +386,10 @@ def main():
         if args.workload == "realistic":
             thin_like_a_guide_alignment(extra, [int(i) + q * world * args.reads for i in more])
         sets.append(extra)
+    if args.event_stride == 1:
+        for js in sets:
+            for j_ in js:
+                j_["events"] = np.ascontiguousarray(np.asarray(j_["events"])[:, 0])
     arrays = [sa.JobArray(js) for js in sets]          # marshalled once: a C caller holds sa_job_t arrays anyway
     n_events_total = sum(len(j["events"]) for j in jobs)
 
@@ -426,7 +425,7 @@ def main():
     cycle = {"create": 0.0, "run": dt_resident * 1e3, "destroy": 0.0}
     if not args.kernels_only:
         samples = []
-        for q in range(1 if args.workload == "scaling" else 5):
+        for q in range(1 if args.workload == "scaling" or compact else 5):
             tc0 = time.perf_counter()
             bb = sa.Batch(pm, params, arrays[(q + 1) % n_sets], ambig=ambig, device=device)
             tc1 = time.perf_counter()
@@ -453,6 +452,7 @@ def main():
     # flight: the result copies of the neighbours queue behind each other on the one copy engine)
     depth = max(1, min(depth, int(6e9 / max(24.0 * n_pairs, 1.0))))
     cells_done = [0.0]
+    groups_seen = [0]
 
     def stream(n_steps, first):
         flying = []
@@ -475,6 +475,7 @@ def main():
                 t_c = time.perf_counter()
                 stc = cur.stats()
                 cells_done[0] += stc.cells_forward + stc.cells_backward
+                groups_seen[0] = int(stc.n_groups)
                 cur.n_pairs(0)
                 cur.close()
                 if dbg:
@@ -488,6 +489,7 @@ def main():
             cur = sa.Batch(pm, params, arrays[(first + s) % n_sets], ambig=ambig, device=device)
             stc = cur.stats()
             cells_done[0] += stc.cells_forward + stc.cells_backward
+            groups_seen[0] = int(stc.n_groups)
             t_b = time.perf_counter()
             cur.start()
             flying.append(cur)
@@ -517,6 +519,16 @@ def main():
         sync()
         dt = time.perf_counter() - t0
     cells_streamed = cells_done[0]
+    long_run = None
+    if (not compact and not args.kernels_only and world == 1 and args.workload == "gaussian" and not args.no_secondary
+            and args.long_steps > args.steps):
+        # K = 20 steps are 0.2 s: a longer sample of the same loop beside it (NOT `value`: the contract times exactly K steps)
+        cells_done[0] = 0.0
+        tl0 = time.perf_counter()
+        stream(args.long_steps, args.warmup + args.steps)
+        dtl = time.perf_counter() - tl0
+        long_run = {"steps": args.long_steps, "seconds": dtl, "ms_per_step": dtl / args.long_steps * 1e3,
+                    "value": cells_done[0] / dtl, "note": "same pipelined loop as the timed steps, run once more for longer"}
     if dist is not None:
         import torch
         tdev = "cuda" if backend == "nccl" else "cpu"
@@ -547,12 +559,15 @@ def main():
         # probes/profile_r02.sh + probes/traffic_from_pmc.py: FETCH_SIZE and WRITE_SIZE in separate passes, fetch doubled as
         # MI355X_MICROARCH.md prescribes for gfx950); collected at the default size of each workload only
         traffic = None
+        profiles_meta = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         default_size = (args.reads == (12500 if args.workload == "scaling" else 2000) and
                         args.events == (10000 if args.workload == "scaling" else 5000))
         if os.path.exists(tp) and default_size:
             try:
-                traffic = json.load(open(tp)).get(args.workload, {}).get(dom, {}).get("bytes_per_step")
+                tj = json.load(open(tp))
+                traffic = tj.get(args.workload, {}).get(dom, {}).get("bytes_per_step")
+                profiles_meta = tj.get("_meta", {}).get(args.workload)   # commit and date of the counter passes (not this run)
             except Exception:
                 traffic = None
         # instruction issue of the dominant kernel: wave-instructions per step from the rocprofv3 --pmc passes
@@ -590,7 +605,8 @@ def main():
             "config": {
                 "workload": "%s, %d synthetic %d-event reads per GPU, band=50, threshold %g, traceBackDiagonals 100"
                             % (wl_name, args.reads, args.events, args.threshold),
-                "reads_per_gpu": args.reads, "events_per_read": args.events,
+                "reads_per_gpu": args.reads, "events_per_read": args.events, "event_stride": args.event_stride,
+                "host_threads": os.environ.get("SA_HOST_THREADS"),
                 "events_per_s": events_all / dt,
                 "cells_per_event": cells / max(n_events_total, 1),
                 "pairs_rank0": n_pairs, "pairs_per_event": n_pairs / max(n_events_total, 1),
@@ -598,12 +614,12 @@ def main():
                 "regions_on_ring_kernels": "%d/%d" % (st0.n_ring_regions - st0.n_strip_regions, st0.n_regions),
                 "regions_on_strip_kernels": "%d/%d" % (st0.n_strip_regions, st0.n_regions),
                 "forward_storage_passes": int(st0.n_chunks),
-                "result_groups": int(st0.n_groups),
+                "result_groups": {"resident_batch_phase": int(st0.n_groups), "timed_pipeline": groups_seen[0] or None},
                 "step": "one batch of fresh reads through the whole boundary: sa_batch_create (checks, planning, upload) + run + "
                         "results on the host + sa_batch_destroy; %s" % ("%d batches in flight (sa_batch_start / sa_batch_wait)" % depth
                                                                         if depth > 1 else "one batch on the device at a time, the next one checked, "
                                                                         "packed, uploaded and planned meanwhile (sa_batch_create_deferred)"),
-                "read_sets_cycled": n_sets,
+                "read_sets_cycled": n_sets, "long_run": long_run,
                 "first_batch_create_s": t_create,
                 "serial_cycle_ms": cycle,
                 "value_serial_cycle": cells / (sum(cycle.values()) * 1e-3),
@@ -614,11 +630,16 @@ def main():
                 "kernel_cell_updates_per_s": {"forward": st0.cells_forward / (ms_f * 1e-3),
                                               "backward_posterior": st0.cells_backward / (ms_b * 1e-3)},
             },
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # `frac` follows SURVEY section 8(d): algorithmic bytes (24 B per cell update) over the stage time against HBM peak;
+            # `frac_by_counters` are the bytes the counters saw.  `bound` names what the evidence says limits the kernel: the
+            # sweeps issue instructions during most of their cycles while HBM idles ("issue"; HBM figures kept beside it)
+            "roofline": {"bound": "issue" if issue and issue["frac"] > (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else 0.0)
+                         else "hbm", "bound_of_the_formula": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "frac_by_counters": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "limiter": "instruction issue (VALU + SALU of the serial per-diagonal chain), not HBM: see "
                                     "profiles/ and DESIGN.md section 4",
+                         "counters_collected_at": profiles_meta,
                          "kernel_passes_phase1": (max(1, min(args.warmup, 3)) + KR),
                          "algorithmic_bytes_per_step": ALGO_BYTES_PER_CELL * dom_cells,
                          "stage_ms": dom_ms,
@@ -629,6 +650,113 @@ def main():
         if not args.no_cpu_baseline and world == 1 and args.workload in ("gaussian", "scaling"):   # (rank 0 at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(alpha, k, t10, tab, args.events, args.cpu_reads_per_thread,
                                                first_index=10 ** 6)
+        return out
+    return None
+
+
+def main():
+    # A streaming caller keeps three batches in flight, each with two compute streams, a copy stream and the upload stream: more
+    # hardware queues than the runtime's default of four keep one batch's short kernels from queueing behind another's long
+    # sweeps (12.7-12.9 against 12.6-13.9 ms per step; must be set before the first HIP call; ranks inherit it)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--in-flight", type=int, default=3, help="batches in flight in the timed pipeline (create of the next "
+                                                            "overlaps the runs of the previous ones)")
+    ap.add_argument("--reads", type=int, default=None, help="reads per GPU (default: 2000 = BASELINE configs[1]; "
+                                                             "scaling: 12500 = configs[4]'s 100k reads / 8 GPUs)")
+    ap.add_argument("--events", type=int, default=None, help="events per read (default 5000; scaling: 10000)")
+    ap.add_argument("--workload", choices=["gaussian", "scaling", "cpg", "hdp", "realistic", "event_align", "mea", "expectations"],
+                    default="gaussian",
+                    help="gaussian = BASELINE configs[1] (the headline); scaling = configs[4]'s per-GPU slice (12500 "
+                         "10k-event reads per GPU, several forward-storage passes); cpg = configs[2] (ACEGT model, every "
+                         "CpG cytosine ambiguous C/E); hdp = configs[3] (HDP emissions); realistic = configs[1] reads with "
+                         "the sparse anchors of a real guide alignment; event_align, mea = the steps either side of the "
+                         "pair-HMM.")
+    ap.add_argument("--threshold", type=float, default=None, help="posterior threshold (default 0.01; hdp: 0.1, what the "
+                                                                  "reference's own HDP test uses, tests/stateMachineTests.c:912)")
+    ap.add_argument("--event-stride", type=int, choices=[1, 4], default=4,
+                    help="layout of the events a job hands over: 4 = the reference's NB_EVENT_PARAMS records (mean, noise, "
+                         "duration, start: what signalMachine holds; the library gathers the means), 1 = a dense vector of means "
+                         "(sa_job_t.event_stride; a quarter of the host memory traffic of sa_batch_create)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernels-only", action="store_true", help="phase 1 only (sa_batch_run on one resident batch): for "
+                                                                "profiler runs that count per-kernel launches")
+    ap.add_argument("--no-secondary", action="store_true", help="gaussian at N = 1 also measures `realistic` and `cpg` compactly "
+                                                                "(config.secondary) and a long steady-state run (config.long_run); "
+                                                                "this skips both")
+    ap.add_argument("--long-steps", type=int, default=200, help="steps of the long steady-state sample reported beside the "
+                                                                "K timed steps (config.long_run)")
+    ap.add_argument("--cpu-reads-per-thread", type=int, default=30)
+    args = ap.parse_args()
+    if args.reads is None:
+        args.reads = {"scaling": 12500, "hdp": 5000}.get(args.workload, 2000)   # hdp: BASELINE configs[3] names 5000 reads
+    if args.events is None:
+        args.events = 10000 if args.workload == "scaling" else 5000
+    if args.threshold is None:
+        args.threshold = 0.1 if args.workload == "hdp" else 0.01
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: become one (nothing in this process has touched or will touch the GPU)
+        sys.exit(self_launch(args.gpus))
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    device = 0
+    backend = os.environ.get("SA_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N > 1 path on a box with one GPU
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        device = local_rank % max(torch.cuda.device_count(), 1)  # identity on a full node
+        torch.cuda.set_device(device)
+        dist.init_process_group(backend=backend)  # RCCL; only used for the barrier and the max-over-ranks
+    if world > 1:
+        # Ranks of one node share the host (and, in a container, one CPU quota): the library sizes its host fan-out for a process
+        # that has the machine to itself, so every rank gets its share here.  (SA_HOST_THREADS / SA_PLAN_THREADS: DESIGN.md.)
+        info = host_cpu_info()
+        cpus = int(info["cgroup_cpu_quota"]) if info["cgroup_cpu_quota"] else len(info["allowed"])
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        share = max(2, min(16, cpus // max(local_world, 1) - 2))
+        os.environ.setdefault("SA_HOST_THREADS", str(share))
+        os.environ.setdefault("SA_PLAN_THREADS", str(share))
+    import signalalign_amd as sa
+    from signalalign_amd import synth
+
+    if args.workload in ("mea", "event_align", "expectations"):
+        # the two "next" rows are single-GPU side benchmarks: under a multi-rank launch only rank 0 runs them
+        if world > 1:
+            dist.barrier()
+            if rank != 0:
+                dist.destroy_process_group()
+                return
+        res = (bench_mea(args) if args.workload == "mea" else
+               bench_expectations(args) if args.workload == "expectations" else bench_event_align(args))
+        if world > 1:
+            dist.destroy_process_group()
+        return res
+    ctx = dict(dist=dist, rank=rank, world=world, device=device, backend=backend)
+    out = measure(args, ctx)
+    if out is not None and world == 1 and args.workload == "gaussian" and not args.kernels_only and not args.no_secondary:
+        # the other hot-path workloads, compactly, on the same line (a few seconds each): anchors as sparse as a real guide
+        # alignment leaves them (strip kernels) and configs[2] (several paths per cell, ring kernels)
+        import copy
+        out["config"]["secondary"] = {}
+        for wl in ("realistic", "cpg"):
+            a2 = copy.copy(args)
+            a2.workload, a2.reads, a2.events, a2.threshold = wl, 2000, 5000, 0.01
+            a2.steps, a2.warmup, a2.no_cpu_baseline = max(4, min(args.steps, 10)), 5, True   # (warm-up: three batches' pinned blocks)
+            r2 = measure(a2, ctx, compact=True)
+            rf = r2["roofline"]
+            out["config"]["secondary"][wl] = {
+                "workload": r2["config"]["workload"], "value": r2["value"], "ms_per_step": r2["ms_per_step"], "steps": r2["steps"],
+                "kernels_only_value": r2["config"]["kernels_only_resident_inputs"]["value"],
+                "kernel_ms": r2["config"]["kernel_ms"], "pairs_per_event": r2["config"]["pairs_per_event"],
+                "dominant_kernel": rf["kernel"], "roofline_frac": rf["frac"], "roofline_frac_by_counters": rf["frac_by_counters"],
+                "stage_ms": rf["stage_ms"]}
+    if out is not None:
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -35,6 +35,9 @@ for fname, src in (("instr_mix.json", "instr.json"), ("traffic.json", "traffic.j
             if isinstance(v, dict):
                 groups.setdefault(bare(k), []).append(v)
         merged[w] = {k: (vs[0] if len(vs) == 1 else merge(vs)) for k, vs in groups.items()}
+        import subprocess, time
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+        merged.setdefault("_meta", {})[w] = {"head": head, "collected": time.strftime("%Y-%m-%d %H:%M"), "tag": tag}
     json.dump(merged, open(path, "w"), indent=1)
     print("wrote", path)
 for w in workloads:

@@ -362,8 +362,11 @@ class Batch:
 def expect_batch(model, params, jobs, ambig=None, device=0, flags=0, pseudocount=0.0):
     """sa_expect_batch: per job the 3x3 transition expectations (from*3+to), the summed log-likelihood and the HDP
     assignments as (reference position, event index) arrays."""
-    n = len(jobs)
-    arr, keep = _make_jobs(jobs)
+    if isinstance(jobs, JobArray):
+        n, arr, keep = jobs.n, jobs.arr, jobs
+    else:
+        n = len(jobs)
+        arr, keep = _make_jobs(jobs)
     amb = ambig if ambig is not None else default_ambig()
     trans = np.full((max(n, 1), 9), pseudocount, dtype=np.float64)
     lik = np.zeros(max(n, 1), dtype=np.float64)

@@ -1882,7 +1882,7 @@ static int submit_group(sa_batch *b, const DevPlan &P, int g, int which_stream, 
     }
     for (int cl = 15; cl >= 0; cl--)   // widest (longest-running) classes first
         if (G.nrs[cl]) launch_bwd_ring(P, b->d_ids + G.ids_rs[cl], G.nrs[cl], st, 64 * ((cl & 7) + 1), cl >= 8);
-    if (G.nfs) launch_bwd_fast(P, b->d_ids + G.ids_fs, G.nfs, st);
+    if (G.nfs) launch_bwd_fast(P, b->d_ids + G.ids_fs, G.nfs, st, b->expect);
     HIPCHK(hipEventRecord(b->gev[4 * g + 1], st));
     if (G.ck1 > G.ck0)
         hipLaunchKernelGGL(k_fold, dim3((unsigned) ((G.ck1 - G.ck0 + 63) / 64)), dim3(64), 0, st, P, G.ck0, G.ck1);
@@ -2292,29 +2292,44 @@ int sa_expect_batch(const sa_model_t *m, const sa_params_t *p, const sa_job_t *j
                     sa_assignment_t **assign_out, int64_t *n_assign_out) {
     if (!trans9_out || !likelihood_out) return SA_EINVAL;
     sa_batch_t *b = nullptr;
-    int rc = sa_batch_create(&b, m, p, jobs, n_jobs, ambig, device,
-                             flags | SA_FLAG_FORCE_GENERIC | SA_FLAG_EXPECT_INTERNAL);
+    // regions with one path per cell take the register kernels' expectation variant (k_bwd_fast_expect, sa_fast.inc); several
+    // paths per cell, SA_FLAG_EXACT or SA_FLAG_FORCE_GENERIC: the memory-resident kernels (the checker of the former)
+    int rc = sa_batch_create(&b, m, p, jobs, n_jobs, ambig, device, flags | SA_FLAG_EXPECT_INTERNAL);
     if (rc) return rc;
     rc = run_passes(b);
     if (rc) { sa_batch_destroy(b); return rc; }
     const sa_plan_t *pl = b->plan;
-    std::vector<sa_cand_t> cands((size_t) (pl->n_cand > 0 ? pl->n_cand : 1));
-    std::vector<int> counts((size_t) (pl->n_segs > 0 ? pl->n_segs : 1));
-    std::vector<double> totals((size_t) (pl->n_cks > 0 ? pl->n_cks : 1)), gmc(totals.size()), gsum(8 * totals.size());
+    // what the host needs: totals, the groups' scaling maxima and sums, candidate counts and (HDP models: the assignment
+    // candidates -- 24 B x slots per posterior diagonal).  Into ONE pinned block (a copy to pageable memory moves 3 GB/s, and
+    // 1.6 million checkpoints of 2000 reads are 130 MB), then the per-read rescale on all host threads.
+    const bool want_cands = m->hdp != nullptr && assign_out != nullptr;
+    const size_t n_ck = (size_t) (pl->n_cks > 0 ? pl->n_cks : 1), n_sg = (size_t) (pl->n_segs > 0 ? pl->n_segs : 1);
+    const size_t o_tot = 0, o_gmc = o_tot + sa_up256(8 * n_ck), o_gsum = o_gmc + sa_up256(8 * n_ck), o_cnt = o_gsum + sa_up256(64 * n_ck);
+    const size_t o_cand = o_cnt + sa_up256(4 * n_sg);
+    const size_t host_bytes = o_cand + (want_cands ? sizeof(sa_cand_t) * (size_t) (pl->n_cand > 0 ? pl->n_cand : 1) : 0);
+    char *hb = nullptr;
+    if (g_sa_pool.get(SaPool::PINNED, (void **) &hb, host_bytes, b->device) != hipSuccess) { (void) hipGetLastError(); sa_batch_destroy(b); return SA_ENOMEM; }
     auto dl = [&](void *dst, const void *src, size_t bytes) -> int {
-        if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+        if (bytes) HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, b->stream));
         return SA_OK;
     };
-    rc = dl(cands.data(), b->d_cands, sizeof(sa_cand_t) * (size_t) pl->n_cand);
-    if (!rc) rc = dl(counts.data(), b->d_cand_count, 4 * (size_t) pl->n_segs);
-    if (!rc) rc = dl(totals.data(), b->d_totals, 8 * (size_t) pl->n_cks);
-    if (!rc) rc = dl(gmc.data(), b->d_gmc, 8 * (size_t) pl->n_cks);
-    if (!rc) rc = dl(gsum.data(), b->d_gsum, 64 * (size_t) pl->n_cks);
-    if (rc) { sa_batch_destroy(b); return rc; }
+    rc = dl(hb + o_tot, b->d_totals, 8 * (size_t) pl->n_cks);
+    if (!rc) rc = dl(hb + o_gmc, b->d_gmc, 8 * (size_t) pl->n_cks);
+    if (!rc) rc = dl(hb + o_gsum, b->d_gsum, 64 * (size_t) pl->n_cks);
+    if (!rc) rc = dl(hb + o_cnt, b->d_cand_count, 4 * (size_t) pl->n_segs);
+    if (!rc && want_cands) rc = dl(hb + o_cand, b->d_cands, sizeof(sa_cand_t) * (size_t) pl->n_cand);
+    if (!rc && sa_sync_stream(b->stream, b->device) != hipSuccess) rc = SA_ENODEVICE;
+    if (rc) { g_sa_pool.put(SaPool::PINNED, hb); sa_batch_destroy(b); return rc; }
+    const double *totals = reinterpret_cast<const double *>(hb + o_tot), *gmc = reinterpret_cast<const double *>(hb + o_gmc),
+                 *gsum = reinterpret_cast<const double *>(hb + o_gsum);
+    const int *counts = reinterpret_cast<const int *>(hb + o_cnt);
+    const sa_cand_t *cands = reinterpret_cast<const sa_cand_t *>(hb + o_cand);
     // (from, to) slots of hmm->transitions[from * 3 + to] in the order the kernel accumulates them
     static const int slot[7] = {0 * 3 + 1, 1 * 3 + 1, 0 * 3 + 0, 1 * 3 + 0, 2 * 3 + 0, 0 * 3 + 2, 2 * 3 + 2};
     const double thr = pl->params.threshold;
-    for (int64_t j = 0; j < n_jobs; j++) {
+    std::atomic<int> oom(0);
+    sa_parallel_for((size_t) n_jobs, [&](size_t jj) {
+        const int64_t j = (int64_t) jj;
         const sa_jobinfo_t *J = &pl->jobs[j];
         std::vector<sa_assignment_t> as;
         for (long long r = J->region_off; r < J->region_off + J->n_regions; r++) {
@@ -2331,7 +2346,7 @@ int sa_expect_batch(const sa_model_t *m, const sa_params_t *p, const sa_job_t *j
                     double sc = exp(gmc[S->ck_base + c] - total);
                     for (int k = 0; k < 7; k++) trans9_out[j * 9 + slot[k]] += gsum[8 * (S->ck_base + c) + k] * sc;
                 }
-                if (!assign_out) continue;
+                if (!want_cands) continue;
                 for (int i = 0; i < counts[sg]; i++) {
                     const sa_cand_t &cd = cands[S->cand_off + i];
                     long long e = (long long) cd.x + cd.y + 2;
@@ -2347,11 +2362,13 @@ int sa_expect_batch(const sa_model_t *m, const sa_params_t *p, const sa_job_t *j
         }
         if (assign_out) {
             assign_out[j] = (sa_assignment_t *) malloc(sizeof(sa_assignment_t) * (as.size() ? as.size() : 1));
-            if (!assign_out[j]) { sa_batch_destroy(b); return SA_ENOMEM; }
+            if (!assign_out[j]) { oom.store(1); return; }
             if (!as.empty()) memcpy(assign_out[j], as.data(), sizeof(sa_assignment_t) * as.size());
             if (n_assign_out) n_assign_out[j] = (int64_t) as.size();
         }
-    }
+    });
+    g_sa_pool.put(SaPool::PINNED, hb);
+    if (oom.load()) { sa_batch_destroy(b); return SA_ENOMEM; }
     sa_batch_destroy(b);
     return SA_OK;
 }

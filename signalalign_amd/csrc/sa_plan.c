@@ -738,7 +738,10 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
             ck->nB = e < S->start ? rows[e + 1].width : 0;
             pl->n_vbuf += ck->nA + ck->nB;
         }
-        int64_t cap = 2 * (S->from - S->to) + 64; /* measured: 0.54 pairs per diagonal at threshold 0.01; overflow re-runs with 4x */
+        /* measured: 0.54 pairs per diagonal at threshold 0.01 with Gaussian emissions; HDP densities as broad as the bundled
+         * model's leave the posteriors flat across the band (3-6 candidates per diagonal at threshold 0.1); overflow re-runs
+         * the pass with 4x */
+        int64_t cap = (m->hdp ? SA_CAND_PER_DIAG_HDP : SA_CAND_PER_DIAG) * (S->from - S->to) + 64;
         if (p->threshold <= 0.0) { /* everything passes: every cell-path of the posterior diagonals */
             cap = 64;
             for (int64_t e = S->to + 1; e <= S->from; e++) {
@@ -758,7 +761,9 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
     {   /* derived flags (the words behind diagonal N are zero) */
         int32_t *pk = pl->pk + R->pk_off + SA_PK_PAD;
         for (int64_t d = 0; d <= N; d++) {
-            if ((pk[d] & SA_PK_CK) || !(pk[d + 1] & SA_PK_FWD) || !(pk[d + 2] & SA_PK_FWD) || d + 2 > N)
+            /* (the expectation pass reads all three forward states of every diagonal: impl/pairwiseAligner.c:1423-1443) */
+            if ((pk[d] & SA_PK_CK) || !(pk[d + 1] & SA_PK_FWD) || !(pk[d + 2] & SA_PK_FWD) || d + 2 > N ||
+                (pl->flags & SA_FLAG_EXPECT_INTERNAL))
                 pk[d] |= SA_PK_FULL;
             if (d < N && (pk[d + 1] & SA_PK_FWD)) pk[d] |= SA_PK_FWD_MORE;
             if (d >= 1 && (pk[d - 1] & SA_PK_BWD)) pk[d] |= SA_PK_BWD_MORE;

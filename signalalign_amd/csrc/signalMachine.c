@@ -23,6 +23,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "sa_io.h"
@@ -311,8 +312,25 @@ static int estimate_strand(const strand_model_t *sm, const int64_t *strand_map, 
 }
 
 /* everything of impl/signalMachine.c:main between option parsing and performSignalAlignment, for one read */
+/* SA_CLI_TIMING=1: wall time of the three stages of every slice and the thread-seconds spent inside the host stage, printed
+ * at the end of the run (probes/batch_cli_timing.sh; INTEGRATION.md quotes them) */
+static double g_t_prep, g_t_gpu, g_t_render;                 /* wall seconds, summed over slices */
+static double g_ts_parse, g_ts_fetch, g_ts_estimate;         /* thread-seconds inside the host stage */
+static pthread_mutex_t g_t_mu = PTHREAD_MUTEX_INITIALIZER;
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
+}
+static void t_add(double *acc, double dt) {
+    pthread_mutex_lock(&g_t_mu);
+    *acc += dt;
+    pthread_mutex_unlock(&g_t_mu);
+}
+
 static int validate_read(const run_t *R, read_t *rd);
 static int prepare_read(const run_t *R, read_t *rd, int fatal) {
+    const double tp0 = now_s();
     if (rd->cigar_path == NULL) return fail(rd, fatal, "[signalMachine]ERROR: Need to provide input guide alignments, exiting", NULL);
     if (sa_cigar_load(rd->cigar_path, &rd->pA) != SA_OK)
         return fail(rd, fatal, "[signalMachine]ERROR: Didn't find input alignment file, looked %s", rd->cigar_path);
@@ -328,6 +346,8 @@ static int prepare_read(const run_t *R, read_t *rd, int fatal) {
         pA->start2 = np->template_read_length - pA->end2;
         pA->end2 = np->template_read_length - tmp;
     }
+    const double tp1 = now_s();
+    t_add(&g_ts_parse, tp1 - tp0);
     const char *seq_name = rd->seq_name ? rd->seq_name : pA->contig1;
     if (R->fwd_ref == NULL || seq_name == NULL)
         return fail(rd, fatal, "[signalMachine] ERROR: need -f <fasta> and -n <sequence name>", NULL);
@@ -383,6 +403,8 @@ static int prepare_read(const run_t *R, read_t *rd, int fatal) {
     rd->r_shift_c = R->two_d ? pA->end1 : 0;
     rd->forward = pA->strand1;
 
+    const double tp2 = now_s();
+    t_add(&g_ts_fetch, tp2 - tp1);
     /* anchors from the guide alignment (pA is rebased inside, impl/signalMachineUtils.c:142-164) */
     int64_t cap = 0;
     for (int64_t i = 0; i < pA->n_ops; i++) cap += pA->op_len[i];
@@ -429,6 +451,7 @@ static int prepare_read(const run_t *R, read_t *rd, int fatal) {
     }
     free(gx);
     free(gy);
+    t_add(&g_ts_estimate, now_s() - tp2);
     /* batch mode: the reads of a slice share one GPU batch, and the planner rejects a whole batch for one bad job (a
      * reference window with a letter outside the alphabet, anchors that give an invalid diagonal).  The reference runs one
      * process per read, so only that read may fail.  Alignment runs find the offender when -- and only when -- a batch is
@@ -451,7 +474,9 @@ static int validate_read(const run_t *R, read_t *rd) {
 typedef struct { const run_t *R; read_t *reads; const int64_t *who; } validate_ctx_t;
 static void validate_one(int64_t j, void *ctx) {
     validate_ctx_t *v = ctx;
-    (void) validate_read(v->R, &v->reads[v->who[j]]);
+    read_t *rd = &v->reads[v->who[j]];
+    if (validate_read(v->R, rd) != 0)
+        fprintf(stderr, "[signalMachine] ERROR: read %s skipped: %s\n", rd->label, rd->err);
 }
 
 static void set_hdp_expected(strand_model_t *sm) { /* stateMachine3_setModelToHdpExpectedValues, once per run */
@@ -653,11 +678,14 @@ static int64_t run_slice(run_t *Rp, read_t *reads, int64_t n_reads, int batch_mo
 #define R (*Rp)
     /* ---- host side of every read ---- */
     int64_t n_ok = 0;
+    const double ts0 = now_s();
     {
         prep_ctx_t pc = {&R, reads, !batch_mode};
         parallel_for(n_reads, prep_one, &pc);
         for (int64_t i = 0; i < n_reads; i++) n_ok += reads[i].failed ? 0 : 1;
     }
+    const double ts1 = now_s();
+    g_t_prep += ts1 - ts0;
     const strand_model_t *sms[2] = {&R.smt, &R.smc};
     const int n_strands = R.two_d ? 2 : 1;
 
@@ -763,6 +791,8 @@ static int64_t run_slice(run_t *Rp, read_t *reads, int64_t n_reads, int batch_mo
     }
 
     /* ---- outputs: rendered in parallel (one file per read), summary lines in read order ---- */
+    const double ts2 = now_s();
+    g_t_gpu += ts2 - ts1;
     double (*score)[2] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(*score));
     {
         out_job_t oc = {&R, reads, who, pairs, n_pairs, score, mea, n_mea};
@@ -781,6 +811,7 @@ static int64_t run_slice(run_t *Rp, read_t *reads, int64_t n_reads, int batch_mo
             if (R.mea) sa_free(mea[s][j]);
         }
     }
+    g_t_render += now_s() - ts2;
     int64_t n_failed = 0;
     for (int64_t i = 0; i < n_reads; i++) n_failed += reads[i].failed ? 1 : 0;
     for (int s = 0; s < n_strands; s++) { free(pairs[s]); free(n_pairs[s]); if (R.mea) { free(mea[s]); free(n_mea[s]); } }
@@ -955,5 +986,9 @@ int main(int argc, char **argv) {
     }
     if (batch_mode)
         fprintf(stderr, "[signalMachine] batch: %" PRId64 " of %" PRId64 " reads aligned\n", n_reads - n_failed, n_reads);
+    if (getenv("SA_CLI_TIMING"))
+        fprintf(stderr, "[signalMachine] timing: host stage %.3f s wall (thread-seconds: npRead+cigar parse %.3f, reference fetch "
+                        "%.3f, parameter estimation+anchors %.3f), GPU stage %.3f s wall, render+write %.3f s wall\n",
+                g_t_prep, g_ts_parse, g_ts_fetch, g_ts_estimate, g_t_gpu, g_t_render);
     return n_failed == 0 ? 0 : 1;
 }

@@ -44,6 +44,11 @@ def test_device_plan_equals_host_plan(monkeypatch):
     assert sa.dplan_compare(pm5, sa.default_params(), cases.synthetic_jobs(cases.MODEL_5MER, 6, 800, 1)) == 0
     hd = sa.Model.load(cases.MODEL_R73, cases.NHDP)
     assert sa.dplan_compare(hd, sa.default_params(), cases.synthetic_jobs(cases.MODEL_R73, 3, 900, 5)) == 0
+    # the expectation pass (sa_expect_batch's internal flag): every diagonal keeps all three forward states, no ring kernels
+    FLAG_EXPECT_INTERNAL = 0x10000
+    assert sa.dplan_compare(pm, sa.default_params(), jobs, flags=FLAG_EXPECT_INTERNAL) == 0
+    assert sa.dplan_compare(hd, sa.default_params(threshold=0.1), cases.synthetic_jobs(cases.MODEL_R73, 3, 900, 5),
+                            flags=FLAG_EXPECT_INTERNAL) == 0
 
 
 def test_device_plan_equals_host_plan_with_ambiguous_positions(monkeypatch):

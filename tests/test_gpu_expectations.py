@@ -86,3 +86,57 @@ def test_hdp_assignments(oracle):
         if got != exp:
             # only assignments whose probability sits on the threshold may differ
             assert abs(len(got) - len(exp)) <= 2 and len(set(got) ^ set(exp)) <= 2
+
+
+def test_register_kernel_expectations_against_the_memory_resident_checker(oracle):
+    """One path per cell: sa_expect_batch runs k_bwd_fast_expect (register sweeps; forward states of e-1 / e-2 in registers);
+    SA_FLAG_FORCE_GENERIC keeps the memory-resident kernels, the checker.  Both against the oracle at 1e-9, on dense anchors
+    (register sections), anchors thinned to a sixth (bands wider than a wave: the in-kernel memory-resident stretches), a read
+    with several traceback segments and checkpoint groups, a tiny read, and no anchors at all."""
+    pm, om = _models(oracle, cases.MODEL_6MER)
+    p = sa.default_params()
+    op = cases.oracle_params(oracle, p)
+    jobs = cases.synthetic_jobs(cases.MODEL_6MER, 2, 900, 300) + cases.synthetic_jobs(cases.MODEL_6MER, 1, 3100, 310)
+    jobs += cases.realistic_anchor_jobs(cases.MODEL_6MER, 1, 1200, 320)
+    jobs += cases.synthetic_jobs(cases.MODEL_6MER, 1, 30, 330)
+    bare = dict(jobs[0])
+    bare["ax"], bare["ay"] = bare["ax"][:0], bare["ay"][:0]
+    jobs.append(bare)
+    fast_t, fast_l, _ = sa.expect_batch(pm, p, jobs)
+    gen_t, gen_l, _ = sa.expect_batch(pm, p, jobs, flags=sa.FLAG_FORCE_GENERIC)
+    for j, job in enumerate(jobs):
+        t, l, _, _, _ = _oracle_expect(oracle, om, job, op)
+        np.testing.assert_allclose(fast_t[j], t, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(gen_t[j], t, rtol=1e-9, atol=1e-12)
+        assert abs(fast_l[j] - l) <= 1e-12 * abs(l) and abs(gen_l[j] - l) <= 1e-12 * abs(l)
+    # the register kernels really took these regions
+    b = sa.Batch(pm, p, jobs[:3])
+    assert b.stats().n_fast_regions == 3
+    b.close()
+
+
+def test_register_kernel_hdp_assignments_match_the_checker(oracle):
+    """HDP: the assignment lists (transitions into the match state at or above the threshold, reference order) of the register
+    kernels against the memory-resident kernels' and the oracle's, on the HDP workload's reads."""
+    pm, om = _models(oracle, cases.MODEL_R73, cases.NHDP)
+    pm.set_to_hdp_expected_values()
+    om.set_to_hdp_expected_values()
+    p = sa.default_params(threshold=0.05)
+    op = cases.oracle_params(oracle, p)
+    jobs = cases.hdp_jobs(2, 1100, 50, table5=pm.table5())
+    ft, fl, fa = sa.expect_batch(pm, p, jobs)
+    gt, gl, ga = sa.expect_batch(pm, p, jobs, flags=sa.FLAG_FORCE_GENERIC)
+    for j, job in enumerate(jobs):
+        t, l, pos, evs, st = _oracle_expect(oracle, om, job, op)
+        np.testing.assert_allclose(ft[j], t, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(gt[j], t, rtol=1e-6, atol=1e-9)
+        assert abs(fl[j] - l) <= 1e-9 * abs(l)
+        assert len(pos) > 20
+        a, g = [tuple(r) for r in fa[j].tolist()], [tuple(r) for r in ga[j].tolist()]
+        if a != g:   # the two device logs differ in the last bit: only assignments sitting on the threshold may differ
+            assert abs(len(a) - len(g)) <= 2 and len(set(a) ^ set(g)) <= 2
+        mean = np.asarray(job["events"], dtype=np.float64)[:, 0]
+        got = list(zip(fa[j][:, 0].tolist(), mean[fa[j][:, 1]].tolist()))
+        exp = list(zip(pos.tolist(), evs.tolist()))
+        if got != exp:
+            assert abs(len(got) - len(exp)) <= 2 and len(set(got) ^ set(exp)) <= 2
