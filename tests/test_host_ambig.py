@@ -40,3 +40,25 @@ def test_reference_ambig_model_fixture_and_errors(tmp_path):
     p.write_text("".join("%s\tAC\n" % chr(33 + (i % 90)) for i in range(400)))
     rc, arr = _load(str(p))
     assert rc == 0 and arr[ord("!")] == b"AC"
+
+
+def test_number_parser_rounds_like_strtod(tmp_path):
+    """The loaders parse decimal text with a one-multiplication fast path (sa_io.c:sa_atod) and fall back to strtod for anything
+    it cannot convert exactly: the values must equal Python's float() (correctly rounded, as glibc's strtod) bit for bit."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    toks = ["0", "-0.0", "1", "102.77682312", "1.17174478293", "0.001", "5e-324", "1e22", "1e23", "1.7976931348623157e308",
+            "123456789012345", "1234567890123456", "0.1234567890123456789", "9007199254740993", "4.35e-5", "6.02E+23",
+            "000012.5000", ".5", "5.", "-3.25e-7", "+2.5", "0.000000000000000000000123", "1e-22", "1e-23", "0x1p3", "inf"]
+    toks += ["%.*g" % (int(rng.integers(1, 18)), v) for v in rng.normal(0, 1, 400) * 10.0 ** rng.integers(-12, 12, 400)]
+    toks += ["%.6f" % v for v in rng.uniform(0, 200, 400)]
+    n_kmers = 4 ** 3
+    while len(toks) < 5 * n_kmers:
+        toks.append("1.5")
+    toks = toks[:5 * n_kmers]
+    path = tmp_path / "tiny.model"
+    path.write_text("3\t4\tACGT\t3\n" + "\t".join(["0.1"] * 10) + "\n" + "\t".join(toks) + "\n")
+    m = sa.Model.load(str(path))
+    got = np.array(m.table5())
+    exp = np.array([float(t) if not t.startswith("0x") else float.fromhex(t) for t in toks])
+    assert got.tobytes() == exp.tobytes()
