@@ -444,7 +444,8 @@ def measure(args, ctx, compact=False):
     # fits HBM together with room to spare -- a 10k-event slice or 10k reads with several paths per cell take half of
     # the card alone and go one at a time
     hbm_bytes = float(sa.device_memory(device)[1])
-    depth = max(1, min(args.in_flight, int(0.6 * hbm_bytes / max(1.25 * st0.f_bytes, 1.0))))
+    depth = max(1, min(args.in_flight, int(0.6 * hbm_bytes / max(1.25 * st0.f_bytes, 1.0)),
+                       int(0.8 * hbm_bytes / max(st0.device_bytes, 1.0))))   # (all working storage: candidate slots weigh as much as the planes with HDP models)
     if args.workload == "scaling":
         depth = 1
     # ... and only while a batch's pairs are a small part of the traffic: the HDP workload returns 4.3 GB of pairs per batch

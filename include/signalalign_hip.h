@@ -110,6 +110,8 @@ typedef struct sa_batch_stats {
                                 than a wave)                                           */
     int64_t n_strip_regions; /* of those: one-path regions swept in strips of 64 reference columns (register-resident,
                                 no barrier; sa_strip.inc)                               */
+    double device_bytes;     /* working storage of the batch in HBM: forward planes, emission plane (HDP), candidate and
+                                result slots, checkpoint buffers -- what a caller sizes its pipeline depth with */
 } sa_batch_stats_t;
 
 /* ---- model -------------------------------------------------------------------------------------

@@ -49,7 +49,8 @@ class BatchStats(C.Structure):
                 ("ms_backward", C.c_double), ("ms_fold", C.c_double), ("ms_total_device", C.c_double),
                 ("f_bytes", C.c_double), ("n_regions", C.c_int64), ("n_segments", C.c_int64),
                 ("n_checkpoints", C.c_int64), ("n_fast_regions", C.c_int64), ("n_chunks", C.c_int64),
-                ("n_groups", C.c_int64), ("n_ring_regions", C.c_int64), ("n_strip_regions", C.c_int64)]
+                ("n_groups", C.c_int64), ("n_ring_regions", C.c_int64), ("n_strip_regions", C.c_int64),
+                ("device_bytes", C.c_double)]
 
 
 class EaJob(C.Structure):

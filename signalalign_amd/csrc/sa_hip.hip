@@ -791,7 +791,7 @@ __global__ __launch_bounds__(1024) void k_scan(const int *in, long long *out, lo
 // the order of stList_pop + stable sort by x+y, impl/pairwiseAligner.c:2043-2050, impl/signalMachine.c:872)
 // seg_off: exclusive scan over the n_segs segments starting at seg0 (indexed from 0); out: first slot of that range
 __global__ __launch_bounds__(64) void k_gather(DevPlan P, int seg0, int n_segs, const long long *prob_e7,
-                                               const long long *seg_off, sa_pair_t *out) {
+                                               const long long *seg_off, sa_pair16_t *out) {
     if ((int) blockIdx.x >= n_segs) return;
     const int lseg = blockIdx.x;
     int seg = seg0 + lseg;
@@ -812,13 +812,8 @@ __global__ __launch_bounds__(64) void k_gather(DevPlan P, int seg0, int n_segs, 
             sa_cand_t c = P.cands[S->cand_off + i];
             long long k = done + rank;              // index in candidate order
             long long pos = seg_off[lseg] + (total - 1 - k);
-            sa_pair_t o;
-            o.prob_e7 = prob_e7[S->cand_off + i];
-            o.x = (int) (c.x + R->x1);
-            o.y = (int) (c.y + R->y1);
-            o.path = c.path;
-            o.kmer_id = pid[poff[c.x + 1] + c.path];
-            out[pos] = o;
+            out[pos] = sa_pair16_pack(prob_e7[S->cand_off + i], (int) (c.x + R->x1), (int) (c.y + R->y1), c.path,
+                                      pid[poff[c.x + 1] + c.path]);
         }
         done += __popcll(mask);
     }
@@ -922,7 +917,7 @@ struct sa_batch {
     unsigned seam_cap_bwd;   // records per seam array of the backward launches (a traceback segment is shorter than a region)
     long long seam_bwd_off;  // bytes: the forward launch's slots come first, then those of a pass's backward launches
     double *d_tab6; int *d_hdp_slot; double *d_hdp_y, *d_hdp_slope, *d_hdp_grid, *d_hdp_tab;
-    long long *d_prob; int *d_seg_pass; long long *d_seg_off; sa_pair_t *d_out;
+    long long *d_prob; int *d_seg_pass; long long *d_seg_off; sa_pair16_t *d_out;
     int *d_ids;  // region / segment id lists per launch
     long long cand_alloc;
     long long out_alloc;
@@ -938,11 +933,11 @@ struct sa_batch {
     long long *h_seg_off;          // pinned: per group n+1 exclusive offsets
     int *h_overflow;               // pinned
     // results
-    sa_pair_t *h_pairs;      // pinned host copy of all pairs, job after job
+    sa_pair16_t *h_pairs;    // pinned host copy of all pairs (packed, sa_internal.h), job after job
     long long h_pairs_cap, n_pairs_total;
     std::vector<long long> job_off;
     std::vector<long long> job_dev_off;   // where a job's pairs start in d_out (device finalisation only)
-    sa_pair_t *d_pairs_up;                // host-finalised pairs uploaded for a downstream device step (sa_batch_mea)
+    sa_pair16_t *d_pairs_up;              // host-finalised pairs uploaded for a downstream device step (sa_batch_mea)
     long long d_pairs_up_cap;
     bool ran;
     bool quiet;            // the last run returned SA_OK: it waited for everything it had queued, the batch's streams are idle
@@ -1554,8 +1549,10 @@ static int batch_finish_body(sa_batch *b) {
     up_lock.unlock();
     if (trace_c) fprintf(stderr, "[trace] create: inputs uploaded at %.1f ms\n", now_ms_c() - tc0);
     // working buffers
+    double working_bytes = 0;
     auto dalloc = [&](void **p_, long long bytes) -> int {
         HIPCHK(g_sa_pool.get(SaPool::DEVICE, p_, (size_t) (bytes > 0 ? bytes : 8), device));
+        working_bytes += (double) (bytes > 0 ? bytes : 8);
         return SA_OK;
     };
     TRY(dalloc((void **) &b->d_F, 24 * pl->max_chunk_cellpaths));
@@ -1728,7 +1725,7 @@ static int batch_finish_body(sa_batch *b) {
             return SA_ENOMEM;
         }
         if (!host_finalize) {
-            TRY(dalloc((void **) &b->d_out, (long long) sizeof(sa_pair_t) * pl->n_cand));
+            TRY(dalloc((void **) &b->d_out, (long long) sizeof(sa_pair16_t) * pl->n_cand));
             b->out_alloc = pl->n_cand;
         }
     }
@@ -1754,6 +1751,7 @@ static int batch_finish_body(sa_batch *b) {
     for (long long r = 0; r < pl->n_regions; r++)   // (HDP register-kernel regions: 8 B more per cell, the emission plane)
         fb += (m->hdp && pl->regions[r].kind == SA_KIND_FAST ? 32.0 : 24.0) * (double) pl->regions[r].f_cellpaths;
     b->stats.f_bytes = fb;
+    b->stats.device_bytes = working_bytes;
 #undef TRY
     // The pinned result buffer, from an estimate of the result size (measured: 0.9 pairs per event at the default threshold): taken
     // here and not at the start of the run, so that a stream of batches asks the pinned cache for its blocks in the same order in
@@ -1763,7 +1761,7 @@ static int batch_finish_body(sa_batch *b) {
     if (!(flags & SA_FLAG_EXACT) && !b->expect && b->h_pairs_cap == 0 && pl->params.threshold >= 0.005) {
         const long long total = (long long) (1.5 * (double) pl->n_ev) + 4096;
         const long long cap = total + total / 8 + 1024;
-        if (g_sa_pool.get(SaPool::PINNED, (void **) &b->h_pairs, sizeof(sa_pair_t) * (size_t) cap, device) == hipSuccess) b->h_pairs_cap = cap;
+        if (g_sa_pool.get(SaPool::PINNED, (void **) &b->h_pairs, sizeof(sa_pair16_t) * (size_t) cap, device) == hipSuccess) b->h_pairs_cap = cap;
         else { (void) hipGetLastError(); b->h_pairs = nullptr; }   // (the run asks again)
     }
     if (trace_c) fprintf(stderr, "[trace] create: done at %.1f ms\n", now_ms_c() - tc0);
@@ -2013,7 +2011,7 @@ static int grow_after_overflow(sa_batch *b) {
     if (b->d_out) {
         g_sa_pool.put(SaPool::DEVICE, b->d_out);
         b->d_out = nullptr;
-        HIPCHK(g_sa_pool.get(SaPool::DEVICE, (void **) &b->d_out, sizeof(sa_pair_t) * (size_t) pl->n_cand, b->device));
+        HIPCHK(g_sa_pool.get(SaPool::DEVICE, (void **) &b->d_out, sizeof(sa_pair16_t) * (size_t) pl->n_cand, b->device));
         b->out_alloc = pl->n_cand;
     }
     HIPCHK(hipMemcpy(b->d_segs, pl->segs, sizeof(sa_seg_t) * (size_t) pl->n_segs, hipMemcpyHostToDevice));
@@ -2057,7 +2055,7 @@ static int batch_run_body(sa_batch_t *b) {
             g_sa_pool.put(SaPool::PINNED, b->h_pairs);
             b->h_pairs = nullptr;
             long long cap = total + total / 8 + 1024;
-            HIPCHK(g_sa_pool.get(SaPool::PINNED, (void **) &b->h_pairs, sizeof(sa_pair_t) * (size_t) cap, b->device));
+            HIPCHK(g_sa_pool.get(SaPool::PINNED, (void **) &b->h_pairs, sizeof(sa_pair16_t) * (size_t) cap, b->device));
             b->h_pairs_cap = cap;
         }
         return SA_OK;
@@ -2090,7 +2088,8 @@ static int batch_run_body(sa_batch_t *b) {
         total = 0;
         for (long long j = 0; j < pl->n_jobs; j++) {
             b->job_off[j] = total;
-            if (np[j]) memcpy(b->h_pairs + total, pp[j], sizeof(sa_pair_t) * (size_t) np[j]);
+            for (int64_t q = 0; q < np[j]; q++)
+                b->h_pairs[total + q] = sa_pair16_pack(pp[j][q].prob_e7, pp[j][q].x, pp[j][q].y, pp[j][q].path, pp[j][q].kmer_id);
             total += np[j];
             free(pp[j]);
         }
@@ -2120,7 +2119,7 @@ static int batch_run_body(sa_batch_t *b) {
             if (piped && running + tg <= b->h_pairs_cap) {
                 if (tg > 0)
                     HIPCHK(hipMemcpyAsync(b->h_pairs + running, b->d_out + pl->segs[G.seg0].cand_off,
-                                          sizeof(sa_pair_t) * (size_t) tg, hipMemcpyDeviceToHost, b->pair_stream));
+                                          sizeof(sa_pair16_t) * (size_t) tg, hipMemcpyDeviceToHost, b->pair_stream));
             } else {
                 piped = false;  // first run (or a larger result than last time): size the pinned buffer afterwards
             }
@@ -2150,7 +2149,7 @@ static int batch_run_body(sa_batch_t *b) {
                 long long tg = gbase[g + 1] - gbase[g];
                 if (tg > 0)
                     HIPCHK(hipMemcpyAsync(b->h_pairs + gbase[g], b->d_out + pl->segs[G.seg0].cand_off,
-                                          sizeof(sa_pair_t) * (size_t) tg, hipMemcpyDeviceToHost, b->pair_stream));
+                                          sizeof(sa_pair16_t) * (size_t) tg, hipMemcpyDeviceToHost, b->pair_stream));
             }
             HIPCHK(sa_sync_stream(b->pair_stream, b->device));
         }
@@ -2186,7 +2185,7 @@ static int batch_run_body(sa_batch_t *b) {
 
 // Device-side view of the results for a downstream device step (sa_mea.hip): per job the first pair in *pairs and the
 // number of pairs and of events.  After host finalisation (SA_FLAG_EXACT) the pairs are uploaded once.
-int sa_batch_device_view(sa_batch_t *b, const sa_pair_t **pairs, std::vector<long long> *first, std::vector<long long> *count,
+int sa_batch_device_view(sa_batch_t *b, const sa_pair16_t **pairs, std::vector<long long> *first, std::vector<long long> *count,
                          std::vector<long long> *n_events, int *device) {
     if (!b || !pairs || !first || !count || !n_events || !device) return SA_EINVAL;
     if (!b->ran) return SA_ESTATE;
@@ -2207,11 +2206,11 @@ int sa_batch_device_view(sa_batch_t *b, const sa_pair_t **pairs, std::vector<lon
     if (b->n_pairs_total > b->d_pairs_up_cap) {
         g_sa_pool.put(SaPool::DEVICE, b->d_pairs_up);
         b->d_pairs_up = nullptr; b->d_pairs_up_cap = 0;
-        HIPCHK(g_sa_pool.get(SaPool::DEVICE, (void **) &b->d_pairs_up, sizeof(sa_pair_t) * (size_t) b->n_pairs_total, b->device));
+        HIPCHK(g_sa_pool.get(SaPool::DEVICE, (void **) &b->d_pairs_up, sizeof(sa_pair16_t) * (size_t) b->n_pairs_total, b->device));
         b->d_pairs_up_cap = b->n_pairs_total;
     }
     if (b->n_pairs_total)
-        HIPCHK(hipMemcpy(b->d_pairs_up, b->h_pairs, sizeof(sa_pair_t) * (size_t) b->n_pairs_total, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(b->d_pairs_up, b->h_pairs, sizeof(sa_pair16_t) * (size_t) b->n_pairs_total, hipMemcpyHostToDevice));
     *pairs = b->d_pairs_up;
     for (size_t j = 0; j < nj; j++) (*first)[j] = b->job_off[j];
     return SA_OK;
@@ -2249,7 +2248,8 @@ int sa_batch_pairs(const sa_batch_t *b, int64_t job, sa_pair_t *out, int64_t cap
     if (!b->ran) return SA_ESTATE;
     long long n = b->job_off[job + 1] - b->job_off[job];
     if (n > cap) return SA_EINVAL;
-    if (n > 0) memcpy(out, b->h_pairs + b->job_off[job], sizeof(sa_pair_t) * (size_t) n);
+    const sa_pair16_t *src = b->h_pairs + b->job_off[job];
+    for (long long i = 0; i < n; i++) out[i] = sa_pair16_unpack(src[i]);
     return SA_OK;
 }
 int sa_batch_stats(const sa_batch_t *b, sa_batch_stats_t *out) {

@@ -882,13 +882,13 @@ __device__ __forceinline__ bool mea_next_cell(const int *sr, const int *sp, int 
     return true;
 }
 
-__global__ __launch_bounds__(64) void k_mea_from_pairs(const sa_pair_t *__restrict__ pairs, const MeaChain *__restrict__ chain,
+__global__ __launch_bounds__(64) void k_mea_from_pairs(const sa_pair16_t *__restrict__ pairs, const MeaChain *__restrict__ chain,
                                                        MeaPlan P, int *fill, int *s_ref, int *s_prob, int *n_dev, int *mins,
                                                        int n_jobs) {
     const int jb = blockIdx.x, lane = threadIdx.x;
     const MeaChain C = chain[jb];
     const MeaJob J = P.jobs[jb];
-    const sa_pair_t *pr = pairs + C.pair_off;
+    const sa_pair16_t *pr = pairs + C.pair_off;   // packed result records (sa_internal.h)
     int *fl = fill + J.sh_off, *sr = s_ref + J.off, *sp = s_prob + J.off;
     int *rows = const_cast<int *>(P.rows) + J.off, *cols = const_cast<int *>(P.cols) + J.off;
     double *data = const_cast<double *>(P.data) + J.off;
@@ -896,7 +896,8 @@ __global__ __launch_bounds__(64) void k_mea_from_pairs(const sa_pair_t *__restri
     const int n = C.n_raw;
     int xmin = 0x7fffffff, ymin = 0x7fffffff, ymax = -0x7fffffff;
     for (int j = lane; j < n; j += 64) {
-        const int x = (int) pr[j].x, y = (int) pr[j].y;
+        const sa_pair_t pj = sa_pair16_unpack(pr[j]);
+        const int x = (int) pj.x, y = (int) pj.y;
         xmin = min(xmin, x); ymin = min(ymin, y); ymax = max(ymax, y);
     }
     xmin = wave_min(xmin); ymin = wave_min(ymin); ymax = wave_max_i(ymax);
@@ -908,7 +909,7 @@ __global__ __launch_bounds__(64) void k_mea_from_pairs(const sa_pair_t *__restri
     // rows per event -> bucket starts -> rows placed by event (order inside a bucket is irrelevant: mea_next_cell)
     for (int e = lane; e < n_ev; e += 64) fl[e] = 0;
     __threadfence();
-    for (int j = lane; j < n; j += 64) atomicAdd(&fl[(int) pr[j].y - ymin], 1);
+    for (int j = lane; j < n; j += 64) atomicAdd(&fl[(int) sa_pair16_unpack(pr[j]).y - ymin], 1);
     __threadfence();
     int carry = 0;
     for (int base = 0; base < n_ev; base += 64) {
@@ -920,9 +921,10 @@ __global__ __launch_bounds__(64) void k_mea_from_pairs(const sa_pair_t *__restri
     }
     __threadfence();
     for (int j = lane; j < n; j += 64) {
-        const int pos = atomicAdd(&fl[(int) pr[j].y - ymin], 1);   // fl[e] ends as the END of bucket e
-        sr[pos] = (int) pr[j].x - xmin;
-        sp[pos] = (int) pr[j].prob_e7;
+        const sa_pair_t pj = sa_pair16_unpack(pr[j]);
+        const int pos = atomicAdd(&fl[(int) pj.y - ymin], 1);   // fl[e] ends as the END of bucket e
+        sr[pos] = (int) pj.x - xmin;
+        sp[pos] = (int) pj.prob_e7;
     }
     __threadfence();
     // the COO matrix, events ascending, reference positions ascending inside an event, zeros dropped
@@ -986,7 +988,7 @@ extern "C" int sa_batch_mea(sa_batch_t *b, unsigned flags, sa_mea_pair_t **path_
     const bool trace = getenv("SA_TRACE") != nullptr;
     auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double t0 = now_ms();
-    const sa_pair_t *d_pairs = nullptr;
+    const sa_pair16_t *d_pairs = nullptr;
     std::vector<long long> first, count, n_events;
     int device = 0;
     int rc = sa_batch_device_view(b, &d_pairs, &first, &count, &n_events, &device);

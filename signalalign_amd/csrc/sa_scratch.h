@@ -251,7 +251,7 @@ extern SaPool g_sa_pool;
 
 // sa_hip.hip: device-side view of a finished batch for a downstream device step (per job: first pair in *pairs, number
 // of pairs, number of events)
-int sa_batch_device_view(sa_batch_t *b, const sa_pair_t **pairs, std::vector<long long> *first, std::vector<long long> *count,
+int sa_batch_device_view(sa_batch_t *b, const sa_pair16_t **pairs, std::vector<long long> *first, std::vector<long long> *count,
                          std::vector<long long> *n_events, int *device);
 
 // Worker threads of the host fan-out below, started on first use and parked between calls: a fresh std::thread per worker and
