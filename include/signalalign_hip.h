@@ -92,6 +92,10 @@ typedef struct sa_pair {
     int32_t kmer_id; /* kmer_id() of the path's k-mer                                  */
 } sa_pair_t;
 
+/* Test hook (host only): `in` through the packed 16-byte record results travel in between HBM and sa_batch_pairs (x, y < 2^28,
+ * prob_e7 <= 1e7 < 2^24, path < 2^16) and back into `out`. */
+int sa_pair_roundtrip(const sa_pair_t *in, sa_pair_t *out, int64_t n);
+
 typedef struct sa_batch_stats {
     double cells_forward;    /* sum over forward diagonals of width*paths           */
     double cells_backward;   /* ditto for backward diagonals actually computed      */

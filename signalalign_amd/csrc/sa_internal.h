@@ -20,7 +20,7 @@ extern "C" {
 #define SA_FLAG_EXPECT_INTERNAL 0x10000u /* sa_expect_batch: expectation pass instead of posteriors */
 #define SA_FLAG_DEVICE_XC_INTERNAL 0x20000u /* sa_batch_create: the emission constants (xc) are filled on the device; the
                                              * planner leaves pl->xc NULL */
-#define SA_CAND_PER_DIAG 2            /* planned candidate slots per posterior diagonal of a traceback (+64 per segment) */
+#define SA_CAND_PER_DIAG 2            /* planned candidate slots per posterior diagonal of a traceback (+32 diagonals' worth per segment) */
 #define SA_CAND_PER_DIAG_HDP 8
 #define SA_CAND_EPS 1e-6              /* slack of the on-device candidate filter (see sa_hip.hip) */
 

@@ -46,6 +46,13 @@ const char *sa_strerror(int code) {
 const char *sa_version(void) { return "signalalign_hip 0.1 (gfx950)"; }
 void sa_free(void *p) { free(p); }
 
+/* test hook (host only): pairs through the 16-byte record they cross PCIe in (sa_internal.h) and back */
+int sa_pair_roundtrip(const sa_pair_t *in, sa_pair_t *out, int64_t n) {
+    if (!in || !out || n < 0) return SA_EINVAL;
+    for (int64_t i = 0; i < n; i++) out[i] = sa_pair16_unpack(sa_pair16_pack(in[i].prob_e7, in[i].x, in[i].y, in[i].path, in[i].kmer_id));
+    return SA_OK;
+}
+
 /* ---- model ------------------------------------------------------------------------------------ */
 static void sort_chars(char *s, int n) {
     for (int i = 1; i < n; i++) {
@@ -741,7 +748,7 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
         /* measured: 0.54 pairs per diagonal at threshold 0.01 with Gaussian emissions; HDP densities as broad as the bundled
          * model's leave the posteriors flat across the band (3-6 candidates per diagonal at threshold 0.1); overflow re-runs
          * the pass with 4x */
-        int64_t cap = (m->hdp ? SA_CAND_PER_DIAG_HDP : SA_CAND_PER_DIAG) * (S->from - S->to) + 64;
+        int64_t cap = (m->hdp ? SA_CAND_PER_DIAG_HDP : SA_CAND_PER_DIAG) * (S->from - S->to + 32);   /* (the 32: short tracebacks at a read's end) */
         if (p->threshold <= 0.0) { /* everything passes: every cell-path of the posterior diagonals */
             cap = 64;
             for (int64_t e = S->to + 1; e <= S->from; e++) {

@@ -62,3 +62,23 @@ def test_number_parser_rounds_like_strtod(tmp_path):
     got = np.array(m.table5())
     exp = np.array([float(t) if not t.startswith("0x") else float.fromhex(t) for t in toks])
     assert got.tobytes() == exp.tobytes()
+
+
+def test_result_pairs_survive_the_16_byte_record():
+    """Pairs cross PCIe as 16-byte records (signalalign_amd/csrc/sa_internal.h: x and y in 28 bits, prob_e7 in 24, path in 16,
+    kmer_id in 32) and sa_batch_pairs expands them: the extremes of every field and random values come back unchanged."""
+    import numpy as np
+    rng = np.random.default_rng(11)
+    n = 5000
+    a = np.zeros(n, dtype=_capi.PAIR_DTYPE)
+    a["prob_e7"] = rng.integers(0, 10_000_001, n)
+    a["x"] = rng.integers(0, 1 << 28, n)
+    a["y"] = rng.integers(0, 1 << 28, n)
+    a["path"] = rng.integers(0, 1 << 16, n)
+    a["kmer_id"] = rng.integers(0, (1 << 31) - 1, n)
+    a[0] = (10_000_000, (1 << 28) - 1, (1 << 28) - 1, 65535, (1 << 31) - 1)
+    a[1] = (0, 0, 0, 0, 0)
+    a[2] = (100_000, 3000, 5000, 728, 46655)          # hdCell worst case: 729 paths (tests/signalPairwiseAlignerTest.c:543-568)
+    b = np.zeros(n, dtype=_capi.PAIR_DTYPE)
+    rc = _capi.lib().sa_pair_roundtrip(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), C.c_int64(n))
+    assert rc == 0 and a.tobytes() == b.tobytes()
