@@ -140,3 +140,23 @@ def test_register_kernel_hdp_assignments_match_the_checker(oracle):
         exp = list(zip(pos.tolist(), evs.tolist()))
         if got != exp:
             assert abs(len(got) - len(exp)) <= 2 and len(set(got) ^ set(exp)) <= 2
+
+
+def test_register_kernel_expectations_in_several_forward_storage_passes(oracle, monkeypatch):
+    """The expectation batch keeps all three forward planes; with a small forward-storage budget it runs in several passes
+    (regions packed into chunks) and must give the same numbers as in one."""
+    pm, om = _models(oracle, cases.MODEL_6MER)
+    p = sa.default_params()
+    jobs = cases.synthetic_jobs(cases.MODEL_6MER, 6, 800, 400)
+    one_t, one_l, _ = sa.expect_batch(pm, p, jobs)
+    monkeypatch.setenv("SA_F_BUDGET_CELLPATHS", "120000")
+    b = sa.Batch(pm, p, jobs)
+    assert b.stats().n_chunks >= 2
+    b.close()
+    many_t, many_l, _ = sa.expect_batch(pm, p, jobs)
+    monkeypatch.delenv("SA_F_BUDGET_CELLPATHS")
+    np.testing.assert_allclose(many_t, one_t, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(many_l, one_l, rtol=1e-14, atol=0)
+    op = cases.oracle_params(oracle, p)
+    t, l, _, _, _ = _oracle_expect(oracle, om, jobs[0], op)
+    np.testing.assert_allclose(many_t[0], t, rtol=1e-9, atol=1e-12)
