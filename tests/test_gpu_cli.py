@@ -280,6 +280,43 @@ def test_signalmachine_rna(oracle, tmp_path):
     assert vrows and all(v[4] == "t" and v[5] == "forward" for v in vrows)
 
 
+def test_signalmachine_two_d_read_against_the_reference_output(oracle, tmp_path):
+    """The reference's own output for the bundled 2-D read (tests/test_alignments/zymo_C_test_alignments_sm3/...7f22f937...,
+    600 rows committed under tests/golden/format/) against this signalMachine run on the same read (--twoD, template and
+    complement models, ZYMO contig, guide alignment from the reference's lastz): rows are matched by (strand, reference
+    position, event, k-mer) and the seven columns that do not depend on the HMM's parameters -- event mean after the drift
+    correction, noise, duration, scaled model mean and noise, descaled event mean, model mean -- must be the reference's bytes.
+    (The posterior column cannot be: the golden file was written with model parameters the tree does not hold; see
+    tests/test_host_golden_columns.py.)  At least 80 % of the golden rows must have a partner."""
+    import json
+    gold = [l.rstrip("\n").split("\t") for l in open(os.path.join(cases.GOLDEN, "format", "zymo_C_sm3_7f22f937.forward.t300_c300.tsv"))]
+    cig = json.load(open(os.path.join(cases.GOLDEN, "cigars", "zymoC_lastz_anchors.json")))["calls"][0]["cigars"][0].split()
+    # lastz writes "cigar: query s e + target s e + score ops": the same field order signalMachine reads (read first)
+    cigar = str(tmp_path / "guide.cigar")
+    with open(cigar, "w") as f:
+        f.write(" ".join(["cigar:", "read2d"] + cig[2:5] + ["ZYMO"] + cig[6:]) + "\n")
+    fasta = os.path.join(cases.GOLDEN, "sequences", "zymo_sequence.fasta")
+    out = str(tmp_path / "twod.tsv")
+    npread = os.path.join(cases.GOLDEN, "npReads", "ZymoC_ch_1_file1.npRead")
+    model_c = os.path.join(cases.GOLDEN, "models", "testModelR73_acegot_complement.model")
+    pr = subprocess.run([BIN, "-T", cases.MODEL_R73, "-C", model_c, "-q", npread, "-f", fasta, "-n", "ZYMO", "-p", cigar, "-u", out,
+                         "-L", gold[0][3], "--twoD", "-s", "0", "-g", "100"], capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr
+    mine = {}
+    for l in open(out):
+        g = l.rstrip("\n").split("\t")
+        mine[(g[4], g[1], g[5], g[15])] = g
+    hit = 0
+    for g in gold:
+        m = mine.get((g[4], g[1], g[5], g[15]))
+        if m is None:
+            continue
+        hit += 1
+        assert [m[i] for i in (0, 2, 3, 6, 7, 8, 9, 10, 11, 13, 14)] == [g[i] for i in (0, 2, 3, 6, 7, 8, 9, 10, 11, 13, 14)], (m, g)
+    assert hit >= 0.8 * len(gold), hit
+    assert any(g[4] == "c" for g in gold) and any(k[0] == "c" for k in mine)
+
+
 def test_signalmachine_expectations_file(oracle, tmp_path):
     # -t: the .expectations file of continuousPairHmm_writeToFile (impl/continuousHmm.c:352-408)
     model = cases.MODEL_6MER
