@@ -132,6 +132,19 @@ int sa_model_alphabet(const sa_model_t *m, char *out64, int *n_alpha, int *k);
 const double *sa_model_table5(const sa_model_t *m);        /* EMISSION_MATCH_MATRIX view */
 int sa_model_set_to_hdp_expected_values(sa_model_t *m);    /* impl/stateMachine.c:1275-1304 */
 int64_t sa_kmer_id(const sa_model_t *m, const char *kmer); /* impl/nanopore_hdp.c:405-410 */
+/* Which match / gapY emission a Gaussian model uses (the function pointers stateMachine3_construct takes, inc/stateMachine.h):
+ *   SA_EMISSION_MEAN_ONLY  emissions_signal_strawManGetKmerEventMatchProbWithDescaling_MeanOnly (impl/stateMachine.c:557-605),
+ *                          what signalMachine installs (impl/signalMachine.c:337); every kernel family
+ *   SA_EMISSION_TWO_DIST   emissions_signal_strawManGetKmerEventMatchProbWithDescaling (:607-650): Gaussian on the descaled mean
+ *                          x inverse Gaussian on the event noise -- what the reference's shipped output files were written with
+ *                          (tests/test_oracle_reference_outputs.py).  Reference-ordered memory-resident kernels only
+ *                          (the batch behaves as with SA_FLAG_EXACT); jobs must hand over event records (event_stride >= 2: the
+ *                          noise is a record's second value); the noise columns are the MODEL's, so the reads of a batch share
+ *                          one noise scaling (the reference rescales them per read, emissions_signal_scaleNoise: create the
+ *                          model from the rescaled table sa_estimate_params leaves). */
+#define SA_EMISSION_MEAN_ONLY 0
+#define SA_EMISSION_TWO_DIST 1
+int sa_model_set_emission(sa_model_t *m, int emission);
 
 /* ambiguity table: 256 entries (index = character), NULL = not ambiguous.
  * sa_default_ambig fills create_ambig_bases() (impl/pairwiseAligner.c:32-65);

@@ -45,6 +45,8 @@ struct DevModel {
     long long pow_km1;
     int n_alpha;
     int hdp;
+    int emission;           // 0: MeanOnly (what signalMachine installs); 1: the two-distribution emission (sa_model_set_emission)
+    const double *noise3;   // emission 1: per k-mer noise mean, noise lambda, log(lambda)  (columns 2 and 4 of the model table)
     const int *hdp_slot;    // per k-mer: row of y/slope tables of the first observed ancestor, -1 if none
     const double *hdp_y, *hdp_slope, *hdp_grid;
     const double *hdp_tab;  // register kernels: {y[i], slope[i]} interleaved, one row per observed process
@@ -63,6 +65,7 @@ struct DevPlan {
     const double *xc;
     const sa_prec_t *prec; // per cell-path records of SA_KIND_RING regions with several paths per cell
     const double *ev;
+    const double *evn;    // two-distribution emission only: per event its noise and log(noise) (C library's log, from the host)
     const sa_seg_t *segs;
     const sa_ck_t *cks;
     double *F;
@@ -103,6 +106,7 @@ __device__ __forceinline__ double la_exact(double x, double y) {
 // ---------------------------------------------------------------------------------------------------
 struct ReadPar {
     double scale, shift, var, lvar;
+    const double *evn;   // the region's {noise, log noise} pairs (two-distribution emission), else nullptr
 };
 
 __device__ __forceinline__ double hdp_interp(const DevModel &m, int slot, double q) {
@@ -124,11 +128,25 @@ __device__ __forceinline__ double hdp_interp(const DevModel &m, int slot, double
 }
 
 // match != 0: EMISSION_MATCH_MATRIX; == 0: EMISSION_GAP_Y_MATRIX (sd * 1.75).  id < 0: NULL k-mer.
-__device__ __forceinline__ double emit_ref(const DevModel &m, const ReadPar &rp, int id, double e, int match) {
+// yi: index of the event (matrix row - 1), read by the two-distribution emission only
+__device__ __forceinline__ double emit_ref(const DevModel &m, const ReadPar &rp, int id, double e, int match, long long yi) {
     if (id < 0) return NEG_INF;
     const double *t = m.tab6 + 6ll * id;
     double mu = t[0];
     double en = (e + rp.var * mu - rp.scale * mu - rp.shift) / rp.var;
+    if (m.emission == 1) {
+        // emissions_signal_strawManGetKmerEventMatchProbWithDescaling (impl/stateMachine.c:607-650): logGaussPdf of the descaled
+        // mean + logInvGaussPdf of the event noise (:296-306, :320-330), in the reference's order of operations
+        double sd = match ? t[1] : t[3];
+        double c = match ? t[2] : t[4];  // -log(sqrt(2 pi)) - log(sd); -inf when sd == 0
+        double a = (en - mu) / sd;
+        double l1 = c + (-0.5 * a * a);
+        double n = rp.evn[2 * yi], l_n = rp.evn[2 * yi + 1];
+        const double *nz = m.noise3 + 3ll * id;
+        double a2 = (n - nz[0]) / nz[0];
+        double l2 = (nz[2] - 1.8378770664093453 - 3 * l_n - nz[1] * a2 * a2 / n) / 2;
+        return l1 + l2;
+    }
     if (m.hdp) {
         int slot = m.hdp_slot[id];
         if (slot < 0) return NEG_INF;
@@ -229,8 +247,8 @@ __device__ __forceinline__ void fwd_generic_cellpath(const DevModel &m, const Re
         if (RELAX) {
             emit_gauss(xc4[g], e, eM, eY);
         } else {
-            eM = has_mid ? emit_ref(m, rp, id, e, 1) : NEG_INF;
-            eY = has_up ? emit_ref(m, rp, id, e, 0) : NEG_INF;
+            eM = has_mid ? emit_ref(m, rp, id, e, 1, y - 1) : NEG_INF;
+            eY = has_up ? emit_ref(m, rp, id, e, 0, y - 1) : NEG_INF;
         }
         if (has_lo) {
             double eP = (m.hdp || id >= 0) ? SA_LOG_GAPX : NEG_INF;
@@ -292,7 +310,7 @@ __global__ __launch_bounds__(128) void k_fwd_generic(DevPlan P, const int *regio
     const double *ev = P.ev + R->ev_off;
     double *F = P.F + 3 * R->f_base;
     const DevModel &m = P.m;
-    ReadPar rp = {R->scale, R->shift, R->var, R->lvar};
+    ReadPar rp = {R->scale, R->shift, R->var, R->lvar, P.evn ? P.evn + 2 * R->ev_off : nullptr};
     const long long N = R->N;
 
     {   // diagonal 0: startStateProb / raggedStartStateProb (impl/stateMachine.c:1134-1143)
@@ -391,7 +409,7 @@ __global__ __launch_bounds__(128) void k_bwd_generic(DevPlan P, const int *seg_i
     const double *ev = P.ev + R->ev_off;
     const double *F = P.F + 3 * R->f_base;
     const DevModel &m = P.m;
-    ReadPar rp = {R->scale, R->shift, R->var, R->lvar};
+    ReadPar rp = {R->scale, R->shift, R->var, R->lvar, P.evn ? P.evn + 2 * R->ev_off : nullptr};
     // backward rows: the LDS ring for diagonals of at most ring_cap cell-paths, the global ring for the others
     const long long grow = R->max_rowpaths;
     double *gring = P.bscratch + S->bscratch_off;  // 3 rows x grow x 3
@@ -459,7 +477,7 @@ __global__ __launch_bounds__(128) void k_bwd_generic(DevPlan P, const int *seg_i
                         if (legal_any<RELAX>(m, inv_pow, inv_alpha, idq, idn[p])) {
                             double eP, eU;
                             if (RELAX) emit_gauss(xc4[poff[x + 1] + p], e_next, eP, eU);
-                            else eP = emit_ref(m, rp, idn[p], e_next, 1);
+                            else eP = emit_ref(m, rp, idn[p], e_next, 1, y);
                             double c = cm[3 * p + 0];
                             tm = la_any<RELAX>(LT, tm, c + (eP + m.t_mm));
                             tx = la_any<RELAX>(LT, tx, c + (eP + m.t_xm));
@@ -468,7 +486,7 @@ __global__ __launch_bounds__(128) void k_bwd_generic(DevPlan P, const int *seg_i
                 if (has_up) {
                     double eP, eU;
                     if (RELAX) emit_gauss(xc4[g], e_next, eU, eP);
-                    else eP = emit_ref(m, rp, idq, e_next, 0);
+                    else eP = emit_ref(m, rp, idq, e_next, 0, y);
                     double c = cu[3 * q + 2];
                     tm = la_any<RELAX>(LT, tm, c + (eP + m.t_my));
                     ty = la_any<RELAX>(LT, ty, c + (eP + m.t_yy));
@@ -602,7 +620,7 @@ __global__ __launch_bounds__(128) void k_bwd_generic(DevPlan P, const int *seg_i
                             }
                     }
                     if (has_mid) {
-                        double eP = emit_ref(m, rp, idp, e_cur, 1);
+                        double eP = emit_ref(m, rp, idp, e_cur, 1, y - 1);
                         for (int q = 0; q < nl; q++)
                             if (legal_step(m, idl[q], idp)) {
                                 double v2 = fm[3 * q + 0] + cb[3 * p + 0] + (eP + m.t_mm);
@@ -615,7 +633,7 @@ __global__ __launch_bounds__(128) void k_bwd_generic(DevPlan P, const int *seg_i
                             }
                     }
                     if (has_up) {
-                        double eP = emit_ref(m, rp, idp, e_cur, 0);
+                        double eP = emit_ref(m, rp, idp, e_cur, 0, y - 1);
                         acc[5] += exp(fu[3 * p + 0] + cb[3 * p + 2] + (eP + m.t_my) - Mc);
                         acc[6] += exp(fu[3 * p + 2] + cb[3 * p + 2] + (eP + m.t_yy) - Mc);
                     }
@@ -632,7 +650,7 @@ __global__ __launch_bounds__(128) void k_bwd_generic(DevPlan P, const int *seg_i
                 if (mine > 0)
                     for (int p = 0; p < np; p++) {
                         int idp = idc[p];
-                        double eP = emit_ref(m, rp, idp, e_cur, 1);
+                        double eP = emit_ref(m, rp, idp, e_cur, 1, y - 1);
                         for (int q = 0; q < nl; q++)
                             if (legal_step(m, idl[q], idp)) {
                                 double v[3] = {fm[3 * q + 0] + cb[3 * p + 0] + (eP + m.t_mm),
@@ -916,7 +934,7 @@ struct sa_batch {
     unsigned seam_cap;
     unsigned seam_cap_bwd;   // records per seam array of the backward launches (a traceback segment is shorter than a region)
     long long seam_bwd_off;  // bytes: the forward launch's slots come first, then those of a pass's backward launches
-    double *d_tab6; int *d_hdp_slot; double *d_hdp_y, *d_hdp_slope, *d_hdp_grid, *d_hdp_tab;
+    double *d_tab6; double *d_noise3; double *d_evn; int *d_hdp_slot; double *d_hdp_y, *d_hdp_slope, *d_hdp_grid, *d_hdp_tab;
     long long *d_prob; int *d_seg_pass; long long *d_seg_off; sa_pair16_t *d_out;
     int *d_ids;  // region / segment id lists per launch
     long long cand_alloc;
@@ -996,7 +1014,7 @@ static DevPlan make_devplan(const sa_batch *b) {
     P.gsum = b->d_gsum; P.gmc = b->d_gmc;
     P.m.t_mm = m->t_mm; P.m.t_mx = m->t_mx; P.m.t_my = m->t_my; P.m.t_xm = m->t_xm; P.m.t_xx = m->t_xx;
     P.m.t_ym = m->t_ym; P.m.t_yy = m->t_yy;
-    P.m.tab6 = b->d_tab6; P.m.pow_km1 = m->pow_km1; P.m.n_alpha = m->n_alpha; P.m.hdp = m->hdp ? 1 : 0;
+    P.m.tab6 = b->d_tab6; P.m.emission = m->emission; P.m.noise3 = b->d_noise3; P.evn = b->d_evn; P.m.pow_km1 = m->pow_km1; P.m.n_alpha = m->n_alpha; P.m.hdp = m->hdp ? 1 : 0;
     P.m.hdp_slot = b->d_hdp_slot; P.m.hdp_y = b->d_hdp_y; P.m.hdp_slope = b->d_hdp_slope; P.m.hdp_grid = b->d_hdp_grid;
     P.m.grid_len = m->hdp ? (int) m->hdp->grid_length : 0;
     if (m->hdp) {
@@ -1242,7 +1260,7 @@ void sa_batch_destroy(sa_batch_t *b) {
     }
     const double td1 = now_ms_d();
     void *ptrs[] = {b->d_regions, b->d_rows, b->d_pk, b->d_poff, b->d_pid, b->d_px, b->d_xc, b->d_prec, b->d_ev, b->d_segs, b->d_cks, b->d_F, b->d_E,
-                    b->d_vbuf, b->d_cands, b->d_cand_count, b->d_overflow, b->d_totals, b->d_bscratch, b->d_tab6,
+                    b->d_vbuf, b->d_cands, b->d_cand_count, b->d_overflow, b->d_totals, b->d_bscratch, b->d_tab6, b->d_noise3, b->d_evn,
                     b->d_hdp_slot, b->d_hdp_y, b->d_hdp_slope, b->d_hdp_grid, b->d_hdp_tab, b->d_prob, b->d_seg_pass, b->d_seg_off,
                     b->d_out, b->d_ids, b->d_gsum, b->d_gmc, b->d_seam, b->d_ckxy};
     for (void *p : ptrs)
@@ -1283,6 +1301,8 @@ static int batch_create_impl(sa_batch_t **out, const sa_model_t *m, const sa_par
     // backward >= checkpoint maximum + log threshold) has no lower bound then and would pass lanes that hold no cell.  Such a
     // batch takes the reference-ordered kernels with host finalisation, which list a diagonal's cells explicitly.
     if (!(p->threshold > 0.0)) flags |= SA_FLAG_EXACT;
+    // the two-distribution emission (sa_model_set_emission) exists in the reference-ordered memory-resident kernels only
+    if (m->emission != 0) flags |= SA_FLAG_EXACT;
     const bool trace_c = getenv("SA_TRACE") != nullptr;
     auto now_ms_c = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double tc0 = now_ms_c();
@@ -1318,7 +1338,7 @@ static int batch_create_impl(sa_batch_t **out, const sa_model_t *m, const sa_par
     b->d_ev = nullptr; b->d_segs = nullptr; b->d_cks = nullptr; b->d_F = nullptr; b->d_E = nullptr; b->d_vbuf = nullptr;
     b->d_cands = nullptr; b->d_cand_count = nullptr; b->d_overflow = nullptr; b->d_totals = nullptr;
     b->d_seam = nullptr; b->d_ckxy = nullptr; b->seam_cap = 0; b->seam_cap_bwd = 0; b->seam_bwd_off = 0; b->strip_on = false;
-    b->d_bscratch = nullptr; b->d_tab6 = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr;
+    b->d_bscratch = nullptr; b->d_tab6 = nullptr; b->d_noise3 = nullptr; b->d_evn = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr;
     b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr; b->d_hdp_tab = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr;
     b->d_seg_off = nullptr; b->d_out = nullptr; b->d_ids = nullptr; b->d_gsum = nullptr; b->d_gmc = nullptr;
     b->cand_alloc = 0; b->out_alloc = 0; b->cand_factor = 1;
@@ -1515,6 +1535,29 @@ static int batch_finish_body(sa_batch *b) {
             tab6[6 * i + 5] = 0.0;
         }
         TRY(upload(&b->d_tab6, tab6.data(), (long long) tab6.size()));
+        if (m->emission == 1) {   // noise columns of the table, and every event's noise with its logarithm (C library's log)
+            if (m->hdp) return SA_EUNSUPPORTED;
+            std::vector<double> nz((size_t) m->n_kmers * 3);
+            for (long long i = 0; i < m->n_kmers; i++) {
+                nz[3 * i] = m->table5[5 * i + 2];
+                nz[3 * i + 1] = m->table5[5 * i + 4];
+                nz[3 * i + 2] = log(m->table5[5 * i + 4]);
+            }
+            TRY(upload(&b->d_noise3, nz.data(), (long long) nz.size()));
+            std::vector<double> evn((size_t) (2 * (pl->n_ev + 8)), 1.0);
+            for (int64_t j = 0; j < n_jobs; j++) {
+                const sa_job_t *jb = &jobs[j];
+                if (jb->n_events > 0 && jb->event_stride < 2) return SA_EINVAL;   // the noise is the record's second value
+                const sa_jobinfo_t *J = &pl->jobs[j];
+                for (int64_t i = 0; i < J->n_events; i++) {
+                    double n = jb->events[i * jb->event_stride + 1];
+                    if (n == 0) n = 0.000000001;   // (impl/stateMachine.c:619-621)
+                    evn[(size_t) (2 * (J->ev_off + i))] = n;
+                    evn[(size_t) (2 * (J->ev_off + i) + 1)] = log(n);
+                }
+            }
+            TRY(upload(&b->d_evn, evn.data(), (long long) evn.size()));
+        }
         if (m->hdp) {
             const sa_hdp_t *h = m->hdp;
             std::vector<int> slot((size_t) m->n_kmers);
@@ -2294,6 +2337,7 @@ int sa_expect_batch(const sa_model_t *m, const sa_params_t *p, const sa_job_t *j
     sa_batch_t *b = nullptr;
     // regions with one path per cell take the register kernels' expectation variant (k_bwd_fast_expect, sa_fast.inc); several
     // paths per cell, SA_FLAG_EXACT or SA_FLAG_FORCE_GENERIC: the memory-resident kernels (the checker of the former)
+    if (m && m->emission != 0) flags |= SA_FLAG_FORCE_GENERIC;
     int rc = sa_batch_create(&b, m, p, jobs, n_jobs, ambig, device, flags | SA_FLAG_EXPECT_INTERNAL);
     if (rc) return rc;
     rc = run_passes(b);

@@ -49,6 +49,7 @@ struct sa_model {
     double t_ym, t_yy;       /* gapY->match, gapY->gapY                                    */
     double *table5;          /* EMISSION_MATCH_MATRIX                                      */
     sa_hdp_t *hdp;
+    int emission;            /* SA_EMISSION_* (signalalign_hip.h) */
 };
 
 /* ---- plan (host arrays, uploaded as they are) -------------------------------------------------- */

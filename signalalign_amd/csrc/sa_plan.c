@@ -193,6 +193,13 @@ int64_t sa_model_kmer_id(const sa_model_t *m, const char *kmer) {
 int64_t sa_kmer_id(const sa_model_t *m, const char *kmer) { return (m && kmer) ? sa_model_kmer_id(m, kmer) : -1; }
 
 /* expected value / variance of an observed DP's posterior predictive on the grid */
+int sa_model_set_emission(sa_model_t *m, int emission) {
+    if (!m || (emission != SA_EMISSION_MEAN_ONLY && emission != SA_EMISSION_TWO_DIST)) return SA_EINVAL;
+    if (emission == SA_EMISSION_TWO_DIST && m->hdp) return SA_EUNSUPPORTED;
+    m->emission = emission;
+    return SA_OK;
+}
+
 int sa_model_set_to_hdp_expected_values(sa_model_t *m) {
     if (!m || !m->hdp) return SA_EINVAL;
     const sa_hdp_t *h = m->hdp;

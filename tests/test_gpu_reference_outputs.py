@@ -1,0 +1,64 @@
+"""The HIP path against posteriors the reference itself wrote: the Zymo 2-D read's template strand (fixtures and background:
+tests/test_oracle_reference_outputs.py).  The file was written by a build whose state machine carried the two-distribution
+emission, which the reference-ordered memory-resident kernels offer behind sa_model_set_emission: the GPU's pairs are then
+bit-identical to the CPU restatement's, and both sit on the reference's printed posteriors (median |dp| <= 2e-6, nine rows in ten
+within 1e-4, the rest being the guide alignment bwa made and lastz did not)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import signalalign_amd as sa
+from signalalign_amd import synth
+
+import sa_cases as cases
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gpu_reproduces_the_reference_posteriors_of_the_zymo_read(oracle):
+    z = np.load(os.path.join(cases.GOLDEN, "expected", "reference_output_zymo2d.npz"))
+    t = z["strand"] == "t"
+    gold = {(int(x), int(y)): float(p) for x, y, p in zip(z["x"][t], z["y"][t], z["p"][t])}
+    r = oracle.parse_npread(os.path.join(cases.GOLDEN, "npReads", "ZymoC_ch_1_file1.npRead"))
+    ref = "".join(open(os.path.join(cases.GOLDEN, "sequences", "zymo_sequence.fasta")).read().split("\n")[1:])
+    cig = json.load(open(os.path.join(cases.GOLDEN, "cigars", "zymoC_lastz_anchors.json")))["calls"][0]["cigars"][0].split()
+    s2, e2, s1, e1 = int(cig[2]), int(cig[3]), int(cig[6]), int(cig[7])
+    ops = [({"M": 0, "D": 1, "I": 2}[cig[i]], int(cig[i + 1])) for i in range(10, len(cig), 2)]
+    alpha, k, t10, tab = synth.parse_model_table(cases.MODEL_R73)
+    # the product's own host side: parameter estimation (rescales the noise columns of its table copy), anchors
+    pm0 = sa.Model.load(cases.MODEL_R73)
+    ev = r["template_events"].copy()
+    t5 = np.array(pm0.table5()).copy()
+    pr = sa.estimate_params(pm0, t5, r["template_strand_event_map"], ev, r["template_read"])
+    gx, gy = sa.guide_to_anchors(s1, e1, 1, s2, ops, 14)
+    em = r["template_event_map"]
+    ax, ay = sa.remap_anchors(gx, gy, em, s2)
+    lo, hi = int(em[s2]), int(em[e2 - 1])
+    pm = sa.Model.create(alpha, k, t10, t5)
+    pm.set_emission(1)                                   # SA_EMISSION_TWO_DIST
+    job = dict(ref=ref[s1:e1], events=np.ascontiguousarray(ev[lo:hi]), ax=ax, ay=ay, scale=pr["scale"], shift=pr["shift"], var=pr["var"])
+    p = sa.default_params(threshold=0.01, expansion=50, trace_back=100)
+    b = sa.Batch(pm, p, [job])
+    b.run()
+    got = b.pairs(0)
+    assert b.stats().n_fast_regions == 0                 # the reference-ordered kernels
+    b.close()
+    # the CPU restatement with the same emission: bit-identical
+    om = oracle.Model(alpha, k, t10, tab, emission=oracle.EM_TWODIST_DESCALED)
+    ev_o = r["template_events"].copy()
+    pr_o = oracle.estimate_params(om, r["template_strand_event_map"], ev_o, r["template_read"])
+    om.set_read_params(pr_o["scale"], pr_o["shift"], pr_o["var"])
+    exp = oracle.align(om, ref[s1:e1], ev_o[lo:hi], ax, ay, cases.oracle_params(oracle, p))
+    assert len(got) == len(exp)
+    for f in ("x", "y", "kmer_id", "prob_e7"):
+        assert np.array_equal(got[f], exp[f]), f
+    # ... and on the reference's printed posteriors
+    mine = {(int(q["x"]) + s1, int(q["y"]) + lo): int(q["prob_e7"]) / 1e7 for q in got}
+    common = set(mine) & set(gold)
+    d = np.array([abs(mine[k_] - gold[k_]) for k_ in common])
+    assert len(common) >= 0.97 * len(gold) and np.median(d) <= 2e-6 and (d <= 1e-4).mean() >= 0.9
+    # a dense event vector cannot carry the noise
+    with pytest.raises(sa.SaError):
+        sa.Batch(pm, p, [dict(job, events=np.ascontiguousarray(job["events"][:, 0]))])
