@@ -145,6 +145,10 @@ int64_t sa_kmer_id(const sa_model_t *m, const char *kmer); /* impl/nanopore_hdp.
 #define SA_EMISSION_MEAN_ONLY 0
 #define SA_EMISSION_TWO_DIST 1
 int sa_model_set_emission(sa_model_t *m, int emission);
+/* A Gaussian model with the same alphabet, k-mer length, transitions and emission kind as `m` and the emission table `table5`
+ * (5 * A^k doubles, copied): the per-read model the reference gets from emissions_signal_scaleNoise (impl/stateMachine.c:721-741)
+ * -- sa_estimate_params leaves the rescaled table in its table5_inout argument. */
+int sa_model_clone_with_table(sa_model_t **out, const sa_model_t *m, const double *table5);
 
 /* ambiguity table: 256 entries (index = character), NULL = not ambiguous.
  * sa_default_ambig fills create_ambig_bases() (impl/pairwiseAligner.c:32-65);

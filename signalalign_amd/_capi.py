@@ -76,7 +76,7 @@ class PlanInfo(C.Structure):
 PAIR_DTYPE = np.dtype([("prob_e7", "<i8"), ("x", "<i4"), ("y", "<i4"), ("path", "<i4"), ("kmer_id", "<i4")])
 
 EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alphabet", "sa_model_table5",
-           "sa_model_set_to_hdp_expected_values", "sa_model_set_emission", "sa_kmer_id", "sa_default_ambig", "sa_load_ambig",
+           "sa_model_set_to_hdp_expected_values", "sa_model_set_emission", "sa_model_clone_with_table", "sa_kmer_id", "sa_default_ambig", "sa_load_ambig",
            "sa_batch_create", "sa_batch_create_deferred", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_stats",
            "sa_batch_job_cells", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_plan_describe", "sa_plan_digest",
            "sa_plan_check_path_records", "sa_dplan_compare",

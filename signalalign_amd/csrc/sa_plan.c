@@ -193,6 +193,20 @@ int64_t sa_model_kmer_id(const sa_model_t *m, const char *kmer) {
 int64_t sa_kmer_id(const sa_model_t *m, const char *kmer) { return (m && kmer) ? sa_model_kmer_id(m, kmer) : -1; }
 
 /* expected value / variance of an observed DP's posterior predictive on the grid */
+/* a model with the same alphabet, k-mer length and transitions and another emission table (per-read noise scaling) */
+int sa_model_clone_with_table(sa_model_t **out, const sa_model_t *m, const double *table5) {
+    if (!out || !m || !table5 || m->hdp) return SA_EINVAL;
+    sa_model_t *c = calloc(1, sizeof(*c));
+    if (!c) return SA_ENOMEM;
+    *c = *m;
+    c->hdp = NULL;
+    c->table5 = malloc(sizeof(double) * 5 * (size_t) m->n_kmers);
+    if (!c->table5) { free(c); return SA_ENOMEM; }
+    memcpy(c->table5, table5, sizeof(double) * 5 * (size_t) m->n_kmers);
+    *out = c;
+    return SA_OK;
+}
+
 int sa_model_set_emission(sa_model_t *m, int emission) {
     if (!m || (emission != SA_EMISSION_MEAN_ONLY && emission != SA_EMISSION_TWO_DIST)) return SA_EINVAL;
     if (emission == SA_EMISSION_TWO_DIST && m->hdp) return SA_EUNSUPPORTED;

@@ -63,6 +63,8 @@ static void usage(void) {
     fprintf(stderr, "-r: boolean option if read is RNA\n");
     fprintf(stderr, "--batch <manifest>: align many reads in one process (one GPU batch per strand model)\n");
     fprintf(stderr, "--batch-reads <n>: reads per GPU batch of a manifest (default 2048)\n");
+    fprintf(stderr, "--emission <meanOnly|twoDist>: match emission of a Gaussian model (default meanOnly, what the reference's\n"
+                    "                  signalMachine installs; twoDist adds the inverse Gaussian on the event noise; single read only)\n");
     fprintf(stderr, "--device <n>: GPU to use\n");
     fprintf(stderr, "--mea: also write <posteriors file>.mea, the rows of the full output on the maximum expected accuracy path\n\n");
 }
@@ -265,6 +267,8 @@ static int load_strand_model(strand_model_t *sm, const char *model_path, const c
 typedef struct {
     int hdp, two_d, rna, expect_mode;
     int mea; /* --mea: also write the maximum-expected-accuracy path of every read (not in the reference binary) */
+    int two_dist; /* --emission twoDist: the two-distribution emission (not an option of the reference binary: it is what its
+                   * state machine carried when the reference's shipped output files were written); one read per process */
     int64_t out_fmt, constraint_trim;
     const char *fwd_ref, *bwd_ref;
     sa_params_t p;
@@ -283,6 +287,7 @@ typedef struct {
     int forward;
     int64_t *ax[2], *ay[2];
     sa_job_t jobs[2];
+    sa_model_t *model[2]; /* --emission twoDist: the strand models with this read's noise scaling */
     int failed;
     char err[512];
 } read_t;
@@ -296,7 +301,7 @@ static int fail(read_t *rd, int fatal, const char *fmt, const char *a) {
 }
 
 static int estimate_strand(const strand_model_t *sm, const int64_t *strand_map, double *events, int64_t n_events,
-                           const char *read, int64_t read_len, sa_strand_params_t *out) {
+                           const char *read, int64_t read_len, sa_strand_params_t *out, sa_model_t **read_model) {
     int64_t n = 5;
     for (int i = 0; i < sm->k; i++) n *= sm->n_alpha;
     double *scratch = malloc(sizeof(double) * (size_t) n); /* the estimation rescales the noise columns in place */
@@ -304,6 +309,10 @@ static int estimate_strand(const strand_model_t *sm, const int64_t *strand_map, 
     memcpy(scratch, sm->table_orig, sizeof(double) * (size_t) n);
     double est[7];
     int rc = sa_estimate_params(sm->model, scratch, strand_map, events, n_events, read, read_len, est);
+    if (rc == SA_OK && read_model) {   /* the model this read is aligned with: the rescaled noise columns, two-distribution emission */
+        rc = sa_model_clone_with_table(read_model, sm->model, scratch);
+        if (rc == SA_OK) rc = sa_model_set_emission(*read_model, SA_EMISSION_TWO_DIST);
+    }
     free(scratch);
     if (rc != SA_OK) return rc;
     out->scale = est[0]; out->shift = est[1]; out->var = est[2]; out->drift = est[3];
@@ -415,7 +424,8 @@ static int prepare_read(const run_t *R, read_t *rd, int fatal) {
 
     /* per-strand: estimate the read's parameters (signalUtils_estimateNanoporeParams), build the job */
     if (estimate_strand(&R->smt, np->template_strand_event_map, np->template_events, np->n_template_events,
-                        np->template_read, np->template_read_length, &np->template_params) != SA_OK) {
+                        np->template_read, np->template_read_length, &np->template_params,
+                        R->two_dist ? &rd->model[0] : NULL) != SA_OK) {
         free(gx); free(gy);
         return fail(rd, fatal, "Cannot get scale params with no assignments", NULL);
     }
@@ -433,7 +443,8 @@ static int prepare_read(const run_t *R, read_t *rd, int fatal) {
     rd->jobs[0].var = np->template_params.var;
     if (R->two_d) {
         if (estimate_strand(&R->smc, np->complement_strand_event_map, np->complement_events, np->n_complement_events,
-                            np->complement_read, np->complement_read_length, &np->complement_params) != SA_OK) {
+                            np->complement_read, np->complement_read_length, &np->complement_params,
+                            R->two_dist ? &rd->model[1] : NULL) != SA_OK) {
             free(gx); free(gy);
             return fail(rd, fatal, "Cannot get scale params with no assignments", NULL);
         }
@@ -753,12 +764,13 @@ static int64_t run_slice(run_t *Rp, read_t *reads, int64_t n_reads, int batch_mo
         for (int64_t j = 0; j < n_ok; j++) bj[j] = reads[who[j]].jobs[s];
         int rc;
         if (!R.mea) {
-            rc = sa_align_batch(sms[s]->model, &R.p, bj, n_ok, R.ambig, device, 0, pairs[s], n_pairs[s]);
+            rc = sa_align_batch(R.two_dist ? reads[who[0]].model[s] : sms[s]->model, &R.p, bj, n_ok, R.ambig, device, 0, pairs[s],
+                                n_pairs[s]);
         } else { /* the same batch, kept alive for the path step: its pairs are still on the device */
             sa_batch_t *b = NULL;
             mea[s] = calloc((size_t) n_ok, sizeof(sa_mea_pair_t *));
             n_mea[s] = calloc((size_t) n_ok, sizeof(int64_t));
-            rc = sa_batch_create(&b, sms[s]->model, &R.p, bj, n_ok, R.ambig, device, 0);
+            rc = sa_batch_create(&b, R.two_dist ? reads[who[0]].model[s] : sms[s]->model, &R.p, bj, n_ok, R.ambig, device, 0);
             if (rc == SA_OK) rc = sa_batch_run(b);
             for (int64_t j = 0; j < n_ok && rc == SA_OK; j++) {
                 sa_batch_n_pairs(b, j, &n_pairs[s][j]);
@@ -831,6 +843,7 @@ static void release_read(read_t *rd) {
     if (rd->np) sa_npread_free(rd->np);
     free(rd->forward_seq); free(rd->backward_seq);
     for (int s = 0; s < 2; s++) { free(rd->ax[s]); free(rd->ay[s]); rd->ax[s] = rd->ay[s] = NULL; }
+    for (int s = 0; s < 2; s++) { if (rd->model[s]) sa_model_destroy(rd->model[s]); rd->model[s] = NULL; }
     rd->pA = NULL; rd->np = NULL; rd->forward_seq = rd->backward_seq = NULL;
 }
 
@@ -872,6 +885,7 @@ int main(int argc, char **argv) {
                                            {"device", required_argument, 0, 1001},
                                            {"mea", no_argument, 0, 1002},
                                            {"batch-reads", required_argument, 0, 1003},
+                                           {"emission", required_argument, 0, 1004},
                                            {0, 0, 0, 0}};
     for (;;) {
         int idx = 0;
@@ -906,6 +920,10 @@ int main(int argc, char **argv) {
             case 1001: device = atoi(optarg); break;
             case 1002: R.mea = 1; break;
             case 1003: batch_reads = atoll(optarg) > 0 ? atoll(optarg) : batch_reads; break;
+            case 1004:
+                if (!strcmp(optarg, "twoDist")) R.two_dist = 1;
+                else if (strcmp(optarg, "meanOnly")) die("signalMachine: --emission takes meanOnly or twoDist, not %s", optarg);
+                break;
             default: usage(); return 1;
         }
     }
@@ -920,6 +938,8 @@ int main(int argc, char **argv) {
     read_t *reads = NULL;
     int64_t n_reads = 0;
     const int batch_mode = manifest != NULL;
+    if (R.two_dist && (batch_mode || R.hdp || R.expect_mode))
+        die("signalMachine: --emission twoDist aligns one read per process with a Gaussian model%s", "");
     if (batch_mode) {
         n_reads = load_manifest(manifest, &reads);
         if (n_reads < 0) die("[signalMachine]ERROR: cannot read the batch manifest %s", manifest);

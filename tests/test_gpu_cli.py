@@ -317,6 +317,43 @@ def test_signalmachine_two_d_read_against_the_reference_output(oracle, tmp_path)
     assert any(g[4] == "c" for g in gold) and any(k[0] == "c" for k in mine)
 
 
+def test_signalmachine_reproduces_the_reference_output_file_of_the_two_d_read(tmp_path):
+    """End to end against the reference's binary: its shipped output for the bundled 2-D read (2007 rows, template and complement;
+    positions, events and posteriors committed as tests/golden/expected/reference_output_zymo2d.npz) was written with the
+    two-distribution emission (tests/test_oracle_reference_outputs.py).  `signalMachine --twoD --emission twoDist` on the same
+    read, models and contig must print the same posterior for the same (strand, position, event): median |dp| at the printed
+    precision and at least 85 % of the rows within 1e-4 on BOTH strands -- the rest is the guide alignment (bwa's then, lastz's
+    here)."""
+    import json
+    z = np.load(os.path.join(cases.GOLDEN, "expected", "reference_output_zymo2d.npz"))
+    cig = json.load(open(os.path.join(cases.GOLDEN, "cigars", "zymoC_lastz_anchors.json")))["calls"][0]["cigars"][0].split()
+    cigar = str(tmp_path / "guide.cigar")
+    with open(cigar, "w") as f:
+        f.write(" ".join(["cigar:", "read2d"] + cig[2:5] + ["ZYMO"] + cig[6:]) + "\n")
+    out = str(tmp_path / "twod.tsv")
+    pr = subprocess.run([BIN, "-T", cases.MODEL_R73, "-C", os.path.join(cases.GOLDEN, "models", "testModelR73_acegot_complement.model"),
+                         "-q", os.path.join(cases.GOLDEN, "npReads", "ZymoC_ch_1_file1.npRead"),
+                         "-f", os.path.join(cases.GOLDEN, "sequences", "zymo_sequence.fasta"), "-n", "ZYMO", "-p", cigar, "-u", out,
+                         "-L", "read2d", "--twoD", "--emission", "twoDist", "-s", "0", "-g", "100"],
+                        capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr
+    mine = {}
+    for l in open(out):
+        g = l.rstrip("\n").split("\t")
+        mine[(g[4], int(g[1]), int(g[5]))] = float(g[12])
+    for strand in ("t", "c"):
+        sel = z["strand"] == strand
+        gold = {(strand, int(x), int(y)): float(p) for x, y, p in zip(z["x"][sel], z["y"][sel], z["p"][sel])}
+        common = set(mine) & set(gold)
+        d = np.array([abs(mine[k_] - gold[k_]) for k_ in common])
+        # (measured: template 1031 of 1044 rows, median 3e-7, 91 % within 1e-4; complement 961 of 963, median 0, 89 %)
+        assert len(common) >= 0.95 * len(gold) and np.median(d) <= 2e-6 and (d <= 1e-4).mean() >= 0.85, \
+            (strand, len(common), len(gold), float(np.median(d)), float((d <= 1e-4).mean()))
+    # the option is not for batches, HDP models or the expectation routine
+    pr = subprocess.run([BIN, "-T", cases.MODEL_R73, "--emission", "nope"], capture_output=True, text=True)
+    assert pr.returncode != 0 and "--emission takes" in pr.stderr
+
+
 def test_signalmachine_expectations_file(oracle, tmp_path):
     # -t: the .expectations file of continuousPairHmm_writeToFile (impl/continuousHmm.c:352-408)
     model = cases.MODEL_6MER
