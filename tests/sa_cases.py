@@ -157,3 +157,41 @@ def write_npread_1d(path, read, event_map, events4):
         f.write("\n%s\n%s\n\n\n\n" % (read, " ".join(str(int(v)) for v in event_map)))
         f.write(" ".join(repr(float(v)) for v in np.asarray(events4).reshape(-1)) + "\n")
         f.write("\n\n\n\n\n\n\n")
+
+
+def reference_output_ecoli1d_inputs(oracle):
+    """The reference's output for the bundled R9.4 1-D read (tests/golden/expected/reference_output_ecoli1d.npz) as an alignment
+    job: (posteriors by (window position, event), reference window rebuilt from the rows' k-mers, parsed .npRead, (start1, end1,
+    start2, end2), guide-alignment operations).  The E. coli genome is a missing blob and the guide alignment bwa made is not
+    shipped: the operations are rebuilt from the rows themselves -- per reference position its most probable event (p >= 0.5)
+    mapped to a read base -- which is cruder than the original."""
+    z = np.load(os.path.join(GOLDEN, "expected", "reference_output_ecoli1d.npz"))
+    gold = {(int(x), int(y)): float(p) for x, y, p in zip(z["x"], z["y"], z["p"])}
+    window = str(z["window"]).replace("?", "A")      # (one base no row covers)
+    r = oracle.parse_npread(os.path.join(GOLDEN, "npReads", "r9p4_oneD.npRead"))
+    em = r["template_strand_event_map"]
+    best = {}
+    for (x, y), p in gold.items():
+        if p >= 0.5 and (x not in best or p > best[x][1]):
+            best[x] = (y, p)
+    m, last = [], -1
+    for x in sorted(best):
+        b = int(np.searchsorted(em, best[x][0], side="right") - 1)
+        if b > last:
+            m.append((x, b))
+            last = b
+    ops = []
+
+    def push(t, n):
+        if n > 0:
+            if ops and ops[-1][0] == t:
+                ops[-1] = (t, ops[-1][1] + n)
+            else:
+                ops.append((t, n))
+    for (x, b), (x2, b2) in zip(m[:-1], m[1:]):
+        mm = min(x2 - x, b2 - b)
+        push(0, mm)
+        push(1, x2 - x - mm)
+        push(2, b2 - b - mm)
+    push(0, 1)
+    return gold, window, r, (m[0][0], m[-1][0] + 1, m[0][1], m[-1][1] + 1), ops

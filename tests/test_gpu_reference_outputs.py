@@ -62,3 +62,40 @@ def test_gpu_reproduces_the_reference_posteriors_of_the_zymo_read(oracle):
     # a dense event vector cannot carry the noise
     with pytest.raises(sa.SaError):
         sa.Batch(pm, p, [dict(job, events=np.ascontiguousarray(job["events"][:, 0]))])
+
+
+def test_gpu_reproduces_the_reference_posteriors_of_the_r9p4_read(oracle):
+    """The same for the bundled R9.4 1-D read (10.9k events, 5-mer ACEGT model; window and guide alignment rebuilt from the
+    reference's rows: sa_cases.reference_output_ecoli1d_inputs): bit-identical to the restatement, on the reference's printed
+    posteriors within what the cruder guide alignment allows."""
+    gold, window, r, (s1, e1, s2, e2), ops = cases.reference_output_ecoli1d_inputs(oracle)
+    model = os.path.join(cases.GOLDEN, "models", "testModelR9p4_5mer_acegt_template.model")
+    alpha, k, t10, tab = synth.parse_model_table(model)
+    em, read = r["template_strand_event_map"], r["template_read"]
+    pm0 = sa.Model.load(model)
+    ev = r["template_events"].copy()
+    t5 = np.array(pm0.table5()).copy()
+    pr = sa.estimate_params(pm0, t5, em, ev, read)
+    gx, gy = sa.guide_to_anchors(s1, e1, 1, s2, ops, 14)
+    ax, ay = sa.remap_anchors(gx, gy, em, s2)
+    lo, hi = int(em[s2]), int(em[e2 - 1])
+    pm = sa.Model.create(alpha, k, t10, t5)
+    pm.set_emission(1)
+    p = sa.default_params(threshold=0.01, expansion=50, trace_back=100)
+    job = dict(ref=window[s1:e1], events=np.ascontiguousarray(ev[lo:hi]), ax=ax, ay=ay, scale=pr["scale"], shift=pr["shift"], var=pr["var"])
+    b = sa.Batch(pm, p, [job])
+    b.run()
+    got = b.pairs(0)
+    b.close()
+    om = oracle.Model(alpha, k, t10, tab, emission=oracle.EM_TWODIST_DESCALED)
+    ev_o = r["template_events"].copy()
+    pr_o = oracle.estimate_params(om, em, ev_o, read)
+    om.set_read_params(pr_o["scale"], pr_o["shift"], pr_o["var"])
+    exp = oracle.align(om, window[s1:e1], ev_o[lo:hi], ax, ay, cases.oracle_params(oracle, p))
+    assert len(got) == len(exp) > 10000
+    for f in ("x", "y", "kmer_id", "prob_e7"):
+        assert np.array_equal(got[f], exp[f]), f
+    mine = {(int(q["x"]) + s1, int(q["y"]) + lo): int(q["prob_e7"]) / 1e7 for q in got}
+    common = set(mine) & set(gold)
+    d = np.array([abs(mine[k_] - gold[k_]) for k_ in common])
+    assert len(common) >= 0.8 * len(gold) and np.median(d) <= 5e-6 and (d <= 1e-4).mean() >= 0.8

@@ -59,35 +59,8 @@ def test_zymo_two_d_template_posteriors_of_the_reference(oracle):
 
 
 def test_r9p4_one_d_posteriors_of_the_reference(oracle):
-    z = np.load(os.path.join(EXP, "reference_output_ecoli1d.npz"))
-    gold = {(int(x), int(y)): float(p) for x, y, p in zip(z["x"], z["y"], z["p"])}
-    window = str(z["window"]).replace("?", "A")      # (one base no row covers)
-    r = oracle.parse_npread(os.path.join(cases.GOLDEN, "npReads", "r9p4_oneD.npRead"))
+    gold, window, r, (s1, e1, s2, e2), ops = cases.reference_output_ecoli1d_inputs(oracle)
     read, em = r["template_read"], r["template_strand_event_map"]
-    # a guide alignment from the rows themselves: per reference position its most probable event (p >= 0.5) -> read base
-    best = {}
-    for (x, y), p in gold.items():
-        if p >= 0.5 and (x not in best or p > best[x][1]):
-            best[x] = (y, p)
-    m, last = [], -1
-    for x in sorted(best):
-        b = int(np.searchsorted(em, best[x][0], side="right") - 1)
-        if b > last:
-            m.append((x, b))
-            last = b
-    ops = []
-
-    def push(t, n):
-        if n > 0:
-            if ops and ops[-1][0] == t:
-                ops[-1] = (t, ops[-1][1] + n)
-            else:
-                ops.append((t, n))
-    for (x, b), (x2, b2) in zip(m[:-1], m[1:]):
-        mm = min(x2 - x, b2 - b)
-        push(0, mm); push(1, x2 - x - mm); push(2, b2 - b - mm)
-    push(0, 1)
-    s1, e1, s2, e2 = m[0][0], m[-1][0] + 1, m[0][1], m[-1][1] + 1
     alpha, k, t10, tab = synth.parse_model_table(os.path.join(cases.GOLDEN, "models", "testModelR9p4_5mer_acegt_template.model"))
     om = oracle.Model(alpha, k, t10, tab, emission=oracle.EM_TWODIST_DESCALED)
     ev = r["template_events"].copy()
