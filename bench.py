@@ -349,7 +349,9 @@ def measure(args, ctx, compact=False):
         # on (synth.make_read_hdp); the table's level means (after set_to_hdp_expected_values) enter the event normalisation
         spec = dict(kind="hdp", model=model_path, nhdp=nhdp, events=args.events, table5=np.array(pm.table5()),
                     ref_pool=os.path.join(ROOT, "tests", "golden", "npReads", "ZymoRef.txt"))
-    make_many = lambda idx: synth.make_reads_parallel(spec, idx)   # spawned numpy-only workers; identical to the serial loop
+    # spawned numpy-only workers; identical to the serial loop (several ranks on one host share its CPUs: fewer workers each)
+    gen_workers = None if world == 1 else max(1, min(4, int(os.environ.get("SA_HOST_THREADS", "2"))))
+    make_many = lambda idx: synth.make_reads_parallel(spec, idx, workers=gen_workers)
     # reads are independent: the global read list is dealt to the ranks (no collective on the data path)
     from signalalign_amd import shard
     mine = shard.shard_indices([args.events] * (world * args.reads), rank, world)
