@@ -564,7 +564,7 @@ def measure(args, ctx, compact=False):
         traffic = None
         profiles_meta = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        default_size = (args.reads == (12500 if args.workload == "scaling" else 2000) and
+        default_size = (args.reads == {"scaling": 12500}.get(args.workload, 2000) and   # (the counter passes ran at 2000 reads)
                         args.events == (10000 if args.workload == "scaling" else 5000))
         if os.path.exists(tp) and default_size:
             try:
@@ -695,7 +695,8 @@ def main():
     ap.add_argument("--cpu-reads-per-thread", type=int, default=30)
     args = ap.parse_args()
     if args.reads is None:
-        args.reads = {"scaling": 12500, "hdp": 5000}.get(args.workload, 2000)   # hdp: BASELINE configs[3] names 5000 reads
+        # the sizes BASELINE.json names: configs[2] (cpg) 10 000 reads, configs[3] (hdp) 5000, configs[4]'s slice 12 500
+        args.reads = {"scaling": 12500, "hdp": 5000, "cpg": 10000}.get(args.workload, 2000)
     if args.events is None:
         args.events = 10000 if args.workload == "scaling" else 5000
     if args.threshold is None:

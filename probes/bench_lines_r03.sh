@@ -7,8 +7,8 @@ run() { n=$1; shift; timeout -k 10 400 "$@" > $O/$n.json 2> $O/$n.err || echo "F
 run gaussian python bench.py
 run hdp python bench.py --workload hdp --no-cpu-baseline
 run hdp_t001 python bench.py --workload hdp --threshold 0.01 --no-cpu-baseline
-run cpg python bench.py --workload cpg --no-cpu-baseline
-run cpg10k python bench.py --workload cpg --reads 10000 --steps 8 --warmup 2 --no-cpu-baseline
+run cpg python bench.py --workload cpg --reads 2000 --no-cpu-baseline
+run cpg10k python bench.py --workload cpg --steps 8 --warmup 2 --no-cpu-baseline
 run realistic python bench.py --workload realistic --no-cpu-baseline
 run scaling python bench.py --workload scaling --steps 8 --warmup 2 --no-cpu-baseline
 run expectations python bench.py --workload expectations --steps 10 --warmup 2

@@ -3,7 +3,7 @@
 # the default bench command, HBM traffic counters and instruction-mix counters over `bench.py --kernels-only`.  Counter passes
 # use --kernel-trace only (pool rule) and the program itself behind `--`.  $1 = workload, $2 = tag (default r02)
 set -e
-W=${1:-gaussian}
+W=${1:-gaussian}   # (cpg: pass "cpg --reads 2000" style extra arguments through $3.. if the 2000-read figures are wanted)
 T=${2:-r02}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
