@@ -778,6 +778,34 @@ __global__ __launch_bounds__(64) void k_finalize(DevPlan P, int seg0, int n_segs
     if (lane == 0) seg_pass[seg] = cnt;
 }
 
+// Expectation pass: the per-read sums on the device.  Every checkpoint group holds its seven transition sums scaled by its
+// maximum (gsum / gmc) and its exact total (k_fold); a read's expectations are sum_groups gsum * exp(gmc - total), its
+// likelihood the totals once per diagonal (hmm->likelihood += totalProbability, impl/pairwiseAligner.c:1432).  One wave per
+// region, a lane per checkpoint group; 8 doubles per read come back instead of 80 bytes per group (130 MB per 2000 reads).
+__global__ __launch_bounds__(64) void k_expect_reduce(DevPlan P, double *__restrict__ red) {
+    const sa_region_t *R = &P.regions[blockIdx.x];
+    const int lane = threadIdx.x;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long long sg = R->seg_off; sg < R->seg_off + R->n_seg; sg++) {
+        const sa_seg_t *S = &P.segs[sg];
+        const long long nrows = S->from - S->to;
+        for (int c = lane; c < S->n_ck; c += 64) {
+            const double total = P.totals[S->ck_base + c];
+            long long rows_here = nrows - (long long) c * SA_CKPT_EVERY;
+            if (rows_here > SA_CKPT_EVERY) rows_here = SA_CKPT_EVERY;
+            if (rows_here > 0) acc[7] += total * (double) rows_here;
+            if (!(total > NEG_INF)) continue;
+            const double sc = exp(P.gmc[S->ck_base + c] - total);
+            for (int k = 0; k < 7; k++) acc[k] += P.gsum[8 * (S->ck_base + c) + k] * sc;
+        }
+    }
+    for (int k = 0; k < 8; k++) {
+        double v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0 && v != 0.0) atomicAdd(&red[8ll * R->job + k], v);
+    }
+}
+
 // exclusive scan of seg_pass (single block)
 // out_host (pinned host memory, written straight from the kernel) spares a copy-engine transfer: a queued copy that
 // waits for a kernel blocks every later copy on the engine, including the pair copies of groups already finished
@@ -2343,54 +2371,61 @@ int sa_expect_batch(const sa_model_t *m, const sa_params_t *p, const sa_job_t *j
     rc = run_passes(b);
     if (rc) { sa_batch_destroy(b); return rc; }
     const sa_plan_t *pl = b->plan;
-    // what the host needs: totals, the groups' scaling maxima and sums, candidate counts and (HDP models: the assignment
-    // candidates -- 24 B x slots per posterior diagonal).  Into ONE pinned block (a copy to pageable memory moves 3 GB/s, and
-    // 1.6 million checkpoints of 2000 reads are 130 MB), then the per-read rescale on all host threads.
+    // The per-read sums are taken on the device (k_expect_reduce): 8 doubles per read come back.  HDP models also return the
+    // assignment candidates (24 B x slots per posterior diagonal) with the totals they are tested against -- into ONE pinned
+    // block (a copy to pageable memory moves 3 GB/s), tested on all host threads.
     const bool want_cands = m->hdp != nullptr && assign_out != nullptr;
     const size_t n_ck = (size_t) (pl->n_cks > 0 ? pl->n_cks : 1), n_sg = (size_t) (pl->n_segs > 0 ? pl->n_segs : 1);
-    const size_t o_tot = 0, o_gmc = o_tot + sa_up256(8 * n_ck), o_gsum = o_gmc + sa_up256(8 * n_ck), o_cnt = o_gsum + sa_up256(64 * n_ck);
-    const size_t o_cand = o_cnt + sa_up256(4 * n_sg);
-    const size_t host_bytes = o_cand + (want_cands ? sizeof(sa_cand_t) * (size_t) (pl->n_cand > 0 ? pl->n_cand : 1) : 0);
+    const size_t o_red = 0, o_tot = o_red + sa_up256(64 * (size_t) (n_jobs > 0 ? n_jobs : 1));
+    const size_t o_cnt = o_tot + (want_cands ? sa_up256(8 * n_ck) : 0);
+    const size_t o_cand = o_cnt + (want_cands ? sa_up256(4 * n_sg) : 0);
+    const size_t host_bytes = o_cand + (want_cands ? sizeof(sa_cand_t) * (size_t) (pl->n_cand > 0 ? pl->n_cand : 1) : 256);
     char *hb = nullptr;
+    double *d_red = nullptr;
     if (g_sa_pool.get(SaPool::PINNED, (void **) &hb, host_bytes, b->device) != hipSuccess) { (void) hipGetLastError(); sa_batch_destroy(b); return SA_ENOMEM; }
+    if (g_sa_pool.get(SaPool::DEVICE, (void **) &d_red, 64 * (size_t) (n_jobs > 0 ? n_jobs : 1), b->device) != hipSuccess) {
+        (void) hipGetLastError();
+        g_sa_pool.put(SaPool::PINNED, hb);
+        sa_batch_destroy(b);
+        return SA_ENOMEM;
+    }
     auto dl = [&](void *dst, const void *src, size_t bytes) -> int {
         if (bytes) HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, b->stream));
         return SA_OK;
     };
-    rc = dl(hb + o_tot, b->d_totals, 8 * (size_t) pl->n_cks);
-    if (!rc) rc = dl(hb + o_gmc, b->d_gmc, 8 * (size_t) pl->n_cks);
-    if (!rc) rc = dl(hb + o_gsum, b->d_gsum, 64 * (size_t) pl->n_cks);
-    if (!rc) rc = dl(hb + o_cnt, b->d_cand_count, 4 * (size_t) pl->n_segs);
-    if (!rc && want_cands) rc = dl(hb + o_cand, b->d_cands, sizeof(sa_cand_t) * (size_t) pl->n_cand);
-    if (!rc && sa_sync_stream(b->stream, b->device) != hipSuccess) rc = SA_ENODEVICE;
+    auto tail = [&]() -> int {
+        HIPCHK(hipMemsetAsync(d_red, 0, 64 * (size_t) (n_jobs > 0 ? n_jobs : 1), b->stream));
+        if (pl->n_regions > 0) {
+            hipLaunchKernelGGL(k_expect_reduce, dim3((unsigned) pl->n_regions), dim3(64), 0, b->stream, make_devplan(b), d_red);
+            HIPCHK(hipGetLastError());
+        }
+        int rc_ = dl(hb + o_red, d_red, 64 * (size_t) n_jobs);
+        if (!rc_ && want_cands) rc_ = dl(hb + o_tot, b->d_totals, 8 * (size_t) pl->n_cks);
+        if (!rc_ && want_cands) rc_ = dl(hb + o_cnt, b->d_cand_count, 4 * (size_t) pl->n_segs);
+        if (!rc_ && want_cands) rc_ = dl(hb + o_cand, b->d_cands, sizeof(sa_cand_t) * (size_t) pl->n_cand);
+        if (!rc_ && sa_sync_stream(b->stream, b->device) != hipSuccess) rc_ = SA_ENODEVICE;
+        return rc_;
+    };
+    rc = tail();
+    g_sa_pool.put(SaPool::DEVICE, d_red);
     if (rc) { g_sa_pool.put(SaPool::PINNED, hb); sa_batch_destroy(b); return rc; }
-    const double *totals = reinterpret_cast<const double *>(hb + o_tot), *gmc = reinterpret_cast<const double *>(hb + o_gmc),
-                 *gsum = reinterpret_cast<const double *>(hb + o_gsum);
+    const double *red = reinterpret_cast<const double *>(hb + o_red), *totals = reinterpret_cast<const double *>(hb + o_tot);
     const int *counts = reinterpret_cast<const int *>(hb + o_cnt);
     const sa_cand_t *cands = reinterpret_cast<const sa_cand_t *>(hb + o_cand);
-    // (from, to) slots of hmm->transitions[from * 3 + to] in the order the kernel accumulates them
+    // (from, to) slots of hmm->transitions[from * 3 + to] in the order the kernels accumulate them
     static const int slot[7] = {0 * 3 + 1, 1 * 3 + 1, 0 * 3 + 0, 1 * 3 + 0, 2 * 3 + 0, 0 * 3 + 2, 2 * 3 + 2};
     const double thr = pl->params.threshold;
     std::atomic<int> oom(0);
     sa_parallel_for((size_t) n_jobs, [&](size_t jj) {
         const int64_t j = (int64_t) jj;
         const sa_jobinfo_t *J = &pl->jobs[j];
+        for (int k = 0; k < 7; k++) trans9_out[j * 9 + slot[k]] += red[8 * j + k];
+        likelihood_out[j] += red[8 * j + 7];
         std::vector<sa_assignment_t> as;
-        for (long long r = J->region_off; r < J->region_off + J->n_regions; r++) {
+        for (long long r = J->region_off; want_cands && r < J->region_off + J->n_regions; r++) {
             const sa_region_t *R = &pl->regions[r];
             for (long long sg = R->seg_off; sg < R->seg_off + R->n_seg; sg++) {
                 const sa_seg_t *S = &pl->segs[sg];
-                long long nrows = S->from - S->to;
-                for (int c = 0; c < S->n_ck; c++) {
-                    double total = totals[S->ck_base + c];
-                    long long rows_here = nrows - (long long) c * SA_CKPT_EVERY;
-                    if (rows_here > SA_CKPT_EVERY) rows_here = SA_CKPT_EVERY;
-                    for (long long k = 0; k < rows_here; k++) likelihood_out[j] += total;  // one add per diagonal (:1432)
-                    if (!(total > -INFINITY)) continue;
-                    double sc = exp(gmc[S->ck_base + c] - total);
-                    for (int k = 0; k < 7; k++) trans9_out[j * 9 + slot[k]] += gsum[8 * (S->ck_base + c) + k] * sc;
-                }
-                if (!want_cands) continue;
                 for (int i = 0; i < counts[sg]; i++) {
                     const sa_cand_t &cd = cands[S->cand_off + i];
                     long long e = (long long) cd.x + cd.y + 2;
