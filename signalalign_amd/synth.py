@@ -275,6 +275,9 @@ def make_reads_parallel(spec, indices, workers=None):
     from concurrent.futures import ProcessPoolExecutor
     step = max(64, (len(indices) + 4 * workers - 1) // (4 * workers))
     tasks = [(spec, indices[a:a + step]) for a in range(0, len(indices), step)]
-    with ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as ex:
-        parts = list(ex.map(_reads_chunk, tasks))
+    try:
+        with ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as ex:
+            parts = list(ex.map(_reads_chunk, tasks))
+    except Exception:   # (no processes to be had: process limits, a broken pool) -- the serial loop gives the same reads
+        return _reads_chunk((spec, indices))
     return [r for part in parts for r in part]
