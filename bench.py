@@ -123,8 +123,6 @@ def bench_event_align(args):
     workload.  One step = one sa_event_align_batch call (upload, kernel, traceback, download)."""
     import signalalign_amd as sa
     from signalalign_amd import synth
-    from oracle import sa_oracle_py as oracle
-    from concurrent.futures import ThreadPoolExecutor
     alpha, k, t10, tab = synth.parse_model_table(MODEL)
     pm = sa.Model.load(MODEL)
     jobs = []
@@ -153,6 +151,8 @@ def bench_event_align(args):
                       "kernel_ms": kms / K, "c_call_ms": cms / K, "kernel_cell_updates_per_s": cells / (kms / K * 1e-3),
                       "reads_aligned": int(sum(1 for o in out if o[2] == 0)), "cells_per_read": cells / max(len(jobs), 1)}}
     if not args.no_cpu_baseline:
+        from oracle import sa_oracle_py as oracle          # the CPU restatement: timed here as the baseline, nothing else
+        from concurrent.futures import ThreadPoolExecutor
         om = oracle.Model(alpha, k, t10, tab)
         cores = min(os.cpu_count() or 1, 16)
         sample = jobs[:cores * 4]
@@ -178,8 +178,6 @@ def bench_mea(args):
     sa_mea_batch call (upload of the sparse matrices, kernel, traceback, download of the paths)."""
     import signalalign_amd as sa
     from signalalign_amd import synth
-    from oracle import sa_oracle_py as oracle
-    from concurrent.futures import ThreadPoolExecutor
     alpha, k, t10, tab = synth.parse_model_table(MODEL)
     pm = sa.Model.load(MODEL)
     reads = synth.make_jobs(args.reads, args.events, alpha, k, tab)
@@ -224,6 +222,8 @@ def bench_mea(args):
                       "paths_found": int(sum(1 for o in out if o[2] == 0)),
                       "mean_path_length": float(np.mean([len(o[0]) for o in out]))}}
     if not args.no_cpu_baseline:
+        from oracle import sa_oracle_py as oracle          # the CPU restatement: timed here as the baseline, nothing else
+        from concurrent.futures import ThreadPoolExecutor
         cores = min(os.cpu_count() or 1, 16)
         reps = max(1, int(2e7 // max(entries / len(jobs) * min(len(jobs), cores * 8), 1)))
         sample = jobs[:cores * 8]
@@ -249,8 +249,6 @@ def bench_expectations(args):
     counted as for the alignment (forward + backward cell updates)."""
     import signalalign_amd as sa
     from signalalign_amd import synth
-    from oracle import sa_oracle_py as oracle
-    from concurrent.futures import ThreadPoolExecutor
     alpha, k, t10, tab = synth.parse_model_table(MODEL)
     pm = sa.Model.load(MODEL)
     params = sa.default_params(threshold=args.threshold, expansion=50, trace_back=100)
@@ -284,6 +282,8 @@ def bench_expectations(args):
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                         "note": "whole-call rate; the per-kernel split is in profiles/ (rocprofv3 --kernel-trace --stats)"}}
     if not args.no_cpu_baseline:
+        from oracle import sa_oracle_py as oracle          # the CPU restatement: timed here as the baseline, nothing else
+        from concurrent.futures import ThreadPoolExecutor
         info = host_cpu_info()
         cores = max(1, min(len(info["allowed"]), int(info["cgroup_cpu_quota"] or 64), 16))
         om_p = oracle.default_params()
