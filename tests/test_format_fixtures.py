@@ -50,3 +50,28 @@ def test_build_kmer_list_reference_vectors(oracle):
         osh, osc = oracle.scalings_mom(om, ev, np.array(ids, dtype=np.int32))
         assert sh == osh and sc == osc
     assert sa.scalings_mom(pm, "AUGCAUGC", ev, flags=sa.FLAG_RNA) != sa.scalings_mom(pm, "ATGCATGC", ev)
+
+
+def test_golden_rna_outputs_fix_the_strand_conventions():
+    """The reference's own RNA outputs (tests/test_variantCalled_files/rna/, first 150 rows each, against
+    tests/test_sequences/fake_rna_ref.fa) state the conventions `signalMachine --rna` must keep (tests/test_gpu_cli.py checks the
+    product's files against exactly these relations):
+      forward file   positions FALL as the events advance; the target k-mer is the forward reference REVERSED in place; the
+                     reference k-mer column repeats it;
+      backward file  positions GROW; the target k-mer is the COMPLEMENT of the forward reference in place (not reversed); the
+                     reference k-mer column is its reverse complement."""
+    ref = "".join(open(os.path.join(cases.GOLDEN, "sequences", "fake_rna_ref.fa")).read().split("\n")[1:])
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    fwd = fc.check_full_rows(open(os.path.join(FMT, "rna_7d31de25.sm.forward.head150.tsv")).read(), 5, "ACGT")
+    bwd = fc.check_full_rows(open(os.path.join(FMT, "rna_8898d755.sm.backward.head150.tsv")).read(), 5, "ACGT")
+    assert len(fwd) == 150 and len(bwd) == 150
+    for r in fwd:
+        pos = int(r[1])
+        assert r[9] == ref[pos:pos + 5][::-1] and r[2] == r[9] and r[4] == "t"
+    for r in bwd:
+        pos = int(r[1])
+        assert r[9] == "".join(comp[c] for c in ref[pos:pos + 5]) and r[4] == "t"
+        assert r[2] == "".join(comp[c] for c in reversed(r[9]))
+    ev_f, pos_f = np.array([int(r[5]) for r in fwd]), np.array([int(r[1]) for r in fwd])
+    ev_b, pos_b = np.array([int(r[5]) for r in bwd]), np.array([int(r[1]) for r in bwd])
+    assert np.corrcoef(ev_f, pos_f)[0, 1] < -0.99 and np.corrcoef(ev_b, pos_b)[0, 1] > 0.99

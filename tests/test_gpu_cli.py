@@ -279,6 +279,58 @@ def test_signalmachine_rna(oracle, tmp_path):
     vrows = [l.rstrip("\n").split("\t") for l in open(vc)]
     assert vrows and all(v[4] == "t" and v[5] == "forward" for v in vrows)
 
+    # ---- the same read family mapped to the MINUS strand.  The reference's own RNA outputs fix the conventions
+    # (tests/test_variantCalled_files/rna/: in 8898d755-...sm.backward.tsv positions grow with the events, the target k-mer is the
+    # COMPLEMENT of the forward reference at its position -- not reversed -- and the reference k-mer column its reverse
+    # complement; in 7d31de25-...sm.forward.tsv positions fall, target k-mer = REVERSED forward reference = reference k-mer column)
+    B = seq_of(bwd_fa)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    read_m = ("".join("ACGT"[i] for i in rng.integers(0, 4, pad)) + "".join(comp[c] for c in F0[a:b]) +
+              "".join("ACGT"[i] for i in rng.integers(0, 4, pad)))
+    ev_m, emap_m = cases.events_for_sequence(read_m, model, 78)
+    np_m = str(tmp_path / "rna_minus.npRead")
+    cases.write_npread_1d(np_m, read_m, emap_m, ev_m)
+    cigar_m = str(tmp_path / "guide_minus.cigar")
+    with open(cigar_m, "w") as f:
+        f.write("cigar: rna2 %d %d + rna_fake %d %d - 1 M %d\n" % (pad, Lr - pad, b, a, L))
+    out_m = str(tmp_path / "rna_minus.tsv")
+    pr = subprocess.run([BIN, "-T", model, "-q", np_m, "-f", fwd_fa, "-b", bwd_fa, "-n", "rna_fake", "-p", cigar_m, "-u", out_m,
+                         "-L", "rna2", "-s", "0", "-g", "100", "--rna"], capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr
+    r2 = oracle.parse_npread(np_m)
+    ev3 = r2["template_events"].copy()
+    prm2 = oracle.estimate_params(om, r2["template_strand_event_map"], ev3, read_m)
+    target_m = B[a:b]                                           # the backward file's bases in forward order
+    gx, gy = oracle.guide_to_anchors(a, b, 1, pad, [(0, L)], 14)   # start1 and end1 swapped, strand flipped to forward
+    em2 = r2["template_strand_event_map"]
+    ax, ay = oracle.remap_anchors(gx, gy, em2, pad)
+    lo2, hi2 = int(em2[pad]), int(em2[Lr - pad - 1])
+    om.set_read_params(prm2["scale"], prm2["shift"], prm2["var"])
+    pairs_m = oracle.align(om, target_m, ev3[lo2:hi2], ax, ay, oracle.default_params())
+    got_m = [l.rstrip("\n").split("\t") for l in open(out_m)]
+    assert len(got_m) == len(pairs_m) > 1000
+    rc_ = lambda s_: "".join({"A": "T", "C": "G", "G": "C", "T": "A"}.get(c, c) for c in reversed(s_))
+    for g, p_ in zip(got_m, pairs_m):
+        x, y = int(p_["x"]), int(p_["y"]) + lo2
+        k_i = target_m[x:x + k]
+        assert int(g[1]) == x + a and int(g[5]) == y and g[9] == k_i and g[2] == rc_(k_i), (g, x, y)
+        assert abs(float(g[12]) - int(p_["prob_e7"]) / 1e7) <= 1e-5
+    # the conventions of the reference's files, on positions without an ambiguity letter: complement of the forward
+    # reference in place (minus strand), reversed forward reference (plus strand, first run above)
+    for g in got_m[::37]:
+        if "X" not in g[9]:
+            assert g[9] == "".join(comp[c] for c in F0[int(g[1]):int(g[1]) + k])
+    for g in got[::37]:
+        gf = g.rstrip("\n").split("\t")
+        if "X" not in gf[9]:
+            assert gf[9] == F0[int(gf[1]):int(gf[1]) + k][::-1] and gf[2] == gf[9]
+    vc_m = str(tmp_path / "rna_minus_vc.tsv")
+    pr = subprocess.run([BIN, "-T", model, "-q", np_m, "-f", fwd_fa, "-b", bwd_fa, "-n", "rna_fake", "-p", cigar_m, "-u", vc_m,
+                         "-L", "rna2", "-s", "1", "-g", "100", "--rna"], capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, pr.stderr
+    vm = [l.rstrip("\n").split("\t") for l in open(vc_m)]
+    assert vm and all(v[4] == "t" and v[5] == "backward" for v in vm)
+
 
 def test_signalmachine_two_d_read_against_the_reference_output(oracle, tmp_path):
     """The reference's own output for the bundled 2-D read (tests/test_alignments/zymo_C_test_alignments_sm3/...7f22f937...,
