@@ -74,4 +74,6 @@ def test_golden_rna_outputs_fix_the_strand_conventions():
         assert r[2] == "".join(comp[c] for c in reversed(r[9]))
     ev_f, pos_f = np.array([int(r[5]) for r in fwd]), np.array([int(r[1]) for r in fwd])
     ev_b, pos_b = np.array([int(r[5]) for r in bwd]), np.array([int(r[1]) for r in bwd])
-    assert np.corrcoef(ev_f, pos_f)[0, 1] < -0.99 and np.corrcoef(ev_b, pos_b)[0, 1] > 0.99
+    # (events stall and jump along a real read: the sign of the trend is what the conventions fix)
+    assert np.corrcoef(ev_f, pos_f)[0, 1] < -0.7 and np.corrcoef(ev_b, pos_b)[0, 1] > 0.7
+    assert pos_f[0] > pos_f[-1] and pos_b[0] < pos_b[-1]
