@@ -43,7 +43,7 @@ const char *sa_strerror(int code) {
     }
     return "unknown error";
 }
-const char *sa_version(void) { return "signalalign_hip 0.1 (gfx950)"; }
+const char *sa_version(void) { return "signalalign_hip 0.3 (gfx950)"; }
 void sa_free(void *p) { free(p); }
 
 /* test hook (host only): pairs through the 16-byte record they cross PCIe in (sa_internal.h) and back */
