@@ -392,7 +392,11 @@ def measure(args, ctx, compact=False):
         for js in sets:
             for j_ in js:
                 j_["events"] = np.ascontiguousarray(np.asarray(j_["events"])[:, 0])
-    arrays = [sa.JobArray(js) for js in sets]          # marshalled once: a C caller holds sa_job_t arrays anyway
+    # marshalled once: a C caller holds sa_job_t arrays anyway.  --inputs host-block: the event records and anchors live in one
+    # page-locked block per read set (sa_host_alloc), as a caller that reads its inputs into such a block has them
+    in_block = args.inputs == "host-block"
+    xflags = sa.FLAG_INPUTS_IN_HOST_BLOCK if in_block else 0
+    arrays = [sa.JobArray(js, host_block=in_block) for js in sets]
     n_events_total = sum(len(j["events"]) for j in jobs)
 
     def sync():
@@ -404,7 +408,7 @@ def measure(args, ctx, compact=False):
 
     # ---- phase 1 (not the headline): the kernels alone, on a batch whose plan and inputs are resident in HBM ----
     t_create = time.perf_counter()
-    batch = sa.Batch(pm, params, arrays[0], ambig=ambig, device=device)
+    batch = sa.Batch(pm, params, arrays[0], ambig=ambig, device=device, flags=xflags)
     t_create = time.perf_counter() - t_create
     st0 = batch.stats()
     cells = st0.cells_forward + st0.cells_backward
@@ -429,7 +433,7 @@ def measure(args, ctx, compact=False):
         samples = []
         for q in range(1 if args.workload == "scaling" or compact else 5):
             tc0 = time.perf_counter()
-            bb = sa.Batch(pm, params, arrays[(q + 1) % n_sets], ambig=ambig, device=device)
+            bb = sa.Batch(pm, params, arrays[(q + 1) % n_sets], ambig=ambig, device=device, flags=xflags)
             tc1 = time.perf_counter()
             bb.run()
             tc2 = time.perf_counter()
@@ -465,7 +469,7 @@ def measure(args, ctx, compact=False):
             # creation -- working buffers sized for the device to itself -- follows when the current one has been destroyed
             def make(s_):
                 return sa.Batch(pm, params, arrays[(first + s_) % n_sets], ambig=ambig, device=device, deferred=True,
-                                flags=sa.FLAG_DEVICE_TO_ITSELF)
+                                flags=sa.FLAG_DEVICE_TO_ITSELF | xflags)
             nxt = make(0) if n_steps > 0 else None
             dbg = os.environ.get("SA_BENCH_DEBUG")
             for s in range(n_steps):
@@ -487,29 +491,38 @@ def measure(args, ctx, compact=False):
                           file=sys.stderr)
             return
         dbg = os.environ.get("SA_BENCH_DEBUG")
+        defer = bool(os.environ.get("SA_BENCH_DEFER"))   # (experiment hook)
+
+        def retire(old):
+            old.wait()
+            if defer:
+                stc = old.stats()
+                cells_done[0] += stc.cells_forward + stc.cells_backward
+                groups_seen[0] = int(stc.n_groups)
+            old.n_pairs(0)
+            old.close()
+
         for s in range(n_steps):
             t_a = time.perf_counter()
-            cur = sa.Batch(pm, params, arrays[(first + s) % n_sets], ambig=ambig, device=device)
-            stc = cur.stats()
-            cells_done[0] += stc.cells_forward + stc.cells_backward
-            groups_seen[0] = int(stc.n_groups)
+            # (creation in one piece, also with host-block inputs: created in two halves the batches start in pairs, their
+            # block transfers queue behind each other and their kernels share the chip -- 19.6 against 12 ms per step)
+            cur = sa.Batch(pm, params, arrays[(first + s) % n_sets], ambig=ambig, device=device, flags=xflags, deferred=defer)
+            if not defer:
+                stc = cur.stats()
+                cells_done[0] += stc.cells_forward + stc.cells_backward
+                groups_seen[0] = int(stc.n_groups)
             t_b = time.perf_counter()
             cur.start()
             flying.append(cur)
             if len(flying) >= depth:
-                old = flying.pop(0)
-                old.wait()
-                old.n_pairs(0)
-                old.close()
+                retire(flying.pop(0))
             if dbg:
                 thr = open("/sys/fs/cgroup/cpu.stat").read().split() if os.path.exists("/sys/fs/cgroup/cpu.stat") else []
                 nthr = thr[thr.index("nr_throttled") + 1] if "nr_throttled" in thr else "?"
                 print("[bench] step %d: create %.1f ms, step %.1f ms, cgroup nr_throttled %s"
                       % (s, (t_b - t_a) * 1e3, (time.perf_counter() - t_a) * 1e3, nthr), file=sys.stderr)
         for old in flying:
-            old.wait()
-            old.n_pairs(0)
-            old.close()
+            retire(old)
 
     if args.kernels_only:
         dt, cells_done[0] = dt_resident * args.steps, cells * args.steps
@@ -608,7 +621,7 @@ def measure(args, ctx, compact=False):
             "config": {
                 "workload": "%s, %d synthetic %d-event reads per GPU, band=50, threshold %g, traceBackDiagonals 100"
                             % (wl_name, args.reads, args.events, args.threshold),
-                "reads_per_gpu": args.reads, "events_per_read": args.events, "event_stride": args.event_stride,
+                "reads_per_gpu": args.reads, "events_per_read": args.events, "event_stride": args.event_stride, "inputs": args.inputs,
                 "host_threads": os.environ.get("SA_HOST_THREADS"),
                 "events_per_s": events_all / dt,
                 "cells_per_event": cells / max(n_events_total, 1),
@@ -666,7 +679,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--in-flight", type=int, default=3, help="batches in flight in the timed pipeline (create of the next "
+    ap.add_argument("--in-flight", type=int, default=4, help="batches in flight in the timed pipeline (create of the next "
                                                             "overlaps the runs of the previous ones)")
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU (default: 2000 = BASELINE configs[1]; "
                                                              "scaling: 12500 = configs[4]'s 100k reads / 8 GPUs)")
@@ -684,6 +697,10 @@ def main():
                     help="layout of the events a job hands over: 4 = the reference's NB_EVENT_PARAMS records (mean, noise, "
                          "duration, start: what signalMachine holds; the library gathers the means), 1 = a dense vector of means "
                          "(sa_job_t.event_stride; a quarter of the host memory traffic of sa_batch_create)")
+    ap.add_argument("--inputs", choices=["pageable", "host-block"], default="pageable",
+                    help="host-block: the reads' event records and anchors are handed over in one page-locked block from "
+                         "sa_host_alloc (SA_FLAG_INPUTS_IN_HOST_BLOCK): one DMA, checked and packed by a kernel instead of by "
+                         "host threads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernels-only", action="store_true", help="phase 1 only (sa_batch_run on one resident batch): for "
                                                                 "profiler runs that count per-kernel launches")
@@ -751,7 +768,11 @@ def main():
         for wl in ("realistic", "cpg"):
             a2 = copy.copy(args)
             a2.workload, a2.reads, a2.events, a2.threshold = wl, 2000, 5000, 0.01
-            a2.steps, a2.warmup, a2.no_cpu_baseline = max(4, min(args.steps, 10)), 5, True   # (warm-up: three batches' pinned blocks)
+            # (warm-up: the batches in flight plus two must have been through the caching allocators, which start empty -- the
+            # blocks the previous workload left parked have other sizes)
+            a2.steps, a2.warmup, a2.no_cpu_baseline = max(4, min(args.steps, 10)), max(5, args.in_flight + 3), True
+            import signalalign_amd as sa
+            sa.lib().sa_pool_release()
             r2 = measure(a2, ctx, compact=True)
             rf = r2["roofline"]
             out["config"]["secondary"][wl] = {

@@ -47,6 +47,19 @@ extern "C" {
                                      complete the creation too), the working buffers may not fit and that call returns
                                      SA_ENOMEM; the batch can then only be destroyed */
 
+#define SA_FLAG_INPUTS_IN_HOST_BLOCK 16u /* every job's `events`, `anchor_x` and `anchor_y` point into ONE block from sa_host_alloc
+                                     (8-byte aligned inside it).  The library then does not read them on the host at all: the
+                                     part of the block that holds them crosses PCIe with one DMA and a kernel checks the
+                                     anchors, narrows them and gathers the event means out of their records -- what
+                                     sa_batch_create otherwise does with host cores (416 MB per 2000 reads of 50 000 events
+                                     in the reference's four-double records: two host threads cannot keep up with the GPU).
+                                     The block must stay unchanged until sa_batch_create has returned (for
+                                     sa_batch_create_deferred: until the batch's first use has, as for `jobs`).  Pointers
+                                     outside such a block: SA_EINVAL.  Everything else is as without the flag -- a read the
+                                     device checks turn down sends the batch to the host planner, which reads the same
+                                     memory and names the error -- and the flag is ignored by batches the host plans
+                                     (SA_FLAG_EXACT, ...) and by sa_expect_batch's SA_EMISSION_TWO_DIST models */
+
 typedef struct sa_model sa_model_t; /* replaces StateMachine3 / StateMachine3_HDP (inc/stateMachine.h:150-190) */
 typedef struct sa_batch sa_batch_t;
 
@@ -274,8 +287,12 @@ int sa_fasta_subsequence(const char *fasta_path, const char *name, int64_t start
  *   sa_pool_configure(device_limit_bytes, pinned_limit_bytes)   a negative value leaves that bound as it is; 0 keeps nothing
  *       parked; blocks above a lowered bound are freed at once.  Wins over the environment.
  *   sa_pool_release()                                           returns everything that is parked right now.
+ * sa_host_alloc / sa_host_free: page-locked host memory for a caller's own input arrays (SA_FLAG_INPUTS_IN_HOST_BLOCK); a
+ * block belongs to the caller until sa_host_free, which must not be called while a batch created from it is being created.
  * Environment (read when no limit was configured): SA_POOL=0 disables the cache, SA_POOL_LIMIT_GB bounds both kinds. */
 int sa_pool_configure(int64_t device_limit_bytes, int64_t pinned_limit_bytes);
+void *sa_host_alloc(size_t bytes);   /* NULL: no memory (or no device) */
+void sa_host_free(void *block);      /* NULL or a pointer sa_host_alloc did not return: ignored */
 void sa_pool_release(void);
 
 /* ---- maximum-expected-accuracy path over a read's posteriors ----------------------------------

@@ -12,6 +12,7 @@ _LIB = None
 FLAG_EXACT = 1
 FLAG_FORCE_GENERIC = 2
 FLAG_DEVICE_TO_ITSELF = 8
+FLAG_INPUTS_IN_HOST_BLOCK = 16
 
 
 class SaError(RuntimeError):
@@ -80,7 +81,7 @@ EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alp
            "sa_batch_create", "sa_batch_create_deferred", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_stats",
            "sa_batch_job_cells", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_plan_describe", "sa_plan_digest",
            "sa_plan_check_path_records", "sa_dplan_compare",
-           "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_pool_configure", "sa_pair_roundtrip", "sa_fasta_subsequence", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_device_memory", "sa_strerror",
+           "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_pool_configure", "sa_host_alloc", "sa_host_free", "sa_pair_roundtrip", "sa_fasta_subsequence", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_device_memory", "sa_strerror",
            "sa_version", "sa_free"]
 
 
@@ -135,6 +136,10 @@ def lib():
     L.sa_dplan_compare.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Job), C.c_int64, C.POINTER(C.c_char_p), C.c_int,
                                    C.c_uint]
     L.sa_pool_configure.argtypes = [C.c_int64, C.c_int64]
+    L.sa_host_alloc.argtypes = [C.c_size_t]
+    L.sa_host_alloc.restype = C.c_void_p
+    L.sa_host_free.argtypes = [C.c_void_p]
+    L.sa_host_free.restype = None
     L.sa_batch_n_pairs.argtypes = [C.c_void_p, C.c_int64, ip]
     L.sa_batch_pairs.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
     L.sa_batch_stats.argtypes = [C.c_void_p, C.POINTER(BatchStats)]
@@ -275,12 +280,71 @@ def _make_jobs(jobs):
     return arr, keep
 
 
+class HostBlock:
+    """sa_host_alloc: one page-locked block; empty(shape, dtype) carves 8-byte aligned numpy arrays out of it (for the event
+    records and anchor arrays of jobs passed with FLAG_INPUTS_IN_HOST_BLOCK)."""
+
+    def __init__(self, nbytes):
+        L = lib()
+        self.nbytes = int(nbytes)
+        self._p = L.sa_host_alloc(self.nbytes)
+        if not self._p:
+            raise SaError(-2, "sa_host_alloc")
+        self._buf = (C.c_char * self.nbytes).from_address(self._p)
+        self._used = 0
+
+    def empty(self, shape, dtype):
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+        off = (self._used + 7) & ~7
+        if off + n * dt.itemsize > self.nbytes:
+            raise ValueError("HostBlock: full")
+        self._used = off + n * dt.itemsize
+        return np.frombuffer(self._buf, dtype=dt, count=n, offset=off).reshape(shape)
+
+    def close(self):
+        if self._p:
+            self._buf = None
+            lib().sa_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def jobs_bytes_in_block(jobs):
+    """Bytes a HostBlock needs for these jobs' event records and anchors."""
+    n = 0
+    for j in jobs:
+        n += (np.asarray(j["events"]).size * 8 + 7) & ~7
+        n += 2 * 8 * len(j["ax"])
+    return n + 64
+
+
 class JobArray:
     """A list of jobs marshalled once into the C array sa_batch_create takes (a C caller has it anyway; building it costs
-    Python several milliseconds per thousand reads).  Pass it to Batch in place of the list."""
+    Python several milliseconds per thousand reads).  Pass it to Batch in place of the list.
+    host_block=True: the event records and anchor arrays are copied into one sa_host_alloc block (self.block), as a caller
+    that reads its inputs straight into page-locked memory has them; pass FLAG_INPUTS_IN_HOST_BLOCK with it."""
 
-    def __init__(self, jobs):
+    def __init__(self, jobs, host_block=False, interleaved=False):
         self.n = len(jobs)
+        self.block = None
+        if host_block:
+            self.block = HostBlock(jobs_bytes_in_block(jobs))
+            moved = [dict(j) for j in jobs]
+            if interleaved:          # read after read: events, anchors, events, ...
+                order = [(q, key) for q in moved for key in ("events", "ax", "ay")]
+            else:                    # all event records, then all anchors (the library then sends the block in two pieces)
+                order = [(q, "events") for q in moved] + [(q, key) for q in moved for key in ("ax", "ay")]
+            for q, key in order:
+                src = np.asarray(q[key], dtype=np.float64 if key == "events" else np.int64)
+                q[key] = self.block.empty(src.shape, src.dtype)
+                q[key][...] = src
+            jobs = moved
         self.arr, self._keep = _make_jobs(jobs)
 
 
@@ -570,9 +634,13 @@ def plan_check_path_records(model, params, job, ambig=None):
 
 def dplan_compare(model, params, jobs, ambig=None, device=0, flags=0):
     """Test hook (GPU): 0 when the device planner and the host planner produce identical arrays for `jobs`."""
-    arr, keep = _make_jobs(jobs)
+    if isinstance(jobs, JobArray):
+        arr, keep, n = jobs.arr, jobs, jobs.n
+    else:
+        arr, keep = _make_jobs(jobs)
+        n = len(jobs)
     amb = ambig if ambig is not None else default_ambig()
-    rc = lib().sa_dplan_compare(model._h, C.byref(params), arr, len(jobs), amb, device, flags)
+    rc = lib().sa_dplan_compare(model._h, C.byref(params), arr, n, amb, device, flags)
     del keep
     if rc < 0:
         _chk(rc, "sa_dplan_compare")

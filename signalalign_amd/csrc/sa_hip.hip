@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -947,6 +948,8 @@ struct sa_batch {
     // device buffers
     sa_region_t *d_regions; sa_row_t *d_rows; int *d_pk; int *d_poff; int *d_pid; int *d_px; double *d_xc; double *d_ev;
     sa_prec_t *d_prec;
+    char *d_blk;           // SA_FLAG_INPUTS_IN_HOST_BLOCK: the image of the caller's block (its event records are gathered on this
+                           // batch's own stream, possibly after sa_batch_create has returned: kept until the batch goes)
     sa_seg_t *d_segs; sa_ck_t *d_cks;
     double *d_F; double *d_E; double *d_vbuf; sa_cand_t *d_cands; int *d_cand_count; int *d_overflow; double *d_totals;
     double *d_bscratch;
@@ -1229,6 +1232,40 @@ extern "C" int sa_pool_configure(int64_t device_limit_bytes, int64_t pinned_limi
     return SA_OK;
 }
 
+// sa_host_alloc: page-locked blocks a caller fills with its reads' arrays (SA_FLAG_INPUTS_IN_HOST_BLOCK).  hipHostMalloc's default
+// flags make them visible to every device of the process; the registry is what lets sa_batch_create check that a job's pointers
+// really lie in such a block before a DMA is pointed at them.
+static std::mutex g_host_blocks_mu;
+static std::map<const char *, size_t> g_host_blocks;   // first byte -> bytes
+extern "C" void *sa_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes > 0 ? bytes : 8, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    std::lock_guard<std::mutex> g(g_host_blocks_mu);
+    g_host_blocks[(const char *) p] = bytes > 0 ? bytes : 8;
+    return p;
+}
+extern "C" void sa_host_free(void *block) {
+    if (!block) return;
+    {
+        std::lock_guard<std::mutex> g(g_host_blocks_mu);
+        auto it = g_host_blocks.find((const char *) block);
+        if (it == g_host_blocks.end()) return;
+        g_host_blocks.erase(it);
+    }
+    (void) hipHostFree(block);
+}
+// the block that holds `p`, if any
+static bool sa_host_block_of(const char *p, const char **base, size_t *bytes) {
+    std::lock_guard<std::mutex> g(g_host_blocks_mu);
+    auto it = g_host_blocks.upper_bound(p);
+    if (it == g_host_blocks.begin()) return false;
+    --it;
+    if (p >= it->first + it->second) return false;
+    *base = it->first;
+    *bytes = it->second;
+    return true;
+}
+
 extern "C" void sa_pool_release(void) {
     g_sa_pool.release(SaPool::DEVICE);
     g_sa_pool.release(SaPool::PINNED);
@@ -1290,7 +1327,7 @@ void sa_batch_destroy(sa_batch_t *b) {
     void *ptrs[] = {b->d_regions, b->d_rows, b->d_pk, b->d_poff, b->d_pid, b->d_px, b->d_xc, b->d_prec, b->d_ev, b->d_segs, b->d_cks, b->d_F, b->d_E,
                     b->d_vbuf, b->d_cands, b->d_cand_count, b->d_overflow, b->d_totals, b->d_bscratch, b->d_tab6, b->d_noise3, b->d_evn,
                     b->d_hdp_slot, b->d_hdp_y, b->d_hdp_slope, b->d_hdp_grid, b->d_hdp_tab, b->d_prob, b->d_seg_pass, b->d_seg_off,
-                    b->d_out, b->d_ids, b->d_gsum, b->d_gmc, b->d_seam, b->d_ckxy};
+                    b->d_out, b->d_ids, b->d_gsum, b->d_gmc, b->d_seam, b->d_ckxy, b->d_blk};
     for (void *p : ptrs)
         if (p) g_sa_pool.put(SaPool::DEVICE, p);
     for (int i = 0; i < 8; i++)
@@ -1362,7 +1399,7 @@ static int batch_create_impl(sa_batch_t **out, const sa_model_t *m, const sa_par
     b->quiet = false;
     b->runner = nullptr; b->runner_rc = SA_OK;
     b->d_regions = nullptr; b->d_rows = nullptr; b->d_pk = nullptr; b->d_poff = nullptr; b->d_pid = nullptr; b->d_px = nullptr; b->d_xc = nullptr;
-    b->d_prec = nullptr;
+    b->d_prec = nullptr; b->d_blk = nullptr;
     b->d_ev = nullptr; b->d_segs = nullptr; b->d_cks = nullptr; b->d_F = nullptr; b->d_E = nullptr; b->d_vbuf = nullptr;
     b->d_cands = nullptr; b->d_cand_count = nullptr; b->d_overflow = nullptr; b->d_totals = nullptr;
     b->d_seam = nullptr; b->d_ckxy = nullptr; b->seam_cap = 0; b->seam_cap_bwd = 0; b->seam_bwd_off = 0; b->strip_on = false;
@@ -1862,7 +1899,7 @@ int sa_dplan_compare(const sa_model_t *m, const sa_params_t *p, const sa_job_t *
     b->h_pairs = nullptr; b->d_pairs_up = nullptr; b->h_seg_off = nullptr; b->h_overflow = nullptr;
     for (int i = 0; i < 8; i++) b->ev[i] = nullptr;
     b->d_regions = nullptr; b->d_rows = nullptr; b->d_pk = nullptr; b->d_poff = nullptr; b->d_pid = nullptr; b->d_px = nullptr; b->d_xc = nullptr;
-    b->d_prec = nullptr; b->d_ev = nullptr; b->d_segs = nullptr; b->d_cks = nullptr; b->d_F = nullptr; b->d_E = nullptr; b->d_vbuf = nullptr;
+    b->d_prec = nullptr; b->d_blk = nullptr; b->d_ev = nullptr; b->d_segs = nullptr; b->d_cks = nullptr; b->d_F = nullptr; b->d_E = nullptr; b->d_vbuf = nullptr;
     b->d_cands = nullptr; b->d_cand_count = nullptr; b->d_overflow = nullptr; b->d_totals = nullptr; b->d_bscratch = nullptr;
     b->d_tab6 = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr; b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr;
     b->d_hdp_tab = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr; b->d_seg_off = nullptr; b->d_out = nullptr;
