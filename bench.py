@@ -394,9 +394,22 @@ def measure(args, ctx, compact=False):
                 j_["events"] = np.ascontiguousarray(np.asarray(j_["events"])[:, 0])
     # marshalled once: a C caller holds sa_job_t arrays anyway.  --inputs host-block: the event records and anchors live in one
     # page-locked block per read set (sa_host_alloc), as a caller that reads its inputs into such a block has them
-    in_block = args.inputs == "host-block"
+    # auto: host-block when this rank has few host threads to pack pageable inputs with (ranks of an 8-GPU run under a 16-CPU
+    # quota get two: 16.4 against 11.0 ms per step) and the block is of moderate size; pageable otherwise (faster
+    # when host threads are plentiful: a third of the bytes cross PCIe)
+    from signalalign_amd._capi import jobs_bytes_in_block
+    host_threads = int(os.environ.get("SA_HOST_THREADS") or 0)
+    in_block = args.inputs == "host-block" or (args.inputs == "auto" and 0 < host_threads <= 3 and
+                                               max(jobs_bytes_in_block(js) for js in sets) <= (2 << 30))
+    try:
+        arrays = [sa.JobArray(js, host_block=in_block) for js in sets]
+    except sa.SaError:
+        if args.inputs != "auto":
+            raise
+        in_block = False
+        arrays = [sa.JobArray(js) for js in sets]
     xflags = sa.FLAG_INPUTS_IN_HOST_BLOCK if in_block else 0
-    arrays = [sa.JobArray(js, host_block=in_block) for js in sets]
+    inputs_used = "host-block" if in_block else "pageable"
     n_events_total = sum(len(j["events"]) for j in jobs)
 
     def sync():
@@ -621,7 +634,8 @@ def measure(args, ctx, compact=False):
             "config": {
                 "workload": "%s, %d synthetic %d-event reads per GPU, band=50, threshold %g, traceBackDiagonals 100"
                             % (wl_name, args.reads, args.events, args.threshold),
-                "reads_per_gpu": args.reads, "events_per_read": args.events, "event_stride": args.event_stride, "inputs": args.inputs,
+                "reads_per_gpu": args.reads, "events_per_read": args.events, "event_stride": args.event_stride,
+                "inputs": inputs_used if args.inputs != "auto" else inputs_used + " (auto: host-block when SA_HOST_THREADS <= 3)",
                 "host_threads": os.environ.get("SA_HOST_THREADS"),
                 "events_per_s": events_all / dt,
                 "cells_per_event": cells / max(n_events_total, 1),
@@ -697,10 +711,11 @@ def main():
                     help="layout of the events a job hands over: 4 = the reference's NB_EVENT_PARAMS records (mean, noise, "
                          "duration, start: what signalMachine holds; the library gathers the means), 1 = a dense vector of means "
                          "(sa_job_t.event_stride; a quarter of the host memory traffic of sa_batch_create)")
-    ap.add_argument("--inputs", choices=["pageable", "host-block"], default="pageable",
+    ap.add_argument("--inputs", choices=["auto", "pageable", "host-block"], default="auto",
                     help="host-block: the reads' event records and anchors are handed over in one page-locked block from "
-                         "sa_host_alloc (SA_FLAG_INPUTS_IN_HOST_BLOCK): one DMA, checked and packed by a kernel instead of by "
-                         "host threads")
+                         "sa_host_alloc (SA_FLAG_INPUTS_IN_HOST_BLOCK): sent as they are, checked and packed by a kernel instead "
+                         "of by host threads.  auto (default): host-block when the rank has at most three host threads "
+                         "(SA_HOST_THREADS, set from the CPU quota for multi-rank runs), pageable otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernels-only", action="store_true", help="phase 1 only (sa_batch_run on one resident batch): for "
                                                                 "profiler runs that count per-kernel launches")
