@@ -25,6 +25,8 @@ ph = sa.Model.load(cases.MODEL_R73, cases.NHDP)
 ph.set_to_hdp_expected_values()
 sets = [sa.JobArray(synth.make_jobs(200, 2000, alpha, k, tab, first_index=1000 * q)) for q in range(4)]
 hsets = [sa.JobArray(cases.hdp_jobs(100, 1500, 500 * q, table5=ph.table5())) for q in range(2)]
+# the same reads in page-locked blocks of the caller (SA_FLAG_INPUTS_IN_HOST_BLOCK), anchors and events apart / interleaved
+bsets = [sa.JobArray(synth.make_jobs(200, 2000, alpha, k, tab, first_index=1000 * q), host_block=True, interleaved=bool(q & 1)) for q in range(4)]
 p = sa.default_params()
 ph_p = sa.default_params(threshold=0.1)
 t0 = time.time()
@@ -38,6 +40,18 @@ for c in range(cycles):
     b.close()
     if c % 5 == 0:
         sa.expect_batch(pm, p, sets[(c + 1) % 4])
+    if c % 2 == 0:
+        b = sa.Batch(pm, p, bsets[c % 4], flags=sa.FLAG_INPUTS_IN_HOST_BLOCK, deferred=(c % 4 == 0))
+        if c % 8 == 6:
+            b.close()          # created, never run: the event records may still be on their way
+        else:
+            b.start()
+            b.wait()
+            pairs += b.n_pairs(c % 200)
+            b.close()
+    if c % 400 == 399:         # blocks come and go
+        q = (c // 400) % 4
+        bsets[q] = sa.JobArray(synth.make_jobs(200, 2000, alpha, k, tab, first_index=1000 * q + c), host_block=True, interleaved=bool(q & 1))
     if c % 3 == 0:
         h = sa.Batch(ph, ph_p, hsets[c % 2])
         h.run()
