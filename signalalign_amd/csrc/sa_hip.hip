@@ -167,12 +167,71 @@ __device__ __forceinline__ bool legal_step(const DevModel &m, int from, int to) 
     return (from % m.pow_km1) == (to / m.n_alpha);
 }
 
+// Maximum over the 64 lanes, wave-uniform (values may be -inf, never NaN).  Six DPP steps -- butterflies inside a row of 16
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then row_bcast15 into rows 1 and 3 and row_bcast31 into rows 2 and 3 --
+// leave the maximum in lane 63, which v_readlane hands to every lane as a scalar: 33 issue slots.  The generic __shfl_xor
+// butterfly costs 85 per reduction (ds_bpermute pairs, lane arithmetic, selects, their waits and hazards), and the backward
+// sweeps reduce twice per checkpoint, i.e. twice per ten diagonals: an eighth of k_bwd_fast's instructions.
+// A lane without a source (or outside the row mask) keeps `old` = its own value: max(v, v).
 __device__ __forceinline__ double wave_max(double v) {
+#ifdef SA_WAVE_REDUCE_SHFL   // (A/B build: the former butterfly)
     for (int off = 32; off > 0; off >>= 1) {
         double o = __shfl_xor(v, off, 64);
         v = o > v ? o : v;
     }
     return v;
+#endif
+    int lo_, hi_;
+    double o_;
+    // (butterflies: every lane has a source, the move needs no old value -- no copy in front of it)
+#define SA_WMAX_BFLY(CTRL)                                                                       \
+    lo_ = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, false);                    \
+    hi_ = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, false);                    \
+    o_ = __hiloint2double(hi_, lo_);                                                             \
+    asm("v_max_f64 %0, %1, %2" : "=v"(v) : "v"(v), "v"(o_));
+    // (broadcasts: a lane outside the row mask keeps what the previous step left in the same registers -- a value that
+    // already went into its maximum)
+#define SA_WMAX_BCAST(CTRL, ROWS)                                                                \
+    lo_ = __builtin_amdgcn_update_dpp(lo_, __double2loint(v), CTRL, ROWS, 0xF, false);           \
+    hi_ = __builtin_amdgcn_update_dpp(hi_, __double2hiint(v), CTRL, ROWS, 0xF, false);           \
+    o_ = __hiloint2double(hi_, lo_);                                                             \
+    asm("v_max_f64 %0, %1, %2" : "=v"(v) : "v"(v), "v"(o_));
+    SA_WMAX_BFLY(0xB1)           // quad_perm:[1,0,3,2]
+    SA_WMAX_BFLY(0x4E)           // quad_perm:[2,3,0,1]
+    SA_WMAX_BFLY(0x141)          // row_half_mirror
+    SA_WMAX_BFLY(0x140)          // row_mirror: every lane holds its row's maximum
+    SA_WMAX_BCAST(0x142, 0xA)    // row_bcast15 -> rows 1, 3
+    SA_WMAX_BCAST(0x143, 0xC)    // row_bcast31 -> rows 2, 3: lane 63 holds the wave's
+#undef SA_WMAX_BFLY
+#undef SA_WMAX_BCAST
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+// Sum over the 64 lanes, wave-uniform, with the same six DPP steps (the butterflies are true pairings, so every lane of a row
+// ends with its row's sum; a lane outside a broadcast's row mask adds 0.0).  The order of the additions differs from a serial
+// sum's, as the __shfl_xor butterfly's did.
+__device__ __forceinline__ double wave_sum(double v) {
+#ifdef SA_WAVE_REDUCE_SHFL
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+#endif
+    int lo_, hi_;
+#define SA_WSUM_BFLY(CTRL)                                                                       \
+    lo_ = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, false);                    \
+    hi_ = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, false);                    \
+    v += __hiloint2double(hi_, lo_);
+#define SA_WSUM_BCAST(CTRL, ROWS)                                                                \
+    lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWS, 0xF, false);             \
+    hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWS, 0xF, false);             \
+    v += __hiloint2double(hi_, lo_);
+    SA_WSUM_BFLY(0xB1)
+    SA_WSUM_BFLY(0x4E)
+    SA_WSUM_BFLY(0x141)
+    SA_WSUM_BFLY(0x140)
+    SA_WSUM_BCAST(0x142, 0xA)
+    SA_WSUM_BCAST(0x143, 0xC)
+#undef SA_WSUM_BFLY
+#undef SA_WSUM_BCAST
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 __device__ __forceinline__ int wave_max_i(int v) {
     for (int off = 32; off > 0; off >>= 1) {
@@ -369,8 +428,7 @@ __global__ __launch_bounds__(128) void k_fwd_generic(DevPlan P, const int *regio
 // rescales by exp(Mc - totalProbability) once the exact fold of the group's total is known.
 __device__ __forceinline__ void expect_flush(const DevPlan &P, long long ck, double Mc, double *acc, int lane) {
     for (int k = 0; k < 7; k++) {
-        double v = acc[k];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        const double v = wave_sum(acc[k]);
         if (lane == 0) P.gsum[ck * 8 + k] = v;
         acc[k] = 0.0;
     }
