@@ -585,10 +585,16 @@ def measure(args, ctx, compact=False):
         fam = "fast" if st0.n_fast_regions == st0.n_regions else ("ring" if st0.n_ring_regions > 0 else "generic")
         if fam == "ring" and 2 * st0.n_strip_regions > st0.n_ring_regions:
             fam = "strip"
+        sfx = "_hdp" if (args.workload == "hdp" and fam == "fast") else ""
         if ms_b >= ms_f:
-            dom, dom_ms, dom_cells = "k_bwd_" + fam, ms_b, st0.cells_backward
+            dom, dom_ms, dom_cells = "k_bwd_" + fam + sfx, ms_b, st0.cells_backward
+            dom_parts = [dom]
         else:
-            dom, dom_ms, dom_cells = "k_fwd_" + fam, ms_f, st0.cells_forward
+            dom, dom_ms, dom_cells = "k_fwd_" + fam + sfx, ms_f, st0.cells_forward
+            dom_parts = [dom]
+            if sfx:   # the HDP forward stage is two kernels: the emission plane (k_emit_hdp), then the sweep that reads it
+                dom_parts = ["k_emit_hdp", dom]
+                dom = "k_emit_hdp + " + dom
         achieved = ALGO_BYTES_PER_CELL * dom_cells / (dom_ms * 1e-3) / 1e9
         # HBM bytes per step of the dominant kernel from the rocprofv3 --pmc passes (profiles/traffic.json, written by
         # probes/profile_r02.sh + probes/traffic_from_pmc.py: FETCH_SIZE and WRITE_SIZE in separate passes, fetch doubled as
@@ -596,12 +602,13 @@ def measure(args, ctx, compact=False):
         traffic = None
         profiles_meta = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        default_size = (args.reads == {"scaling": 12500}.get(args.workload, 2000) and   # (the counter passes ran at 2000 reads)
+        default_size = (args.reads == {"scaling": 12500, "hdp": 5000}.get(args.workload, 2000) and   # (sizes of the counter passes)
                         args.events == (10000 if args.workload == "scaling" else 5000))
         if os.path.exists(tp) and default_size:
             try:
                 tj = json.load(open(tp))
-                traffic = tj.get(args.workload, {}).get(dom, {}).get("bytes_per_step")
+                tparts = [tj.get(args.workload, {}).get(q, {}).get("bytes_per_step") for q in dom_parts]
+                traffic = sum(tparts) if all(tparts) else None
                 profiles_meta = tj.get("_meta", {}).get(args.workload)   # commit and date of the counter passes (not this run)
             except Exception:
                 traffic = None
@@ -612,7 +619,12 @@ def measure(args, ctx, compact=False):
         ip = os.path.join(ROOT, "profiles", "instr_mix.json")
         if os.path.exists(ip) and default_size:
             try:
-                rec = json.load(open(ip)).get(args.workload, {}).get(dom)
+                recs = [json.load(open(ip)).get(args.workload, {}).get(q) for q in dom_parts]
+                rec = None
+                if all(recs):
+                    rec = dict(recs[-1])
+                    for kk in ("valu_per_step", "instructions_per_step"):
+                        rec[kk] = sum(r_.get(kk) or 0.0 for r_ in recs)
             except Exception:
                 rec = None
             if rec and rec.get("valu_per_step"):
