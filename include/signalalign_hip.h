@@ -277,6 +277,11 @@ void sa_event_align_release(void);
  * Uses <path>.fai when it exists, otherwise scans the file (nothing is written).  *out is freed with sa_free.
  * SA_EIO: file unreadable; SA_EINVAL: no such record. */
 int sa_fasta_subsequence(const char *fasta_path, const char *name, int64_t start, int64_t end, int strand, char **out);
+/* printf("%f") of v, character for character (the exact binary value rounded to six decimals, ties to even -- glibc's result),
+ * without the stdio formatter: what the TSV writers (impl/signalMachine.c:89-270: nine "%f" per aligned pair) spend their time
+ * in.  `out` needs 32 bytes for |v| < 9e15 (larger values, inf and nan go through snprintf: up to 320); a terminator is
+ * written; returns the length. */
+int sa_format_f6(char *out, double v);
 
 /* Batches take their device and pinned-host storage from a caching allocator: what a destroyed batch held is kept and
  * handed to the next one (a pipeline that sees every read once creates and destroys a batch per few thousand reads;

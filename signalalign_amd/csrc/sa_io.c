@@ -8,7 +8,9 @@
 #define _GNU_SOURCE
 #include "sa_io.h"
 
+#include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <sys/types.h>
 #include <string.h>
@@ -29,6 +31,42 @@ char *sa_read_line(FILE *f) {
 /* Decimal text to double, exactly as strtod rounds it, for the numbers the formats hold: up to 15 significant digits and a
  * decimal exponent within +-22 convert with ONE correctly rounded multiplication or division (both operands are exact
  * doubles: Clinger's fast path); anything else -- more digits, hex, inf/nan, huge exponents -- goes to strtod. */
+/* printf("%f") of a double, digit for digit (glibc: the exact binary value rounded to six decimals, ties to even), without
+ * going through the stdio formatter: the row writers of signalMachine print nine of these per aligned pair, and the formatter
+ * was most of their time.  |v| < 2^53: the integer part and the fraction are exact doubles; the fraction is m * 2^-sh with a
+ * 53-bit m, so m * 10^6 fits 128 bits and the shift's remainder decides the rounding exactly.  Anything else (inf, nan, huge
+ * values) goes to snprintf.  Returns the number of characters written (no terminator needed by the callers, one is written). */
+int sa_format_f6(char *out, double v) {
+    if (!(fabs(v) < 9.0e15)) return sprintf(out, "%f", v);
+    char *p = out;
+    if (signbit(v)) { *p++ = '-'; v = -v; }
+    uint64_t ip = (uint64_t) v;
+    const double fr = v - (double) ip;
+    uint64_t q = 0;
+    if (fr > 0.0) {
+        int ex;
+        const double mant = frexp(fr, &ex);                 /* fr = mant * 2^ex, mant in [0.5, 1), ex <= 0 */
+        const uint64_t m = (uint64_t) ldexp(mant, 53);
+        const int sh = 53 - ex;                             /* fr = m * 2^-sh, sh >= 53 */
+        if (sh < 127) {
+            const unsigned __int128 num = (unsigned __int128) m * 1000000u, one = (unsigned __int128) 1 << sh;
+            const unsigned __int128 rem = num & (one - 1), half = one >> 1;
+            q = (uint64_t) (num >> sh);
+            if (rem > half || (rem == half && (q & 1))) q++;
+        }                                                   /* (else: below 2^-73, rounds to 0) */
+        if (q == 1000000) { q = 0; ip++; }
+    }
+    char t[24];
+    int n = 0;
+    do { t[n++] = (char) ('0' + ip % 10); ip /= 10; } while (ip);
+    while (n) *p++ = t[--n];
+    *p++ = '.';
+    for (int i = 5; i >= 0; i--) { p[i] = (char) ('0' + q % 10); q /= 10; }
+    p += 6;
+    *p = 0;
+    return (int) (p - out);
+}
+
 static double sa_atod(const char *p) {
     static const double p10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16,
                                    1e17, 1e18, 1e19, 1e20, 1e21, 1e22};

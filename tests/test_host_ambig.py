@@ -82,3 +82,32 @@ def test_result_pairs_survive_the_16_byte_record():
     b = np.zeros(n, dtype=_capi.PAIR_DTYPE)
     rc = _capi.lib().sa_pair_roundtrip(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), C.c_int64(n))
     assert rc == 0 and a.tobytes() == b.tobytes()
+
+
+def test_format_f6_prints_what_printf_prints():
+    """sa_format_f6 (the TSV writers' "%f", signalalign_amd/csrc/sa_io.c) against the C library's formatter -- Python's % uses the
+    same exact-decimal, ties-to-even conversion -- on magnitudes the writers see, on exact ties (binary fractions that end at the
+    seventh decimal), on values that carry into the integer part, on signed zeros, denormals, huge values, inf and nan."""
+    import ctypes as C
+    import numpy as np
+    L = sa.lib()
+    L.sa_format_f6.argtypes = [C.c_char_p, C.c_double]
+    L.sa_format_f6.restype = C.c_int
+    buf = C.create_string_buffer(400)
+
+    def f6(v):
+        n = L.sa_format_f6(buf, v)
+        assert buf.raw[n] == 0
+        return buf.raw[:n].decode()
+
+    rng = np.random.default_rng(5)
+    vals = list(rng.uniform(-200, 200, 50000)) + list(rng.uniform(0, 1, 50000)) + list(rng.uniform(0, 1e-5, 20000))
+    vals += list(10.0 ** rng.uniform(-12, 15, 50000)) + list(-(10.0 ** rng.uniform(-12, 15, 5000)))
+    for j in range(1, 30):
+        for k_ in range(64):
+            vals += [k_ / 2.0 ** j, k_ / 2.0 ** j + 5e-7, -(k_ / 2.0 ** j)]
+    vals += [0.0, -0.0, 0.5e-6, 1.5e-6, 2.5e-6, 0.9999995, 0.99999949999, 1e-300, -1e-300, 5e-324, 123456789.1234565, 9.0e15 - 1,
+             2.0 ** 52 + 0.5, 0.1, 0.125, 0.0000005, 0.0000015, float("inf"), float("-inf"), 1e300, -1e22, 9.1e15, 999999.9999995]
+    for v in vals:
+        assert f6(float(v)) == "%f" % float(v), repr(v)
+    assert f6(float("nan")) in ("nan", "-nan")
