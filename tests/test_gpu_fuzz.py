@@ -68,6 +68,17 @@ def test_random_shapes(oracle, model_path, ambiguous, seed):
                     cases.compare_pairs(got, exp[j], 100, p.threshold)
                     assert cases.same_order(got, exp[j])
             b.close()
+        # the same reads left in a page-locked block of the caller (SA_FLAG_INPUTS_IN_HOST_BLOCK): checked and packed on the
+        # device, or -- split regions, odd anchors -- handed back to the host planner: the same bytes as the plain batch
+        ref_b = sa.Batch(pm, p, jobs, ambig=amb_p)
+        ref_b.run()
+        ja = sa.JobArray(jobs, host_block=True, interleaved=bool(seed & 1))
+        blk = sa.Batch(pm, p, ja, ambig=amb_p, flags=sa.FLAG_INPUTS_IN_HOST_BLOCK)
+        blk.run()
+        for j in range(len(jobs)):
+            assert np.array_equal(blk.pairs(j), ref_b.pairs(j)), (j, expansion, split)
+        blk.close()
+        ref_b.close()
     # thinned and absent anchors leave wide one-path bands: those regions run on the strip kernels (sa_strip.inc), small
     # split rectangles and ragged ends included
     assert ambiguous or strips_seen > 0
