@@ -33,7 +33,7 @@ PY
 M=$GRAFT_REPO_ROOT/tests/golden/models/$MODEL
 BIN=$GRAFT_REPO_ROOT/signalalign_amd/bin/signalMachine
 T0=$(date +%s.%N)
-SA_CLI_TIMING=1 $BIN --batch $W/manifest.tsv -T $M -f $W/ref.fa -g 100 > $W/stdout.txt 2> $W/stderr.txt
+SA_CLI_TIMING=1 $BIN --batch $W/manifest.tsv -T $M -f $W/ref.fa -g 100 $SA_CLI_EXTRA > $W/stdout.txt 2> $W/stderr.txt
 T1=$(date +%s.%N)
 tail -2 $W/stderr.txt
 BYTES=$(cat $W/out*.tsv | wc -c)
