@@ -53,8 +53,10 @@ extern "C" {
                                      anchors, narrows them and gathers the event means out of their records -- what
                                      sa_batch_create otherwise does with host cores (416 MB per 2000 reads of 50 000 events
                                      in the reference's four-double records: two host threads cannot keep up with the GPU).
-                                     The block must stay unchanged until sa_batch_create has returned (for
-                                     sa_batch_create_deferred: until the batch's first use has, as for `jobs`).  Pointers
+                                     A block laid out with all event records apart from all anchor arrays is sent in two
+                                     pieces, and sa_batch_create returns while the event records are still travelling (on
+                                     the batch's own stream, ahead of its kernels): the block must stay unchanged until the
+                                     batch has RUN (sa_batch_run / sa_batch_wait has returned) or has been destroyed.  Pointers
                                      outside such a block: SA_EINVAL.  Everything else is as without the flag -- a read the
                                      device checks turn down sends the batch to the host planner, which reads the same
                                      memory and names the error -- and the flag is ignored by batches the host plans
@@ -293,7 +295,8 @@ int sa_format_f6(char *out, double v);
  *       parked; blocks above a lowered bound are freed at once.  Wins over the environment.
  *   sa_pool_release()                                           returns everything that is parked right now.
  * sa_host_alloc / sa_host_free: page-locked host memory for a caller's own input arrays (SA_FLAG_INPUTS_IN_HOST_BLOCK); a
- * block belongs to the caller until sa_host_free, which must not be called while a batch created from it is being created.
+ * block belongs to the caller until sa_host_free, which must not be called before every batch created from it has run or has
+ * been destroyed.
  * Environment (read when no limit was configured): SA_POOL=0 disables the cache, SA_POOL_LIMIT_GB bounds both kinds. */
 int sa_pool_configure(int64_t device_limit_bytes, int64_t pinned_limit_bytes);
 void *sa_host_alloc(size_t bytes);   /* NULL: no memory (or no device) */
