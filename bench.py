@@ -462,7 +462,11 @@ def measure(args, ctx, compact=False):
     # batches in flight: as many as asked for, as long as their forward storage (24 B per band cell, the bulk of a batch)
     # fits HBM together with room to spare -- a 10k-event slice or 10k reads with several paths per cell take half of
     # the card alone and go one at a time
-    hbm_bytes = float(sa.device_memory(device)[1])
+    # (a rank's share of the card: the whole of it on a real node; in a rehearsal with several ranks on one GPU -- gloo backend,
+    # device = local_rank % device_count -- the ranks must not each size a pipeline for all of it)
+    hbm_bytes = float(sa.device_memory(device)[1]) / max(1, ctx.get("ranks_per_device", 1))
+    if ctx.get("ranks_per_device", 1) > 1:
+        sa.pool_configure(device_limit_bytes=int(0.5 * hbm_bytes))   # what may stay parked between batches: this rank's share too
     depth = max(1, min(args.in_flight, int(0.6 * hbm_bytes / max(1.25 * st0.f_bytes, 1.0)),
                        int(0.8 * hbm_bytes / max(st0.device_bytes, 1.0))))   # (all working storage: candidate slots weigh as much as the planes with HDP models)
     if args.workload == "scaling":
@@ -766,6 +770,8 @@ def main():
         import torch
         import torch.distributed as dist
         device = local_rank % max(torch.cuda.device_count(), 1)  # identity on a full node
+        n_dev = max(torch.cuda.device_count(), 1)
+        ranks_per_device = (int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) + n_dev - 1) // n_dev
         torch.cuda.set_device(device)
         dist.init_process_group(backend=backend)  # RCCL; only used for the barrier and the max-over-ranks
     if world > 1:
@@ -792,7 +798,7 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return res
-    ctx = dict(dist=dist, rank=rank, world=world, device=device, backend=backend)
+    ctx = dict(dist=dist, rank=rank, world=world, device=device, backend=backend, ranks_per_device=ranks_per_device if world > 1 else 1)
     out = measure(args, ctx)
     if out is not None and world == 1 and args.workload == "gaussian" and not args.kernels_only and not args.no_secondary:
         # the other hot-path workloads, compactly, on the same line (a few seconds each): anchors as sparse as a real guide
