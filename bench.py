@@ -24,6 +24,7 @@ import os
 import sys
 import time
 
+T_START = time.perf_counter()
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -69,11 +70,12 @@ def host_cpu_info():
                 cgroup_cpu_quota=quota)
 
 
-def cpu_baseline(alpha, k, t10, tab, n_events, reads_per_thread, first_index):
+def cpu_baseline(om, oparams, make_sample, n_events, reads_per_thread, first_index, ambig=None, what=""):
     """The CPU restatement (oracle, 'port') on a bounded sample of the same workload, one read per thread, threads pinned
-    to the physical cores of ONE socket (north_star: single-socket baseline); a one-thread figure beside it."""
+    to the physical cores of ONE socket (north_star: single-socket baseline); a one-thread figure beside it.
+    om / oparams / ambig: the oracle's model (HDP loaded where the workload has one), parameters and ambiguity table;
+    make_sample(n, first_index): n reads of the workload."""
     from oracle import sa_oracle_py as oracle
-    from signalalign_amd import synth
     info = host_cpu_info()
     pin = [c for c in info["socket0_cpus"] if c in set(info["allowed"])] or info["allowed"]
     cores = len(pin)
@@ -87,17 +89,15 @@ def cpu_baseline(alpha, k, t10, tab, n_events, reads_per_thread, first_index):
         os.sched_setaffinity(0, pin)
     except Exception:
         old = None
-    om = oracle.Model(alpha, k, t10, tab)
-    p = oracle.default_params()
     try:
-        one = synth.make_jobs(max(8, reads_per_thread), n_events, alpha, k, tab, first_index=first_index)
+        one = make_sample(max(4, min(8, reads_per_thread)), first_index)
         t0 = time.perf_counter()
-        _, c1 = oracle.align_batch_mt(om, one, p, 1)
+        _, c1 = oracle.align_batch_mt(om, one, oparams, 1, ambig=ambig)
         dt1 = time.perf_counter() - t0
         n = cores * reads_per_thread
-        jobs = synth.make_jobs(n, n_events, alpha, k, tab, first_index=first_index + 1000)
+        jobs = make_sample(n, first_index + 1000)
         t0 = time.perf_counter()
-        npairs, cells = oracle.align_batch_mt(om, jobs, p, cores)
+        npairs, cells = oracle.align_batch_mt(om, jobs, oparams, cores, ambig=ambig)
         dt = time.perf_counter() - t0
     finally:
         if old is not None:
@@ -106,9 +106,9 @@ def cpu_baseline(alpha, k, t10, tab, n_events, reads_per_thread, first_index):
             except Exception:
                 pass
     return dict(value=float(cells.sum() / dt), unit="cell_updates/s", cores=cores, kind="port",
-                sample="%d reads x %d events (same generator and parameters as the GPU workload), oracle/sa_oracle.c, "
+                sample="%d reads x %d events%s (same generator and parameters as the GPU workload), oracle/sa_oracle.c, "
                        "%d threads pinned to physical cores of socket 0, %.1f s wall; 1 thread: %d reads, %.1f s"
-                       % (n, n_events, cores, dt, len(one), dt1),
+                       % (n, n_events, what, cores, dt, len(one), dt1),
                 events_per_s=float(sum(len(j["events"]) for j in jobs) / dt),
                 one_thread_value=float(c1.sum() / dt1),
                 # the GPU box grants this job a CPU quota below one socket: the full-socket figure is bounded from above by
@@ -242,7 +242,7 @@ def bench_mea(args):
     print(json.dumps(res))
 
 
-def bench_expectations(args):
+def bench_expectations(args, compact=False):
     """The expectation pass (getExpectationsUsingAnchors, impl/pairwiseAligner.c:2164-2184: the inner loop of trainModels.py's
     EM): one step = one sa_expect_batch call over the headline workload's reads -- planning, upload, forward sweep storing all
     three states, backward sweep with the transition expectations fused in (k_bwd_fast_expect), fold, host rescale.  Cells are
@@ -264,10 +264,12 @@ def bench_expectations(args):
     for _ in range(args.steps):
         trans, lik, _ = sa.expect_batch(pm, params, jobs)
     dt = (time.perf_counter() - t0) / args.steps
-    tg0 = time.perf_counter()
-    for _ in range(max(1, args.steps // 4)):
-        sa.expect_batch(pm, params, jobs, flags=sa.FLAG_FORCE_GENERIC)
-    dtg = (time.perf_counter() - tg0) / max(1, args.steps // 4)
+    dtg = float("nan")
+    if not compact:   # (the memory-resident checker kernels beside it)
+        tg0 = time.perf_counter()
+        for _ in range(max(1, args.steps // 4)):
+            sa.expect_batch(pm, params, jobs, flags=sa.FLAG_FORCE_GENERIC)
+        dtg = (time.perf_counter() - tg0) / max(1, args.steps // 4)
     res = {"metric": "dp_cell_updates_per_s", "value": cells / dt, "unit": "cell_updates/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
@@ -275,7 +277,8 @@ def bench_expectations(args):
                                   "band=50" % (args.reads, args.events),
                       "step": "one sa_expect_batch call: create (host planner) + forward (all three states stored) + backward with "
                               "fused transition expectations + fold + host rescale + destroy",
-                      "memory_resident_kernels_ms_per_step": dtg * 1e3, "memory_resident_kernels_value": cells / dtg,
+                      "memory_resident_kernels_ms_per_step": None if compact else dtg * 1e3,
+                      "memory_resident_kernels_value": None if compact else cells / dtg,
                       "mean_match_to_match_expectation": float(trans[:, 0].mean()), "mean_log_likelihood": float(lik.mean())},
            # 48 B per cell update: the forward sweep writes and the backward sweep reads all three states of every cell
            "roofline": {"bound": "issue", "bound_of_the_formula": "hbm", "kernel": "k_bwd_fast_expect", "achieved": None,
@@ -300,7 +303,23 @@ def bench_expectations(args):
         res["cpu_baseline"] = {"value": cells / len(job_list) * len(sample) / dtc, "unit": "cell_updates/s", "cores": cores,
                                "kind": "port", "sample": "%d reads, oracle/sa_oracle.c:sao_expectations, %d threads, %.1f s wall"
                                                          % (len(sample), cores, dtc)}
-    print(json.dumps(res))
+    # roofline of the dominant kernel from the per-kernel record of the last profiling session (profiles/kernel_times.json:
+    # average duration of k_bwd_fast_expect over `bench.py --workload expectations` under rocprofv3 --kernel-trace --stats;
+    # sa_expect_batch keeps no stage events of its own)
+    try:
+        kt = json.load(open(os.path.join(ROOT, "profiles", "kernel_times.json"))).get("expectations", {})
+        kms = kt.get("k_bwd_fast_expect", {}).get("ms_per_step")
+        if kms and args.reads == 2000 and args.events == 5000:
+            # 48 B per backward cell update: the backward sweep reads all three forward states of every cell
+            ach = 48.0 * st.cells_backward / (kms * 1e-3) / 1e9
+            res["roofline"].update({"achieved": ach, "frac": ach / HBM_PEAK_GBS, "stage_ms": kms,
+                                    "algorithmic_bytes_per_step": 48.0 * st.cells_backward,
+                                    "source": "profiles/kernel_times.json (rocprofv3 --kernel-trace --stats), " + str(kt.get("_meta"))})
+    except Exception:
+        pass
+    if not compact:
+        print(json.dumps(res))
+    return res
 
 
 def self_launch(n):
@@ -351,7 +370,16 @@ def measure(args, ctx, compact=False):
                     ref_pool=os.path.join(ROOT, "tests", "golden", "npReads", "ZymoRef.txt"))
     # spawned numpy-only workers; identical to the serial loop (several ranks on one host share its CPUs: fewer workers each)
     gen_workers = None if world == 1 else max(1, min(4, int(os.environ.get("SA_HOST_THREADS", "2"))))
-    make_many = lambda idx: synth.make_reads_parallel(spec, idx, workers=gen_workers)
+    def make_many(idx):
+        idx = [int(i) for i in idx]
+        key = (args.workload, args.events, tuple(idx[:2]), idx[-1] if idx else -1, len(idx))
+        memo = ctx.setdefault("reads_memo", {})
+        if memo.get("workload") != args.workload:    # (one workload's sets at a time: a 10k-event slice is 4 GB)
+            memo.clear()
+            memo["workload"] = args.workload
+        if key not in memo:
+            memo[key] = synth.make_reads_parallel(spec, idx, workers=gen_workers)
+        return [dict(j_) for j_ in memo[key]]        # (callers thin anchors / narrow events in their copies)
     # reads are independent: the global read list is dealt to the ranks (no collective on the data path)
     from signalalign_amd import shard
     mine = shard.shard_indices([args.events] * (world * args.reads), rank, world)
@@ -380,7 +408,11 @@ def measure(args, ctx, compact=False):
         wl_name = ("BASELINE configs[1] reads with the anchor density of a real guide alignment "
                    "(tests/golden/cigars/ecoli_minus_strand.cigar, -m 14: a sixth of the bases)")
     # ---- read sets: every timed step aligns reads the library has not seen in the step before ----
-    n_sets = 1 if args.kernels_only else (2 if args.workload == "scaling" or args.reads > 4000 or compact else 3)
+    # (a compact secondary leg of BASELINE size -- 10 000 reads with several paths per cell, 5000 HDP reads, 12 500 10k-event
+    # reads -- cycles ONE read set: generating a second one costs more than the leg's steps, and the library keeps nothing of a
+    # batch's inputs between batches: every step checks, packs, uploads and plans them again)
+    big_compact = compact and args.reads * args.events >= 2.5e7
+    n_sets = 1 if args.kernels_only or big_compact else (2 if args.workload == "scaling" or args.reads > 4000 or compact else 3)
     sets = [jobs]
     for q in range(1, n_sets):
         more = shard.shard_indices([args.events] * (world * args.reads), rank, world)
@@ -391,7 +423,8 @@ def measure(args, ctx, compact=False):
     if args.event_stride == 1:
         for js in sets:
             for j_ in js:
-                j_["events"] = np.ascontiguousarray(np.asarray(j_["events"])[:, 0])
+                if np.asarray(j_["events"]).ndim == 2:
+                    j_["events"] = np.ascontiguousarray(np.asarray(j_["events"])[:, 0])
     # marshalled once: a C caller holds sa_job_t arrays anyway.  --inputs host-block: the event records and anchors live in one
     # page-locked block per read set (sa_host_alloc), as a caller that reads its inputs into such a block has them
     # auto: host-block when this rank has few host threads to pack pageable inputs with (ranks of an 8-GPU run under a 16-CPU
@@ -438,7 +471,45 @@ def measure(args, ctx, compact=False):
         ms_fold += s_.ms_fold
     dt_resident = (time.perf_counter() - t0) / KR
     ms_f, ms_b, ms_fold = ms_f / KR, ms_b / KR, ms_fold / KR
-    n_pairs = sum(batch.n_pairs(j) for j in range(len(jobs)))
+    n_pairs = int(batch.results_view()[1][-1])
+    # The roofline's kernel times: the same resident batch planned with ONE backward launch per forward-storage pass
+    # (SA_GROUPS=1), so that a stage is one launch of the dominant kernel alone on its stream, timed by the library's HIP
+    # events on that stream -- and `rocprofv3 --kernel-trace --stats` over `bench.py --workload W --kernels-only` under
+    # SA_GROUPS=1 (profiles/r04_W_kernel_stats.csv) shows the same average duration.  (The eight result groups of the phase
+    # above overlap pairwise on two streams; their stage time also holds fold / finalisation kernels of earlier groups.)
+    single = None
+    if int(st0.n_groups) > int(st0.n_chunks) and not os.environ.get("SA_GROUPS"):
+        os.environ["SA_GROUPS"] = "1"
+        try:
+            b1 = sa.Batch(pm, params, arrays[0], ambig=ambig, device=device, flags=xflags)
+        finally:
+            del os.environ["SA_GROUPS"]
+        s1 = b1.stats()
+        b1.run()
+        K1 = 3 if compact else 5
+        f1 = bk1 = 0.0
+        for _ in range(K1):
+            b1.run()
+            s_ = b1.stats()
+            f1 += s_.ms_forward
+            bk1 += s_.ms_backward
+        single = {"ms_forward": f1 / K1, "ms_backward": bk1 / K1, "launches_per_pass": int(s1.n_groups) // max(int(s1.n_chunks), 1),
+                  "passes": int(s1.n_chunks)}
+        b1.close()
+    elif int(st0.n_groups) == int(st0.n_chunks):
+        single = {"ms_forward": ms_f, "ms_backward": ms_b, "launches_per_pass": 1, "passes": int(st0.n_chunks)}
+    # what a caller pays who wants sa_pair_t rows instead of the packed records the step ends at: sa_batch_pairs_all (host threads)
+    unpack_ms = None
+    if not compact and 0 < n_pairs < 5e7:
+        from signalalign_amd._capi import PAIR_DTYPE
+        rows_buf = np.empty(n_pairs, dtype=PAIR_DTYPE)
+        t_u = []
+        for _ in range(4):
+            tu0 = time.perf_counter()
+            batch.pairs_all(rows_buf)
+            t_u.append((time.perf_counter() - tu0) * 1e3)
+        unpack_ms = {"first_call_with_page_faults": t_u[0], "steady": min(t_u[1:])}
+        del rows_buf
     batch.close()
     # serial cycles (median of five, outside the timed region): what a caller without overlap pays per batch in steady state
     cycle = {"create": 0.0, "run": dt_resident * 1e3, "destroy": 0.0}
@@ -477,6 +548,8 @@ def measure(args, ctx, compact=False):
     depth = max(1, min(depth, int(6e9 / max(24.0 * n_pairs, 1.0))))
     cells_done = [0.0]
     groups_seen = [0]
+    pairs_seen = [0]
+    first_buf = np.zeros(len(jobs) + 1, dtype=np.int64)
 
     def stream(n_steps, first):
         flying = []
@@ -500,7 +573,7 @@ def measure(args, ctx, compact=False):
                 stc = cur.stats()
                 cells_done[0] += stc.cells_forward + stc.cells_backward
                 groups_seen[0] = int(stc.n_groups)
-                cur.n_pairs(0)
+                pairs_seen[0] += int(cur.results_view(first_buf)[1][-1])
                 cur.close()
                 if dbg:
                     print("[bench] step %d: next batch's first half %.1f ms, then waited %.1f ms, collect %.1f ms; device %.1f ms"
@@ -516,7 +589,9 @@ def measure(args, ctx, compact=False):
                 stc = old.stats()
                 cells_done[0] += stc.cells_forward + stc.cells_backward
                 groups_seen[0] = int(stc.n_groups)
-            old.n_pairs(0)
+            # the step ends where the results are the caller's: every job's packed 16-byte records, in place in the batch's
+            # pinned block (sa_batch_pairs16_all: one call, nothing copied)
+            pairs_seen[0] += int(old.results_view(first_buf)[1][-1])
             old.close()
 
         for s in range(n_steps):
@@ -553,11 +628,13 @@ def measure(args, ctx, compact=False):
         stream(args.warmup, priming)
         sync()
         cells_done[0] = 0.0
+        pairs_seen[0] = 0
         t0 = time.perf_counter()
         stream(args.steps, priming + args.warmup)
         sync()
         dt = time.perf_counter() - t0
     cells_streamed = cells_done[0]
+    pairs_timed = pairs_seen[0]   # (of the K timed steps; the long run below counts on)
     long_run = None
     if (not compact and not args.kernels_only and world == 1 and args.workload == "gaussian" and not args.no_secondary
             and args.long_steps > args.steps):
@@ -590,11 +667,12 @@ def measure(args, ctx, compact=False):
         if fam == "ring" and 2 * st0.n_strip_regions > st0.n_ring_regions:
             fam = "strip"
         sfx = "_hdp" if (args.workload == "hdp" and fam == "fast") else ""
+        rf_f, rf_b = (single["ms_forward"], single["ms_backward"]) if single else (ms_f, ms_b)
         if ms_b >= ms_f:
-            dom, dom_ms, dom_cells = "k_bwd_" + fam + sfx, ms_b, st0.cells_backward
+            dom, dom_ms, dom_cells = "k_bwd_" + fam + sfx, rf_b, st0.cells_backward
             dom_parts = [dom]
         else:
-            dom, dom_ms, dom_cells = "k_fwd_" + fam + sfx, ms_f, st0.cells_forward
+            dom, dom_ms, dom_cells = "k_fwd_" + fam + sfx, rf_f, st0.cells_forward
             dom_parts = [dom]
             if sfx:   # the HDP forward stage is two kernels: the emission plane (k_emit_hdp), then the sweep that reads it
                 dom_parts = ["k_emit_hdp", dom]
@@ -606,7 +684,7 @@ def measure(args, ctx, compact=False):
         traffic = None
         profiles_meta = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        default_size = (args.reads == {"scaling": 12500, "hdp": 5000}.get(args.workload, 2000) and   # (sizes of the counter passes)
+        default_size = (args.reads == {"scaling": 12500, "hdp": 5000, "cpg": 10000}.get(args.workload, 2000) and   # (sizes of the counter passes)
                         args.events == (10000 if args.workload == "scaling" else 5000))
         if os.path.exists(tp) and default_size:
             try:
@@ -671,7 +749,13 @@ def measure(args, ctx, compact=False):
                         "results on the host + sa_batch_destroy; %s" % ("%d batches in flight (sa_batch_start / sa_batch_wait)" % depth
                                                                         if depth > 1 else "one batch on the device at a time, the next one checked, "
                                                                         "packed, uploaded and planned meanwhile (sa_batch_create_deferred)"),
-                "read_sets_cycled": n_sets, "long_run": long_run,
+                "results": {"step_ends_at": "every job's pairs as packed 16-byte records (sa_pair16_t, include/signalalign_hip.h) in "
+                                            "the batch's pinned host block, read in place through sa_batch_pairs16_all",
+                            "pairs_seen_in_timed_steps": pairs_timed,
+                            "expand_to_sa_pair_t_ms": unpack_ms,
+                            "note": "sa_batch_pairs_all (24-byte sa_pair_t rows, host threads) is NOT inside the timed step; "
+                                    "its cost per batch is expand_to_sa_pair_t_ms"},
+                "read_sets_cycled": n_sets, "batches_in_flight": depth, "long_run": long_run,
                 "allocator_priming_batches_before_warmup": (depth + 2 if depth > 1 else 0) if not args.kernels_only else 0,
                 "first_batch_create_s": t_create,
                 "serial_cycle_ms": cycle,
@@ -696,13 +780,37 @@ def measure(args, ctx, compact=False):
                          "kernel_passes_phase1": (max(1, min(args.warmup, 3)) + KR),
                          "algorithmic_bytes_per_step": ALGO_BYTES_PER_CELL * dom_cells,
                          "stage_ms": dom_ms,
-                         "launches_per_step": int(st0.n_groups) if dom.startswith("k_bwd") else int(st0.n_chunks)},
+                         "stage_ms_is": ("the dominant kernel's launches of one step, each alone on its stream (resident batch planned "
+                                         "with SA_GROUPS=1), HIP events on that stream: launches_per_step launches, one per "
+                                         "forward-storage pass" if single else "stage wall of the grouped launches"),
+                         "stage_ms_of_the_grouped_launches": ms_b if dom.startswith("k_bwd") else ms_f,
+                         "launches_per_step": (single["passes"] * single["launches_per_pass"] if single else
+                                               (int(st0.n_groups) if dom.startswith("k_bwd") else int(st0.n_chunks))),
+                         "avg_launch_ms": dom_ms / max(1, (single["passes"] * single["launches_per_pass"]) if single else
+                                                       (int(st0.n_groups) if dom.startswith("k_bwd") else int(st0.n_chunks)))},
         }
         if issue:
             out["issue_roofline"] = issue
-        if not args.no_cpu_baseline and world == 1 and args.workload in ("gaussian", "scaling"):   # (rank 0 at N = 1 only)
-            out["cpu_baseline"] = cpu_baseline(alpha, k, t10, tab, args.events, args.cpu_reads_per_thread,
-                                               first_index=10 ** 6)
+        if not args.no_cpu_baseline and world == 1:   # (rank 0 at N = 1 only)
+            # the CPU restatement on a bounded sample of THIS workload: same generator, model (HDP loaded where the workload has
+            # one), ambiguity table, threshold and anchors
+            from oracle import sa_oracle_py as oracle          # timed here as the baseline, nothing else
+            om = oracle.Model(alpha, k, t10, tab)
+            if nhdp:
+                om.load_hdp(nhdp)
+                om.set_to_hdp_expected_values()
+            op_ = oracle.default_params(threshold=args.threshold, expansion=50, trace_back=100)
+
+            def make_sample(n_, first_):
+                idx_ = list(range(first_, first_ + n_))
+                js_ = synth.make_reads_parallel(spec, idx_, workers=1)
+                if args.workload == "realistic":
+                    thin_like_a_guide_alignment(js_, idx_)
+                return js_
+            out["cpu_baseline"] = cpu_baseline(om, op_, make_sample, args.events, args.cpu_reads_per_thread, 10 ** 6,
+                                               ambig=oracle.ambig_map({"X": "CE"}) if args.workload == "cpg" else None,
+                                               what={"cpg": ", every CpG cytosine C/E", "hdp": ", HDP emissions",
+                                                     "realistic": ", anchors of a guide alignment"}.get(args.workload, ""))
         return out
     return None
 
@@ -748,6 +856,10 @@ def main():
     ap.add_argument("--long-steps", type=int, default=200, help="steps of the long steady-state sample reported beside the "
                                                                 "K timed steps (config.long_run)")
     ap.add_argument("--cpu-reads-per-thread", type=int, default=30)
+    ap.add_argument("--secondary-cpu-reads", type=int, default=6, help="reads per thread of the CPU baselines of the secondary legs")
+    ap.add_argument("--secondary-budget-s", type=float, default=330.0,
+                    help="a secondary leg is not started once the run has taken this long (the default line must stay well inside "
+                         "the driver's time limit)")
     args = ap.parse_args()
     if args.reads is None:
         # the sizes BASELINE.json names: configs[2] (cpg) 10 000 reads, configs[3] (hdp) 5000, configs[4]'s slice 12 500
@@ -798,29 +910,82 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return res
-    ctx = dict(dist=dist, rank=rank, world=world, device=device, backend=backend, ranks_per_device=ranks_per_device if world > 1 else 1)
+    ctx = dict(dist=dist, rank=rank, world=world, device=device, backend=backend, ranks_per_device=ranks_per_device if world > 1 else 1,
+               t_start=T_START)
     out = measure(args, ctx)
     if out is not None and world == 1 and args.workload == "gaussian" and not args.kernels_only and not args.no_secondary:
-        # the other hot-path workloads, compactly, on the same line (a few seconds each): anchors as sparse as a real guide
-        # alignment leaves them (strip kernels) and configs[2] (several paths per cell, ring kernels)
+        # Every other BASELINE config and the two workloads beside them, compactly, on the same line: configs[2] (cpg) at its
+        # 10 000 reads, configs[3] (hdp) at its 5000 reads and the reference's threshold 0.1 with the 0.01 figure beside it, one
+        # GPU's slice of configs[4] (scaling), reads with the anchors of a real guide alignment (realistic) and the expectation
+        # pass -- each with its own roofline fractions and its own CPU baseline (the restatement on a bounded sample of THAT
+        # workload).  A leg that would start after --secondary-budget-s seconds of wall time is skipped and says so.
         import copy
-        out["config"]["secondary"] = {}
-        for wl in ("realistic", "cpg"):
+        import signalalign_amd as sa
+        sec = out["config"]["secondary"] = {}
+        t_start = ctx["t_start"]
+
+        def leg(name, wl, reads, events, threshold, steps, warmup, cpu=True):
+            if time.perf_counter() - t_start > args.secondary_budget_s:
+                sec[name] = {"skipped": "wall-time budget of the default run (%d s) reached" % args.secondary_budget_s}
+                return None
+            t_leg = time.perf_counter()
             a2 = copy.copy(args)
-            a2.workload, a2.reads, a2.events, a2.threshold = wl, 2000, 5000, 0.01
+            a2.workload, a2.reads, a2.events, a2.threshold = wl, reads, events, threshold
             # (warm-up: the batches in flight plus two must have been through the caching allocators, which start empty -- the
             # blocks the previous workload left parked have other sizes)
-            a2.steps, a2.warmup, a2.no_cpu_baseline = max(4, min(args.steps, 10)), max(5, args.in_flight + 3), True
-            import signalalign_amd as sa
+            a2.steps, a2.warmup, a2.no_cpu_baseline, a2.cpu_reads_per_thread = steps, warmup, not cpu, args.secondary_cpu_reads
             sa.lib().sa_pool_release()
-            r2 = measure(a2, ctx, compact=True)
-            rf = r2["roofline"]
-            out["config"]["secondary"][wl] = {
+            try:
+                r2 = measure(a2, ctx, compact=True)
+            except Exception as ex:   # (a leg must not take the headline line down with it)
+                sec[name] = {"failed": "%s: %s" % (type(ex).__name__, ex)}
+                return None
+            rf, cb = r2["roofline"], r2.get("cpu_baseline")
+            sec[name] = {
                 "workload": r2["config"]["workload"], "value": r2["value"], "ms_per_step": r2["ms_per_step"], "steps": r2["steps"],
+                "events_per_s": r2["config"]["events_per_s"],
                 "kernels_only_value": r2["config"]["kernels_only_resident_inputs"]["value"],
                 "kernel_ms": r2["config"]["kernel_ms"], "pairs_per_event": r2["config"]["pairs_per_event"],
+                "batches_in_flight": r2["config"]["batches_in_flight"], "read_sets_cycled": r2["config"]["read_sets_cycled"],
+                "forward_storage_passes": r2["config"]["forward_storage_passes"],
                 "dominant_kernel": rf["kernel"], "roofline_frac": rf["frac"], "roofline_frac_by_counters": rf["frac_by_counters"],
-                "stage_ms": rf["stage_ms"]}
+                "roofline_bound": rf["bound"], "stage_ms": rf["stage_ms"], "launches_per_step": rf["launches_per_step"],
+                "issue_frac": (r2.get("issue_roofline") or {}).get("frac"),
+                "cpu_baseline": None if cb is None else {"value": cb["value"], "cores": cb["cores"], "kind": cb["kind"],
+                                                         "one_thread_value": cb["one_thread_value"], "sample": cb["sample"]},
+                "gpu_over_cpu_baseline": None if cb is None else r2["value"] / cb["value"],
+                "leg_wall_s": time.perf_counter() - t_leg}
+            return r2
+        ks = max(4, min(args.steps, 10))
+        leg("realistic", "realistic", 2000, 5000, 0.01, ks, max(5, args.in_flight + 3))
+        leg("cpg", "cpg", 10000, 5000, 0.01, 5, 2)
+        if leg("hdp", "hdp", 5000, 5000, 0.1, ks, max(5, args.in_flight + 3)) is not None:
+            r3 = leg("hdp_threshold_0.01", "hdp", 5000, 5000, 0.01, 3, 1, cpu=False)
+            if r3 is not None:
+                sec["hdp_threshold_0.01"]["note"] = ("the bundled .nhdp is flat (every process: mean 59.8, sd 15.5 pA): 17.8 pairs "
+                                                     "per event at 0.01, the step is their PCIe transfer")
+        if time.perf_counter() - t_start <= args.secondary_budget_s:
+            t_leg = time.perf_counter()
+            a3 = copy.copy(args)
+            a3.workload, a3.reads, a3.events, a3.threshold, a3.steps, a3.warmup = "expectations", 2000, 5000, 0.01, ks, 2
+            sa.lib().sa_pool_release()
+            try:
+                r4 = bench_expectations(a3, compact=True)
+                rf4, cb4 = r4["roofline"], r4.get("cpu_baseline")
+                sec["expectations"] = {"workload": r4["config"]["workload"], "value": r4["value"], "ms_per_step": r4["ms_per_step"],
+                                       "steps": r4["steps"], "dominant_kernel": rf4["kernel"], "roofline_frac": rf4.get("frac"),
+                                       "roofline_frac_by_counters": None, "stage_ms": rf4.get("stage_ms"),
+                                       "roofline_source": rf4.get("source"),
+                                       "cpu_baseline": None if cb4 is None else {"value": cb4["value"], "cores": cb4["cores"],
+                                                                                 "kind": cb4["kind"], "sample": cb4["sample"]},
+                                       "gpu_over_cpu_baseline": None if cb4 is None else r4["value"] / cb4["value"],
+                                       "leg_wall_s": time.perf_counter() - t_leg}
+            except Exception as ex:
+                sec["expectations"] = {"failed": "%s: %s" % (type(ex).__name__, ex)}
+        else:
+            sec["expectations"] = {"skipped": "wall-time budget of the default run (%d s) reached" % args.secondary_budget_s}
+        leg("scaling_slice", "scaling", 12500, 10000, 0.01, 3, 1)
+        out["config"]["wall_s_whole_run"] = time.perf_counter() - t_start
     if out is not None:
         print(json.dumps(out))
     if dist is not None:

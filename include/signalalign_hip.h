@@ -60,7 +60,13 @@ extern "C" {
                                      outside such a block: SA_EINVAL.  Everything else is as without the flag -- a read the
                                      device checks turn down sends the batch to the host planner, which reads the same
                                      memory and names the error -- and the flag is ignored by batches the host plans
-                                     (SA_FLAG_EXACT, ...) and by sa_expect_batch's SA_EMISSION_TWO_DIST models */
+                                     (SA_FLAG_EXACT, ...) and by sa_expect_batch's SA_EMISSION_TWO_DIST models.
+                                     Layout: what crosses PCIe (and is held in HBM until the batch goes, counted in
+                                     sa_batch_stats_t.device_bytes) is the COVERING RANGE of the batch's arrays -- of its event
+                                     records and of its anchor arrays when the two lie apart, of everything otherwise -- so a
+                                     batch's arrays should be contiguous in the block.  A batch whose covering ranges hold more
+                                     than twice the bytes its jobs name (one arena shared by several batches, gaps) is packed
+                                     by host threads instead, as without the flag: same results, none of the saving */
 
 typedef struct sa_model sa_model_t; /* replaces StateMachine3 / StateMachine3_HDP (inc/stateMachine.h:150-190) */
 typedef struct sa_batch sa_batch_t;
@@ -107,8 +113,42 @@ typedef struct sa_pair {
     int32_t kmer_id; /* kmer_id() of the path's k-mer                                  */
 } sa_pair_t;
 
-/* Test hook (host only): `in` through the packed 16-byte record results travel in between HBM and sa_batch_pairs (x, y < 2^28,
- * prob_e7 <= 1e7 < 2^24, path < 2^16) and back into `out`. */
+/* The same tuple as it lives in HBM and crosses PCIe: 16 bytes instead of 24 (2000 x 5000-event reads return 9 million pairs
+ * per batch; broad HDP densities at threshold 0.01 four hundred million).  This is what a finished batch HOLDS, in pinned host
+ * memory, job after job in output order: sa_batch_pairs16 hands out a job's records in place (no copy), sa_batch_pairs and
+ * sa_batch_pairs_all expand them into sa_pair_t.
+ *   a = x (28 bits) | y (28 bits) << 28 | path bits 0..7 << 56        (the planners refuse matrices of 2^28 rows or columns
+ *   b = kmer_id (32 bits) | prob_e7 (24 bits: <= 1e7) << 32 | path bits 8..15 << 56        and cells of more than 65535 paths) */
+typedef struct sa_pair16 {
+    uint64_t a, b;
+} sa_pair16_t;
+#if defined(__HIPCC__) || defined(__HIP__)
+#define SA_PAIR16_ATTR __host__ __device__
+#else
+#define SA_PAIR16_ATTR
+#endif
+#define SA_PAIR16_FN static inline
+#define SA_PAIR16_MAX_COORD (1ll << 28) /* x, y below this */
+#define SA_PAIR16_MAX_PATHS 65536       /* paths per cell at most this */
+SA_PAIR16_ATTR SA_PAIR16_FN sa_pair16_t sa_pair16_pack(int64_t prob_e7, int32_t x, int32_t y, int32_t path, int32_t kmer_id) {
+    sa_pair16_t r;
+    r.a = ((uint64_t) (uint32_t) x & 0xfffffffull) | (((uint64_t) (uint32_t) y & 0xfffffffull) << 28) |
+          ((uint64_t) ((uint32_t) path & 0xffu) << 56);
+    r.b = (uint64_t) (uint32_t) kmer_id | (((uint64_t) prob_e7 & 0xffffffull) << 32) |
+          ((uint64_t) (((uint32_t) path >> 8) & 0xffu) << 56);
+    return r;
+}
+SA_PAIR16_ATTR SA_PAIR16_FN sa_pair_t sa_pair16_unpack(sa_pair16_t r) {
+    sa_pair_t o;
+    o.x = (int32_t) (r.a & 0xfffffffull);
+    o.y = (int32_t) ((r.a >> 28) & 0xfffffffull);
+    o.path = (int32_t) (((r.a >> 56) & 0xffull) | (((r.b >> 56) & 0xffull) << 8));
+    o.kmer_id = (int32_t) (uint32_t) (r.b & 0xffffffffull);
+    o.prob_e7 = (int64_t) ((r.b >> 32) & 0xffffffull);
+    return o;
+}
+
+/* Test hook (host only): `in` through the packed 16-byte record and back into `out`. */
 int sa_pair_roundtrip(const sa_pair_t *in, sa_pair_t *out, int64_t n);
 
 typedef struct sa_batch_stats {
@@ -195,6 +235,17 @@ int sa_batch_start(sa_batch_t *b);
 int sa_batch_wait(sa_batch_t *b);
 int sa_batch_n_pairs(const sa_batch_t *b, int64_t job, int64_t *n);
 int sa_batch_pairs(const sa_batch_t *b, int64_t job, sa_pair_t *out, int64_t cap);
+/* A job's pairs as the batch holds them: *out points at *n packed records (sa_pair16_t above) inside the batch's pinned result
+ * block, valid until the batch is run again or destroyed.  Nothing is copied: this is where sa_batch_run / sa_batch_wait
+ * leaves the results, and the form a caller that formats or forwards them reads (signalMachine's TSV writers, sa_batch_mea). */
+int sa_batch_pairs16(const sa_batch_t *b, int64_t job, const sa_pair16_t **out, int64_t *n);
+/* The whole batch at once: the records of all jobs are contiguous in job order; *out is the first record of job 0 and job j's
+ * are (*out)[first[j] .. first[j + 1]) (`first`: n_jobs + 1 entries, may be NULL). */
+int sa_batch_pairs16_all(const sa_batch_t *b, const sa_pair16_t **out, int64_t *first);
+/* Every job's pairs expanded into sa_pair_t, job after job, on the library's host threads: out[first[j] .. first[j + 1]) are
+ * job j's rows (`first` has n_jobs + 1 entries; may be NULL).  cap < total number of pairs: SA_EINVAL and *first is still
+ * filled, so first[n_jobs] says how much room is needed. */
+int sa_batch_pairs_all(const sa_batch_t *b, sa_pair_t *out, int64_t cap, int64_t *first);
 int sa_batch_stats(const sa_batch_t *b, sa_batch_stats_t *out);
 int sa_batch_job_cells(const sa_batch_t *b, int64_t job, double *cells_fwd, double *cells_bwd);
 void sa_batch_destroy(sa_batch_t *b);

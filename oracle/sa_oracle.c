@@ -1509,10 +1509,18 @@ static void *mt_worker(void *arg) {
     return NULL;
 }
 
+int sao_align_batch_mt2(const sao_model_t *m, const sao_job_t *jobs, int64_t n_jobs, const sao_params_t *p,
+                        int n_threads, int64_t *n_pairs_out, double *cells_out, const char *const *ambig256);
 int sao_align_batch_mt(const sao_model_t *m, const sao_job_t *jobs, int64_t n_jobs, const sao_params_t *p,
                        int n_threads, int64_t *n_pairs_out, double *cells_out) {
-    const char *ambig[256];
-    sao_default_ambig(ambig);
+    return sao_align_batch_mt2(m, jobs, n_jobs, p, n_threads, n_pairs_out, cells_out, NULL);
+}
+/* ambig256 == NULL: create_ambig_bases' own table */
+int sao_align_batch_mt2(const sao_model_t *m, const sao_job_t *jobs, int64_t n_jobs, const sao_params_t *p,
+                        int n_threads, int64_t *n_pairs_out, double *cells_out, const char *const *ambig256) {
+    const char *dflt[256];
+    sao_default_ambig(dflt);
+    const char *const *ambig = ambig256 ? ambig256 : dflt;
     pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
     int64_t next = 0;
     mt_t t = {m, jobs, n_jobs, p, n_pairs_out, cells_out, &next, &mu, ambig};

@@ -189,6 +189,8 @@ typedef struct sao_job {
 } sao_job_t;
 int sao_align_batch_mt(const sao_model_t *m, const sao_job_t *jobs, int64_t n_jobs, const sao_params_t *p,
                        int n_threads, int64_t *n_pairs_out, double *cells_out);
+int sao_align_batch_mt2(const sao_model_t *m, const sao_job_t *jobs, int64_t n_jobs, const sao_params_t *p,
+                        int n_threads, int64_t *n_pairs_out, double *cells_out, const char *const *ambig256 /* NULL: default table */);
 
 #ifdef __cplusplus
 }

@@ -111,6 +111,8 @@ def lib():
     L.sao_free.argtypes = [C.c_void_p]
     L.sao_align_batch_mt.restype = C.c_int
     L.sao_align_batch_mt.argtypes = [C.c_void_p, C.POINTER(Job), C.c_int64, C.POINTER(Params), C.c_int, ip, dp]
+    L.sao_align_batch_mt2.restype = C.c_int
+    L.sao_align_batch_mt2.argtypes = [C.c_void_p, C.POINTER(Job), C.c_int64, C.POINTER(Params), C.c_int, ip, dp, C.POINTER(C.c_char_p)]
     _LIB = L
     return L
 
@@ -510,8 +512,9 @@ def estimate_params(model, strand_event_map, events4, strand_read):
     return dict(zip(["scale", "shift", "var", "drift", "scale_sd", "var_sd", "shift_sd"], out.tolist()))
 
 
-def align_batch_mt(model, jobs, params, n_threads):
-    """jobs: list of dicts(ref, events4, ax, ay, scale, shift, var). Returns (n_pairs, cells) arrays."""
+def align_batch_mt(model, jobs, params, n_threads, ambig=None):
+    """jobs: list of dicts(ref, events4, ax, ay, scale, shift, var). Returns (n_pairs, cells) arrays.  ambig: an ambig_map()
+    (None: create_ambig_bases' defaults)."""
     n = len(jobs)
     arr = (Job * n)()
     keep = []
@@ -525,5 +528,5 @@ def align_batch_mt(model, jobs, params, n_threads):
                      len(axa), j["scale"], j["shift"], j["var"])
     npairs = np.zeros(n, dtype=np.int64)
     cells = np.zeros(n, dtype=np.float64)
-    lib().sao_align_batch_mt(model._h, arr, n, C.byref(params), n_threads, _ip(npairs), _dp(cells))
+    lib().sao_align_batch_mt2(model._h, arr, n, C.byref(params), n_threads, _ip(npairs), _dp(cells), ambig)
     return npairs, cells

@@ -46,3 +46,36 @@ for w in workloads:
                      ("pmc_mix2.json", "%s_pmc_%s_mix2.json" % (tag, w)), ("traffic.json", "%s_pmc_%s_traffic_by_kernel.json" % (tag, w))):
         if os.path.exists(os.path.join(d, src)):
             shutil.copy(os.path.join(d, src), os.path.join(ROOT, "profiles", dst))
+
+# round 4: the per-kernel times of the single-launch kernel statistics (probes/profile_r04.sh), merged into
+# profiles/kernel_times.json (what bench.py's expectation leg reads for its roofline), and the bench line of the same command
+import csv
+kt_path = os.path.join(ROOT, "profiles", "kernel_times.json")
+kt = json.load(open(kt_path)) if os.path.exists(kt_path) else {}
+for w in workloads:
+    d = os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, w))
+    cs, pf = os.path.join(d, "kernel_stats.csv"), os.path.join(d, "passes")
+    if not (os.path.exists(cs) and os.path.exists(pf)):
+        continue
+    passes = float(open(pf).read().split()[0])
+    rec = {}
+    for row in csv.DictReader(open(cs)):
+        k = bare(row["Name"].split("(")[0])
+        r = rec.setdefault(k, {"calls": 0, "total_ms": 0.0})
+        r["calls"] += int(row["Calls"])
+        r["total_ms"] += float(row["TotalDurationNs"]) * 1e-6
+    for k, r in rec.items():
+        r["avg_ms"] = r["total_ms"] / max(r["calls"], 1)
+        r["launches_per_step"] = r["calls"] / passes
+        r["ms_per_step"] = r["total_ms"] / passes
+    import subprocess, time
+    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    rec["_meta"] = {"head": head, "collected": time.strftime("%Y-%m-%d %H:%M"), "tag": tag, "kernel_passes": passes,
+                    "command": "SA_GROUPS=1 rocprofv3 --kernel-trace --stats -- python3 bench.py --workload %s --kernels-only --no-secondary "
+                               "(probes/profile_r04.sh)" % w}
+    kt[w] = rec
+    b = os.path.join(d, "bench_kernels_only.json")
+    if os.path.exists(b):
+        shutil.copy(b, os.path.join(ROOT, "profiles", "bench_%s_%s_kernels_only_groups1.json" % (tag, w)))
+json.dump(kt, open(kt_path, "w"), indent=1)
+print("wrote", kt_path)

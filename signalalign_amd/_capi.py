@@ -78,7 +78,7 @@ PAIR_DTYPE = np.dtype([("prob_e7", "<i8"), ("x", "<i4"), ("y", "<i4"), ("path", 
 
 EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alphabet", "sa_model_table5",
            "sa_model_set_to_hdp_expected_values", "sa_model_set_emission", "sa_model_clone_with_table", "sa_kmer_id", "sa_default_ambig", "sa_load_ambig",
-           "sa_batch_create", "sa_batch_create_deferred", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_stats",
+           "sa_batch_create", "sa_batch_create_deferred", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_pairs16", "sa_batch_pairs16_all", "sa_batch_pairs_all", "sa_batch_stats",
            "sa_batch_job_cells", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_plan_describe", "sa_plan_digest",
            "sa_plan_check_path_records", "sa_dplan_compare",
            "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_pool_configure", "sa_host_alloc", "sa_host_free", "sa_pair_roundtrip", "sa_fasta_subsequence", "sa_format_f6", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_device_memory", "sa_strerror",
@@ -142,6 +142,9 @@ def lib():
     L.sa_host_free.restype = None
     L.sa_batch_n_pairs.argtypes = [C.c_void_p, C.c_int64, ip]
     L.sa_batch_pairs.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+    L.sa_batch_pairs16.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), ip]
+    L.sa_batch_pairs_all.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, ip]
+    L.sa_batch_pairs16_all.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), ip]
     L.sa_batch_stats.argtypes = [C.c_void_p, C.POINTER(BatchStats)]
     L.sa_batch_job_cells.argtypes = [C.c_void_p, C.c_int64, dp, dp]
     L.sa_batch_destroy.argtypes = [C.c_void_p]
@@ -345,6 +348,7 @@ class JobArray:
                 q[key] = self.block.empty(src.shape, src.dtype)
                 q[key][...] = src
             jobs = moved
+        self.jobs = jobs    # (host_block: the dicts whose arrays live in the block)
         self.arr, self._keep = _make_jobs(jobs)
 
 
@@ -382,6 +386,43 @@ class Batch:
         if n.value:
             _chk(lib().sa_batch_pairs(self._h, job, out.ctypes.data, n.value), "sa_batch_pairs")
         return out
+
+    def pairs16(self, job):
+        """sa_batch_pairs16: the job's packed 16-byte records in place (a view into the batch's pinned result block, valid until
+        the batch runs again or is closed): uint64 array [n, 2] of (a, b), see sa_pair16_t."""
+        n, ptr = C.c_int64(), C.c_void_p()
+        _chk(lib().sa_batch_pairs16(self._h, job, C.byref(ptr), C.byref(n)), "sa_batch_pairs16")
+        if n.value == 0:
+            return np.zeros((0, 2), dtype=np.uint64)
+        buf = (C.c_uint64 * (2 * n.value)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=np.uint64).reshape(-1, 2)
+
+    def results_view(self, first=None):
+        """sa_batch_pairs16_all: what a finished batch holds, without copying anything -- (uint64 view [total, 2] of every job's
+        packed records, first) with job j's records at view[first[j]:first[j + 1]].  `first`: an int64 array of n_jobs + 1
+        entries to reuse."""
+        if first is None:
+            first = np.zeros(self.n_jobs + 1, dtype=np.int64)
+        ptr = C.c_void_p()
+        _chk(lib().sa_batch_pairs16_all(self._h, C.byref(ptr), _ip(first)), "sa_batch_pairs16_all")
+        total = int(first[self.n_jobs])
+        if total == 0:
+            return np.zeros((0, 2), dtype=np.uint64), first
+        buf = (C.c_uint64 * (2 * total)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=np.uint64).reshape(-1, 2), first
+
+    def pairs_all(self, out=None):
+        """sa_batch_pairs_all: every job's pairs as sa_pair_t, expanded on the library's host threads.  Returns (rows, first)
+        with rows[first[j]:first[j + 1]] job j's.  `out`: a PAIR_DTYPE array to reuse (large enough)."""
+        first = np.zeros(self.n_jobs + 1, dtype=np.int64)
+        rc = lib().sa_batch_pairs_all(self._h, None, 0, _ip(first))
+        if rc not in (0, -1):
+            _chk(rc, "sa_batch_pairs_all")
+        total = int(first[-1])
+        if out is None or len(out) < total:
+            out = np.empty(total, dtype=PAIR_DTYPE)
+        _chk(lib().sa_batch_pairs_all(self._h, out.ctypes.data, len(out), _ip(first)), "sa_batch_pairs_all")
+        return out[:total], first
 
     def n_pairs(self, job):
         n = C.c_int64()

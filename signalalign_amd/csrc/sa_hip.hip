@@ -841,27 +841,37 @@ __global__ __launch_bounds__(64) void k_finalize(DevPlan P, int seg0, int n_segs
 // maximum (gsum / gmc) and its exact total (k_fold); a read's expectations are sum_groups gsum * exp(gmc - total), its
 // likelihood the totals once per diagonal (hmm->likelihood += totalProbability, impl/pairwiseAligner.c:1432).  One wave per
 // region, a lane per checkpoint group; 8 doubles per read come back instead of 80 bytes per group (130 MB per 2000 reads).
-__global__ __launch_bounds__(64) void k_expect_reduce(DevPlan P, double *__restrict__ red) {
-    const sa_region_t *R = &P.regions[blockIdx.x];
+// Bit-reproducible from run to run: a read's regions (consecutive in the plan) are summed by ONE wave in region order -- the
+// wave of the read's first region; the others return -- with a fixed lane assignment and a fixed butterfly, no atomics.  What is
+// NOT the reference's order of additions: it adds cell by cell and the likelihood once per diagonal (:1432) where this adds
+// total * rows; transition expectations agree with the restatement to 1e-9 relative and the likelihood to 1e-12
+// (tests/test_gpu_expectations.py) -- that tolerance, not bit equality, is the parity statement of this entry point.
+__global__ __launch_bounds__(64) void k_expect_reduce(DevPlan P, double *__restrict__ red, int n_regions) {
+    const int r0 = (int) blockIdx.x;
+    const int job = P.regions[r0].job;
+    if (r0 > 0 && P.regions[r0 - 1].job == job) return;
     const int lane = threadIdx.x;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (long long sg = R->seg_off; sg < R->seg_off + R->n_seg; sg++) {
-        const sa_seg_t *S = &P.segs[sg];
-        const long long nrows = S->from - S->to;
-        for (int c = lane; c < S->n_ck; c += 64) {
-            const double total = P.totals[S->ck_base + c];
-            long long rows_here = nrows - (long long) c * SA_CKPT_EVERY;
-            if (rows_here > SA_CKPT_EVERY) rows_here = SA_CKPT_EVERY;
-            if (rows_here > 0) acc[7] += total * (double) rows_here;
-            if (!(total > NEG_INF)) continue;
-            const double sc = exp(P.gmc[S->ck_base + c] - total);
-            for (int k = 0; k < 7; k++) acc[k] += P.gsum[8 * (S->ck_base + c) + k] * sc;
+    for (int r = r0; r < n_regions && P.regions[r].job == job; r++) {
+        const sa_region_t *R = &P.regions[r];
+        for (long long sg = R->seg_off; sg < R->seg_off + R->n_seg; sg++) {
+            const sa_seg_t *S = &P.segs[sg];
+            const long long nrows = S->from - S->to;
+            for (int c = lane; c < S->n_ck; c += 64) {
+                const double total = P.totals[S->ck_base + c];
+                long long rows_here = nrows - (long long) c * SA_CKPT_EVERY;
+                if (rows_here > SA_CKPT_EVERY) rows_here = SA_CKPT_EVERY;
+                if (rows_here > 0) acc[7] += total * (double) rows_here;
+                if (!(total > NEG_INF)) continue;
+                const double sc = exp(P.gmc[S->ck_base + c] - total);
+                for (int k = 0; k < 7; k++) acc[k] += P.gsum[8 * (S->ck_base + c) + k] * sc;
+            }
         }
     }
     for (int k = 0; k < 8; k++) {
         double v = acc[k];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (lane == 0 && v != 0.0) atomicAdd(&red[8ll * R->job + k], v);
+        if (lane == 0) red[8ll * job + k] = v;
     }
 }
 
@@ -1006,6 +1016,7 @@ struct sa_batch {
     // device buffers
     sa_region_t *d_regions; sa_row_t *d_rows; int *d_pk; int *d_poff; int *d_pid; int *d_px; double *d_xc; double *d_ev;
     sa_prec_t *d_prec;
+    size_t d_blk_bytes;
     char *d_blk;           // SA_FLAG_INPUTS_IN_HOST_BLOCK: the image of the caller's block (its event records are gathered on this
                            // batch's own stream, possibly after sa_batch_create has returned: kept until the batch goes)
     sa_seg_t *d_segs; sa_ck_t *d_cks;
@@ -1345,19 +1356,47 @@ static int upload(T **dst, const T *src, long long n, long long pad = 0, bool sr
 // What the last overflow taught: batches of one stream resemble each other, so the next batch of the same model and threshold
 // starts with the candidate capacity the previous one had to grow to (a re-run of the whole pass costs a batch's kernel
 // time again: the HDP workload at threshold 0.1 ran 73 instead of 37 ms per batch until it stopped overflowing every time).
-struct SaCandMemo { std::mutex mu; const sa_model_t *model = nullptr; double threshold = 0.0; int factor = 1; };
-static SaCandMemo g_cand_memo;
-static int cand_memo_factor(const sa_model_t *m, double threshold) {
-    std::lock_guard<std::mutex> g(g_cand_memo.mu);
-    return (g_cand_memo.model == m && g_cand_memo.threshold == threshold) ? g_cand_memo.factor : 1;
-}
-static void cand_memo_note(const sa_model_t *m, double threshold, int factor) {
-    std::lock_guard<std::mutex> g(g_cand_memo.mu);
-    if (g_cand_memo.model == m && g_cand_memo.threshold == threshold) {
-        if (factor > g_cand_memo.factor) g_cand_memo.factor = factor;
-    } else {
-        g_cand_memo.model = m; g_cand_memo.threshold = threshold; g_cand_memo.factor = factor;
+// Keyed on the model OBJECT (its uid, not its address: the CLI clones and destroys a model per read and addresses come back), the
+// threshold and the device; a few entries, least recently used out.  The factor is not for ever: after `patience` batches in a
+// row without an overflow the next batch is planned one step (x4) lower; if that one overflows the old factor is back and the
+// patience is four times longer -- one outlier batch no longer inflates every later batch's candidate, probability and result
+// slots 4-16x.
+struct SaCandMemo {
+    struct Entry { uint64_t uid; double threshold; int device; int factor; int quiet; int patience; bool probing; uint64_t used; };
+    std::mutex mu;
+    std::vector<Entry> e;
+    uint64_t clock = 0;
+    Entry *find(uint64_t uid, double thr, int dev) {
+        for (auto &x : e)
+            if (x.uid == uid && x.threshold == thr && x.device == dev) { x.used = ++clock; return &x; }
+        return nullptr;
     }
+};
+static SaCandMemo g_cand_memo;
+static int cand_memo_factor(const sa_model_t *m, double threshold, int device) {   // once per batch created
+    std::lock_guard<std::mutex> g(g_cand_memo.mu);
+    SaCandMemo::Entry *x = g_cand_memo.find(m->uid, threshold, device);
+    if (!x) return 1;
+    if (x->probing && x->quiet >= 8) x->probing = false;   // the lower capacity held for eight batches
+    if (x->factor > 1 && ++x->quiet >= x->patience) { x->factor /= 4; if (x->factor < 1) x->factor = 1; x->quiet = 0; x->probing = true; }
+    return x->factor;
+}
+static void cand_memo_note(const sa_model_t *m, double threshold, int device, int factor) {   // a batch overflowed and grew to `factor`
+    std::lock_guard<std::mutex> g(g_cand_memo.mu);
+    SaCandMemo::Entry *x = g_cand_memo.find(m->uid, threshold, device);
+    if (!x) {
+        if (g_cand_memo.e.size() >= 32) {
+            size_t lru = 0;
+            for (size_t i = 1; i < g_cand_memo.e.size(); i++) if (g_cand_memo.e[i].used < g_cand_memo.e[lru].used) lru = i;
+            g_cand_memo.e.erase(g_cand_memo.e.begin() + (long) lru);
+        }
+        g_cand_memo.e.push_back({m->uid, threshold, device, factor, 0, 64, false, ++g_cand_memo.clock});
+        return;
+    }
+    if (factor > x->factor) x->factor = factor;
+    if (x->probing && x->patience < (1 << 20)) x->patience *= 4;   // the lower capacity did not hold
+    x->probing = false;
+    x->quiet = 0;
 }
 
 static std::atomic<int> g_batches_started(0);
@@ -1598,7 +1637,7 @@ static int batch_finish_body(sa_batch *b) {
     TRY((*UPT).bind(device));
     if (trace_c) fprintf(stderr, "[trace] create: upload ring ready at %.1f ms\n", now_ms_c() - tc0);
     {   // candidate capacity an earlier batch of this stream had to grow to
-        const int f = pl->params.threshold > 0.0 ? cand_memo_factor(m, pl->params.threshold) : 1;
+        const int f = pl->params.threshold > 0.0 ? cand_memo_factor(m, pl->params.threshold, device) : 1;
         if (f > 1) {
             sa_plan_grow_candidates(pl, f);
             b->cand_factor = f;
@@ -1715,7 +1754,7 @@ static int batch_finish_body(sa_batch *b) {
     up_lock.unlock();
     if (trace_c) fprintf(stderr, "[trace] create: inputs uploaded at %.1f ms\n", now_ms_c() - tc0);
     // working buffers
-    double working_bytes = 0;
+    double working_bytes = b->d_blk ? (double) b->d_blk_bytes : 0.0;   // (the image of the caller's block stays until the batch goes)
     auto dalloc = [&](void **p_, long long bytes) -> int {
         HIPCHK(g_sa_pool.get(SaPool::DEVICE, p_, (size_t) (bytes > 0 ? bytes : 8), device));
         working_bytes += (double) (bytes > 0 ? bytes : 8);
@@ -2166,7 +2205,7 @@ static int grow_after_overflow(sa_batch *b) {
     // a traceback segment produced more candidates than planned: enlarge and redo the pass
     sa_plan_grow_candidates(pl, 4);
     b->cand_factor = (b->cand_factor > 0 ? b->cand_factor : 1) * 4;
-    cand_memo_note(pl->model, pl->params.threshold, b->cand_factor);
+    cand_memo_note(pl->model, pl->params.threshold, b->device, b->cand_factor);
     g_sa_pool.put(SaPool::DEVICE, b->d_cands);
     g_sa_pool.put(SaPool::DEVICE, b->d_prob);
     b->d_cands = nullptr;
@@ -2418,6 +2457,38 @@ int sa_batch_pairs(const sa_batch_t *b, int64_t job, sa_pair_t *out, int64_t cap
     for (long long i = 0; i < n; i++) out[i] = sa_pair16_unpack(src[i]);
     return SA_OK;
 }
+int sa_batch_pairs16(const sa_batch_t *b, int64_t job, const sa_pair16_t **out, int64_t *n) {
+    if (!b || !out || !n || job < 0 || job >= b->c_n) return SA_EINVAL;
+    if (!b->ran) return SA_ESTATE;
+    *n = b->job_off[job + 1] - b->job_off[job];
+    *out = b->h_pairs + b->job_off[job];
+    return SA_OK;
+}
+int sa_batch_pairs16_all(const sa_batch_t *b, const sa_pair16_t **out, int64_t *first) {
+    if (!b || !out) return SA_EINVAL;
+    if (!b->ran) return SA_ESTATE;
+    *out = b->h_pairs;
+    if (first)
+        for (long long j = 0; j <= (long long) b->c_n; j++) first[j] = b->job_off[(size_t) j];
+    return SA_OK;
+}
+int sa_batch_pairs_all(const sa_batch_t *b, sa_pair_t *out, int64_t cap, int64_t *first) {
+    if (!b || (!out && cap > 0)) return SA_EINVAL;
+    if (!b->ran) return SA_ESTATE;
+    const long long nj = b->c_n, total = b->n_pairs_total;
+    if (first)
+        for (long long j = 0; j <= nj; j++) first[j] = b->job_off[(size_t) j];
+    if (total > cap) return SA_EINVAL;
+    // the records are contiguous in job order: equal slices to the host threads (9 million pairs per headline batch, 143 MB read
+    // and 215 MB written -- a memory-bound loop, first touch of the caller's buffer included)
+    const sa_pair16_t *src = b->h_pairs;
+    const size_t piece = 1 << 16, np_ = ((size_t) total + piece - 1) / piece;
+    sa_parallel_for(np_, [&](size_t q) {
+        const size_t i0 = q * piece, i1 = i0 + piece < (size_t) total ? i0 + piece : (size_t) total;
+        for (size_t i = i0; i < i1; i++) out[i] = sa_pair16_unpack(src[i]);
+    });
+    return SA_OK;
+}
 int sa_batch_stats(const sa_batch_t *b, sa_batch_stats_t *out) {
     if (!b || !out) return SA_EINVAL;
     { const int rcf = batch_finish(const_cast<sa_batch_t *>(b)); if (rcf) return rcf; }
@@ -2491,7 +2562,8 @@ int sa_expect_batch(const sa_model_t *m, const sa_params_t *p, const sa_job_t *j
     auto tail = [&]() -> int {
         HIPCHK(hipMemsetAsync(d_red, 0, 64 * (size_t) (n_jobs > 0 ? n_jobs : 1), b->stream));
         if (pl->n_regions > 0) {
-            hipLaunchKernelGGL(k_expect_reduce, dim3((unsigned) pl->n_regions), dim3(64), 0, b->stream, make_devplan(b), d_red);
+            hipLaunchKernelGGL(k_expect_reduce, dim3((unsigned) pl->n_regions), dim3(64), 0, b->stream, make_devplan(b), d_red,
+                               (int) pl->n_regions);
             HIPCHK(hipGetLastError());
         }
         int rc_ = dl(hb + o_red, d_red, 64 * (size_t) n_jobs);

@@ -50,7 +50,10 @@ struct sa_model {
     double *table5;          /* EMISSION_MATCH_MATRIX                                      */
     sa_hdp_t *hdp;
     int emission;            /* SA_EMISSION_* (signalalign_hip.h) */
+    uint64_t uid;            /* unique per model object of the process, never reused (an address is: the CLI clones and destroys a
+                              * model per read): what the library keys per-model memory on (candidate capacity, sa_hip.hip) */
 };
+uint64_t sa_model_next_uid(void);
 
 /* ---- plan (host arrays, uploaded as they are) -------------------------------------------------- */
 typedef struct sa_row {
@@ -139,40 +142,8 @@ typedef struct sa_cand {
     double fb;       /* forward.match + backward.match (log space)                    */
 } sa_cand_t;
 
-/* A result pair as it lives in HBM and crosses PCIe: 16 bytes instead of sa_pair_t's 24 (2000 x 5000-event reads return 9
- * million pairs per batch; broad HDP densities at threshold 0.01 four hundred million).  sa_batch_pairs() expands it.
- *   a = x (28 bits) | y (28 bits) << 28 | path bits 0..7 << 56        (the planners limit x, y < 2^28)
- *   b = kmer_id (32 bits) | prob_e7 (24 bits: <= 1e7) << 32 | path bits 8..15 << 56 */
-typedef struct sa_pair16 {
-    uint64_t a, b;
-} sa_pair16_t;
-#ifdef __cplusplus
-#define SA_PAIR16_FN static inline
-#else
-#define SA_PAIR16_FN static inline
-#endif
-#if defined(__HIPCC__) || defined(__HIP__)
-#define SA_PAIR16_ATTR __host__ __device__
-#else
-#define SA_PAIR16_ATTR
-#endif
-SA_PAIR16_ATTR SA_PAIR16_FN sa_pair16_t sa_pair16_pack(int64_t prob_e7, int32_t x, int32_t y, int32_t path, int32_t kmer_id) {
-    sa_pair16_t r;
-    r.a = ((uint64_t) (uint32_t) x & 0xfffffffull) | (((uint64_t) (uint32_t) y & 0xfffffffull) << 28) |
-          ((uint64_t) ((uint32_t) path & 0xffu) << 56);
-    r.b = (uint64_t) (uint32_t) kmer_id | (((uint64_t) prob_e7 & 0xffffffull) << 32) |
-          ((uint64_t) (((uint32_t) path >> 8) & 0xffu) << 56);
-    return r;
-}
-SA_PAIR16_ATTR SA_PAIR16_FN sa_pair_t sa_pair16_unpack(sa_pair16_t r) {
-    sa_pair_t o;
-    o.x = (int32_t) (r.a & 0xfffffffull);
-    o.y = (int32_t) ((r.a >> 28) & 0xfffffffull);
-    o.path = (int32_t) (((r.a >> 56) & 0xffull) | (((r.b >> 56) & 0xffull) << 8));
-    o.kmer_id = (int32_t) (uint32_t) (r.b & 0xffffffffull);
-    o.prob_e7 = (int64_t) ((r.b >> 32) & 0xffffffull);
-    return o;
-}
+/* (sa_pair16_t, the 16-byte result record, and its pack / unpack functions are part of the public header: a caller may read
+ * the packed records in place, sa_batch_pairs16) */
 
 typedef struct sa_jobinfo {
     int64_t region_off;

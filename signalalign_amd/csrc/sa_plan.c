@@ -112,6 +112,11 @@ static sa_hdp_t *hdp_from_desc(const sa_hdp_desc_t *d) {
     return h;
 }
 
+uint64_t sa_model_next_uid(void) {
+    static uint64_t next = 1;
+    return __atomic_fetch_add(&next, 1, __ATOMIC_RELAXED);
+}
+
 int sa_model_create(sa_model_t **out, int n_states, const char *alphabet, int k, const double *t10,
                     const double *table5, const sa_hdp_desc_t *hdp) {
     if (!out || !alphabet || !t10 || !table5) return SA_EINVAL;
@@ -122,6 +127,7 @@ int sa_model_create(sa_model_t **out, int n_states, const char *alphabet, int k,
     if (!m) return SA_ENOMEM;
     m->n_alpha = na;
     m->k = k;
+    m->uid = sa_model_next_uid();
     memcpy(m->alphabet, alphabet, na);
     sort_chars(m->alphabet, na);
     for (int i = 1; i < na; i++)
@@ -199,6 +205,7 @@ int sa_model_clone_with_table(sa_model_t **out, const sa_model_t *m, const doubl
     sa_model_t *c = calloc(1, sizeof(*c));
     if (!c) return SA_ENOMEM;
     *c = *m;
+    c->uid = sa_model_next_uid();
     c->hdp = NULL;
     c->table5 = malloc(sizeof(double) * 5 * (size_t) m->n_kmers);
     if (!c->table5) { free(c); return SA_ENOMEM; }
@@ -599,10 +606,14 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
     poff[0] = 0;
     poff[1] = 1;
     int maxP = 1;
+    /* results travel as 16-byte records (sa_pair16_t: 28 bits of x and y, 16 bits of path index) whatever kernels and
+     * finalisation produce them: a matrix or a cell they cannot name is refused here, as the device planner refuses it */
+    if (rc.x1 + lX >= SA_PAIR16_MAX_COORD || rc.y1 + lY >= SA_PAIR16_MAX_COORD) return SA_EUNSUPPORTED;
     for (int64_t x = 1; x <= lX; x++) {
         const char *s = jb->ref + rc.x1 + (x - 1);
         int64_t cnt = expand_kmer(m, s, ambig, NULL, 0);
         if (cnt < 0) return (int) cnt;
+        if (cnt > SA_PAIR16_MAX_PATHS) return SA_EUNSUPPORTED;
         GROW(pl, pid, n_pid, cap_pid, cnt, int32_t);
         int64_t got = expand_kmer(m, s, ambig, pl->pid + pl->n_pid, cnt);
         if (got < 0) return (int) got;

@@ -851,9 +851,11 @@ static int64_t run_slice(run_t *Rp, read_t *reads, int64_t n_reads, int batch_mo
             if (rc == SA_OK) rc = sa_batch_mea(b, 0, mea[s], n_mea[s], NULL, NULL, NULL);
             sa_batch_destroy(b);
         }
-        if (!validated && (rc == SA_EALPHABET || rc == SA_EBAND || rc == SA_EINVAL)) {
-            /* the planner turned the batch down: find the reads whose jobs it rejects (each planned alone on the host, all
-             * host threads), let them fail alone as the reference's one-process-per-read runs would, and start over */
+        if (!validated && rc != SA_OK && rc != SA_ENODEVICE && rc != SA_ENOMEM) {
+            /* the planner turned the batch down (a letter outside the alphabet, anchors that give no band, a cell of more paths
+             * or a matrix larger than the result records can name -- SA_EUNSUPPORTED --, ...): find the reads whose jobs it
+             * rejects (each planned alone on the host, all host threads), let them fail alone as the reference's
+             * one-process-per-read runs would, and start over.  Only when no read is to blame does the run end below. */
             validated = 1;
             validate_ctx_t vc = {&R, reads, who};
             parallel_for(n_ok, validate_one, &vc);

@@ -260,6 +260,28 @@ def make_reads_parallel(spec, indices, workers=None):
     the result is identical to the serial loop (every read is seeded by its index)."""
     import os
     indices = [int(i) for i in indices]
+    # SA_SYNTH_CACHE=<dir>: read sets are kept there (files of this code's own making) and loaded instead of generated again --
+    # the counter passes of one profiling session run the same workload many times, and under a profiler the generator is serial
+    cache = os.environ.get("SA_SYNTH_CACHE")
+    cpath = None
+    if cache and len(indices) >= 256:
+        import hashlib
+        import pickle
+        key = repr((spec["kind"], os.path.basename(spec["model"]), os.path.basename(spec.get("nhdp") or ""), spec["events"],
+                    sorted(spec.get("kw", {}).items()), indices[0], indices[-1], len(indices),
+                    hashlib.sha1(np.asarray(spec["table5"]).tobytes()).hexdigest() if "table5" in spec else ""))
+        cpath = os.path.join(cache, "reads_" + hashlib.sha1(key.encode()).hexdigest()[:20] + ".pkl")
+        if os.path.exists(cpath):
+            with open(cpath, "rb") as f:
+                return pickle.load(f)
+
+    def keep(reads):
+        if cpath:
+            os.makedirs(cache, exist_ok=True)
+            with open(cpath + ".tmp%d" % os.getpid(), "wb") as f:
+                pickle.dump(reads, f, protocol=4)
+            os.replace(cpath + ".tmp%d" % os.getpid(), cpath)
+        return reads
     if workers is None:
         workers = min(8, max(1, len(os.sched_getaffinity(0)) - 2))
         if os.environ.get("SA_SYNTH_WORKERS"):
@@ -270,7 +292,7 @@ def make_reads_parallel(spec, indices, workers=None):
                 any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
             workers = 1
     if workers <= 1 or len(indices) < 256:
-        return _reads_chunk((spec, indices))
+        return keep(_reads_chunk((spec, indices)))
     import multiprocessing as mp
     from concurrent.futures import ProcessPoolExecutor
     step = max(64, (len(indices) + 4 * workers - 1) // (4 * workers))
@@ -279,5 +301,5 @@ def make_reads_parallel(spec, indices, workers=None):
         with ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as ex:
             parts = list(ex.map(_reads_chunk, tasks))
     except Exception:   # (no processes to be had: process limits, a broken pool) -- the serial loop gives the same reads
-        return _reads_chunk((spec, indices))
-    return [r for part in parts for r in part]
+        return keep(_reads_chunk((spec, indices)))
+    return keep([r for part in parts for r in part])

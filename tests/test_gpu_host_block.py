@@ -10,6 +10,7 @@ import pytest
 
 import signalalign_amd as sa
 from signalalign_amd import synth
+from signalalign_amd._capi import jobs_bytes_in_block
 
 import sa_cases as cases
 
@@ -67,6 +68,32 @@ def test_same_plan_and_same_pairs_with_the_inputs_left_in_the_callers_block(reco
     for j in range(len(jobs)):
         assert np.array_equal(b.pairs(j), ref.pairs(j)), j
     b.close()
+    ref.close()
+
+
+def test_a_batch_that_uses_a_small_part_of_a_shared_arena(monkeypatch):
+    """One page-locked arena holds the arrays of many reads and a batch aligns every fourth of them: the covering range of its
+    arrays is four times what it names.  The library then packs the batch with host threads (as without the flag) instead of
+    sending -- and holding in HBM -- the other reads' bytes: same pairs, and the batch's device_bytes do not grow by the arena."""
+    pm = sa.Model.load(cases.MODEL_6MER)
+    p = sa.default_params()
+    jobs = [_records(j) for j in cases.synthetic_jobs(cases.MODEL_6MER, 24, 1800, 500)]
+    ja = sa.JobArray(jobs, host_block=True)
+    some = [ja.jobs[i] for i in range(0, len(jobs), 4)]
+    ref = sa.Batch(pm, p, [jobs[i] for i in range(0, len(jobs), 4)])
+    ref.run()
+    b = sa.Batch(pm, p, some, flags=FLAG)
+    b.run()
+    for j in range(len(some)):
+        assert np.array_equal(b.pairs(j), ref.pairs(j)), j
+    assert b.stats().device_bytes <= ref.stats().device_bytes * 1.02 + 4096
+    b.close()
+    # all of them: the block travels as it is, and its image in HBM is counted
+    full = sa.Batch(pm, p, ja, flags=FLAG)
+    full_ref = sa.Batch(pm, p, jobs)
+    assert full.stats().device_bytes >= full_ref.stats().device_bytes + 0.9 * jobs_bytes_in_block(jobs) - 4096
+    full.close()
+    full_ref.close()
     ref.close()
 
 

@@ -19,6 +19,8 @@ def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "signalalign_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(sa_[a-z0-9_]+)\s*\(", hdr))
+    # (the pack / unpack helpers of the 16-byte result record are `static inline` in the header itself, not exports)
+    declared -= set(re.findall(r"SA_PAIR16_FN\s+\w+\s+(sa_[a-z0-9_]+)\s*\(", hdr))
     L = sa.lib()
     for name in sorted(declared):
         assert hasattr(L, name), name
@@ -204,6 +206,26 @@ def test_planner_error_codes_and_empty_batch():
         with pytest.raises(sa.SaError) as ei:
             sa.plan_digest(pm, p, jobs, threads=t)
         assert ei.value.code == -5
+
+
+def test_cells_the_result_record_cannot_name_are_refused():
+    # results travel as 16-byte records with 16 bits of path index (sa_pair16_t): an ambiguity letter with eight options at
+    # six adjacent positions of a 6-mer window gives a cell 8^6 = 262144 paths -- refused by the planner (SA_EUNSUPPORTED)
+    # instead of truncated; the same letter at five positions (32768 paths) is planned
+    pm = sa.Model.load(cases.MODEL_6MER)
+    p = sa.default_params()
+    amb = sa.default_ambig({"Z": "ACGTACGT"})
+    job = cases.synthetic_jobs(cases.MODEL_6MER, 1, 120)[0]
+    ref = job["ref"]
+    too_many = dict(job)
+    too_many["ref"] = ref[:30] + "ZZZZZZ" + ref[36:]
+    with pytest.raises(sa.SaError) as ei:
+        sa.plan_digest(pm, p, [too_many], ambig=amb, threads=1)
+    assert ei.value.code == -8                                    # SA_EUNSUPPORTED
+    fits = dict(job)
+    fits["ref"] = ref[:30] + "ZZZZZ" + ref[35:]
+    info, _ = sa.plan_digest(pm, p, [fits], ambig=amb, threads=1)
+    assert info.n_regions == 1
 
 
 def test_scalings_by_method_of_moments(oracle):
