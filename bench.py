@@ -472,6 +472,19 @@ def measure(args, ctx, compact=False):
     dt_resident = (time.perf_counter() - t0) / KR
     ms_f, ms_b, ms_fold = ms_f / KR, ms_b / KR, ms_fold / KR
     n_pairs = int(batch.results_view()[1][-1])
+    # what a caller pays who wants sa_pair_t rows instead of the packed records the step ends at: sa_batch_pairs_all (host threads)
+    unpack_ms = None
+    if not compact and 0 < n_pairs < 5e7:
+        from signalalign_amd._capi import PAIR_DTYPE
+        rows_buf = np.empty(n_pairs, dtype=PAIR_DTYPE)
+        t_u = []
+        for _ in range(4):
+            tu0 = time.perf_counter()
+            batch.pairs_all(rows_buf)
+            t_u.append((time.perf_counter() - tu0) * 1e3)
+        unpack_ms = {"first_call_with_page_faults": t_u[0], "steady": min(t_u[1:])}
+        del rows_buf
+    batch.close()
     # The roofline's kernel times: the same resident batch planned with ONE backward launch per forward-storage pass
     # (SA_GROUPS=1), so that a stage is one launch of the dominant kernel alone on its stream, timed by the library's HIP
     # events on that stream -- and `rocprofv3 --kernel-trace --stats` over `bench.py --workload W --kernels-only` under
@@ -498,19 +511,7 @@ def measure(args, ctx, compact=False):
         b1.close()
     elif int(st0.n_groups) == int(st0.n_chunks):
         single = {"ms_forward": ms_f, "ms_backward": ms_b, "launches_per_pass": 1, "passes": int(st0.n_chunks)}
-    # what a caller pays who wants sa_pair_t rows instead of the packed records the step ends at: sa_batch_pairs_all (host threads)
-    unpack_ms = None
-    if not compact and 0 < n_pairs < 5e7:
-        from signalalign_amd._capi import PAIR_DTYPE
-        rows_buf = np.empty(n_pairs, dtype=PAIR_DTYPE)
-        t_u = []
-        for _ in range(4):
-            tu0 = time.perf_counter()
-            batch.pairs_all(rows_buf)
-            t_u.append((time.perf_counter() - tu0) * 1e3)
-        unpack_ms = {"first_call_with_page_faults": t_u[0], "steady": min(t_u[1:])}
-        del rows_buf
-    batch.close()
+
     # serial cycles (median of five, outside the timed region): what a caller without overlap pays per batch in steady state
     cycle = {"create": 0.0, "run": dt_resident * 1e3, "destroy": 0.0}
     if not args.kernels_only:

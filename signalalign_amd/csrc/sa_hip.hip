@@ -1761,7 +1761,8 @@ static int batch_finish_body(sa_batch *b) {
         return SA_OK;
     };
     TRY(dalloc((void **) &b->d_F, 24 * pl->max_chunk_cellpaths));
-    if (m->hdp && pl->n_fast_regions > 0) TRY(dalloc((void **) &b->d_E, 8 * pl->max_chunk_cellpaths));
+    // HDP: the emission plane of the register-, ring- and strip-kernel regions (one value per cell-path, laid out like the match plane)
+    if (m->hdp && pl->n_fast_regions + pl->n_ring_regions > 0) TRY(dalloc((void **) &b->d_E, 8 * pl->max_chunk_cellpaths));
     TRY(dalloc((void **) &b->d_vbuf, 8 * pl->n_vbuf));
     TRY(dalloc((void **) &b->d_cands, (long long) sizeof(sa_cand_t) * pl->n_cand));
     TRY(dalloc((void **) &b->d_prob, 8 * pl->n_cand));
@@ -1790,7 +1791,7 @@ static int batch_finish_body(sa_batch *b) {
         b->ids_flat.clear();
         // One-path ring-kernel regions go to the strip kernels (sa_strip.inc): Gaussian emissions, default arithmetic,
         // device-side finalisation, reference windows of fewer than 64 * STRIP_NS_MAX positions.  SA_STRIP=0: ring kernels.
-        b->strip_on = b->relax && !host_finalize && m->hdp == nullptr && !(getenv("SA_STRIP") && atoi(getenv("SA_STRIP")) == 0);
+        b->strip_on = !host_finalize && !(getenv("SA_STRIP") && atoi(getenv("SA_STRIP")) == 0);   // (HDP regions too: they read the emission plane)
         auto strip_region = [&](const sa_region_t &Rq) {
             return b->strip_on && Rq.kind == SA_KIND_RING && Rq.max_p == 1 && Rq.lX < 64ll * STRIP_NS_MAX && Rq.N >= 1;
         };
@@ -1954,7 +1955,7 @@ static int batch_finish_body(sa_batch *b) {
     b->stats.n_groups = (int64_t) b->groups.size();
     double fb = 0;
     for (long long r = 0; r < pl->n_regions; r++)   // (HDP register-kernel regions: 8 B more per cell, the emission plane)
-        fb += (m->hdp && pl->regions[r].kind == SA_KIND_FAST ? 32.0 : 24.0) * (double) pl->regions[r].f_cellpaths;
+        fb += (m->hdp && pl->regions[r].kind != SA_KIND_GENERIC ? 32.0 : 24.0) * (double) pl->regions[r].f_cellpaths;
     b->stats.f_bytes = fb;
     b->stats.device_bytes = working_bytes;
 #undef TRY
@@ -2131,6 +2132,13 @@ static int enqueue_pass(sa_batch *b, bool finalize, AfterGroup after_group) {
                     if (g_handles.stream(&b->xstream[q - 2], b->device, 0) != hipSuccess) { n_lanes = q; break; }
                     lanes[q] = b->xstream[q - 2];
                 }
+            if (P.m.hdp) {   // the emission plane of this pass's ring / strip regions, ahead of the sweeps that read it (on s0: the
+                             // other lanes wait for the event recorded below)
+                if (C.nst) launch_emit_hdp_ring(P, b->d_ids + C.ids_st, C.nst, pl->regions[b->ids_flat[(size_t) C.ids_st]].N, s0, false);
+                for (int cl = 0; cl < 16; cl++)
+                    if (C.nrr[cl])
+                        launch_emit_hdp_ring(P, b->d_ids + C.ids_rr[cl], C.nrr[cl], pl->regions[b->ids_flat[(size_t) C.ids_rr[cl]]].N, s0, cl >= 8);
+            }
             if (n_lanes > 1) {
                 HIPCHK(hipEventRecord(b->ev[1], s0));
                 for (int q = 1; q < n_lanes; q++) HIPCHK(hipStreamWaitEvent(lanes[q], b->ev[1], 0));

@@ -712,7 +712,10 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
     if (foff + 1 > SA_FAST_MAX_CELLS || ((lX + lY + K) >> 1) >= (1ll << (31 - SA_PK_SHIFT))) fast_ok = 0;
     rows[N + 1].xmyL = 0; rows[N + 1].width = 0; rows[N + 1].foff = foff;
     /* ring kernels (sa_ring.inc): several paths per cell, or one path and a band mostly wider than a wave */
-    int ring_ok = !(pl->flags & (SA_FLAG_EXACT | SA_FLAG_FORCE_GENERIC | SA_FLAG_EXPECT_INTERNAL)) && m->hdp == NULL &&
+    /* (HDP models: both read the emission plane k_emit_hdp_ring fills, one value per cell-path; same table limit as above) */
+    const int hdp_plane_ok = m->hdp == NULL ||
+                             !(m->hdp->grid_length < 2 || m->hdp->n_slots * m->hdp->grid_length * 16 >= SA_HDP_FAST_MAX_BYTES);
+    int ring_ok = !(pl->flags & (SA_FLAG_EXACT | SA_FLAG_FORCE_GENERIC | SA_FLAG_EXPECT_INTERNAL)) && hdp_plane_ok &&
                   max_rowpaths <= SA_RING_MAX_ROWPATHS && foff + 1 <= SA_FAST_MAX_CELLS && ring_env_on() &&
                   (maxP == 1 || (maxP <= 255 && ambig_options_distinct(ambig)));
     int use_ring = 0;

@@ -77,7 +77,7 @@ def test_a_batch_that_uses_a_small_part_of_a_shared_arena(monkeypatch):
     sending -- and holding in HBM -- the other reads' bytes: same pairs, and the batch's device_bytes do not grow by the arena."""
     pm = sa.Model.load(cases.MODEL_6MER)
     p = sa.default_params()
-    jobs = [_records(j) for j in cases.synthetic_jobs(cases.MODEL_6MER, 24, 1800, 500)]
+    jobs = [_records(j) for j in cases.synthetic_jobs(cases.MODEL_6MER, 16, 9000, 500)]   # (2.2 MB named of 8.6 MB covered)
     ja = sa.JobArray(jobs, host_block=True)
     some = [ja.jobs[i] for i in range(0, len(jobs), 4)]
     ref = sa.Batch(pm, p, [jobs[i] for i in range(0, len(jobs), 4)])
