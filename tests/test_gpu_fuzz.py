@@ -102,7 +102,9 @@ def test_random_shapes_hdp_and_expectations(oracle):
         b = sa.Batch(pm, p, jobs)
         b.run()
         st = b.stats()
-        assert st.n_fast_regions == st.n_regions and (split > 10 ** 6 or st.n_regions != len(jobs))   # (the small limit splits / drops matrices)
+        # (round 4: HDP regions whose band is mostly wider than a wave take the strip kernels, the rest the register kernels; nothing
+        # is left to the memory-resident ones.  The small limit splits / drops matrices)
+        assert st.n_fast_regions + st.n_ring_regions == st.n_regions and (split > 10 ** 6 or st.n_regions != len(jobs))
         for j, job in enumerate(jobs):
             cases.compare_pairs(b.pairs(j), cases.oracle_pairs(oracle, om, job, op), 100, p.threshold)
         b.close()

@@ -74,6 +74,9 @@ def test_hdp_with_cpg_ambiguity_against_the_oracle(oracle, threshold):
     st = b.stats()
     got = [b.pairs(j) for j in range(len(jobs))]
     b.close()
+    # several paths per cell: the ring kernels (they read one emission per cell-path from the plane k_emit_hdp_ring fills)
+    # (a read without a CpG keeps one path per cell and the register kernels)
+    assert st.n_ring_regions >= 4, (st.n_regions, st.n_fast_regions, st.n_ring_regions)
     worst, most_paths = 0, 0
     for j, job in enumerate(jobs):
         exp = cases.oracle_pairs(oracle, om, job, op, ambig=amb_o)
@@ -139,6 +142,36 @@ def test_hdp_ambiguity_is_independent_of_the_kernel_family(oracle, monkeypatch):
     for a, c in zip(*outs):
         cases.compare_pairs(a, c, 2, p.threshold)
         assert cases.same_order(a, c)
+
+
+def test_hdp_wide_bands_on_the_strip_kernels(oracle, monkeypatch):
+    """HDP emissions with the anchors a real guide alignment leaves (bands of 100-300 cells, one path per cell): the strip kernels
+    read the emission plane; against the oracle, and bit-identical to the ring kernels' one-path HDP flavour (SA_STRIP=0)."""
+    pm, om = _models(oracle)
+    p = sa.default_params(threshold=0.05)
+    op = cases.oracle_params(oracle, p)
+    jobs = [_thin(j, 29) for j in _jobs(pm, 2600, 431, n=3)] + [_thin(_jobs(pm, 300, 461, n=1)[0], 1000)]
+    b = sa.Batch(pm, p, jobs)
+    b.run()
+    st = b.stats()
+    got = [b.pairs(j) for j in range(len(jobs))]
+    b.close()
+    assert st.n_strip_regions >= 3, (st.n_regions, st.n_fast_regions, st.n_ring_regions, st.n_strip_regions)
+    for j, job in enumerate(jobs):
+        exp = cases.oracle_pairs(oracle, om, job, op)
+        assert len(exp) > 0.05 * len(job["events"])
+        w, lonely = cases.compare_pairs(got[j], exp, TOL_E7, p.threshold)
+        assert lonely <= max(4, len(exp) // 500)
+        assert cases.same_order(got[j], exp)
+    monkeypatch.setenv("SA_STRIP", "0")
+    b = sa.Batch(pm, p, jobs)
+    b.run()
+    st2 = b.stats()
+    ring = [b.pairs(j) for j in range(len(jobs))]
+    b.close()
+    assert st2.n_strip_regions == 0 and st2.n_ring_regions == st.n_ring_regions
+    for a, c in zip(got, ring):
+        assert np.array_equal(a, c)
 
 
 def _write_fasta(path, name, seq, width=60):
