@@ -353,10 +353,15 @@ def measure(args, ctx, compact=False):
         wl_name = "BASELINE configs[2]: R9.4 6-mer CpG model (ACEGT), every CpG cytosine ambiguous (C/E)"
     elif args.workload == "scaling":
         wl_name = "BASELINE configs[4], one GPU's slice (100k reads / 8): R9.4 6-mer template Gaussian HMM"
-    elif args.workload == "hdp":
+    elif args.workload in ("hdp", "hdp_cpg", "hdp_realistic"):
         model_path = os.path.join(gold, "testModelR73_acegot_template.model")
         nhdp = os.path.join(gold, "templateSingleLevelFixed.nhdp")
         wl_name = "BASELINE configs[3]: HDP emissions (templateSingleLevelFixed.nhdp, R7.3 ACEGOT 6-mer model)"
+        if args.workload == "hdp_cpg":     # the reference's methylation-calling workflow: --sm3Hdp with variant positions
+            ambig = sa.default_ambig({"X": "CE"})
+            wl_name += ", every CpG cytosine ambiguous (C/E): several paths per cell"
+        if args.workload == "hdp_realistic":
+            wl_name += ", anchors of a real guide alignment (a sixth of the bases)"
     alpha, k, t10, tab = synth.parse_model_table(model_path)
     pm = sa.Model.load(model_path, nhdp)
     if nhdp:
@@ -370,6 +375,10 @@ def measure(args, ctx, compact=False):
                     ref_pool=os.path.join(ROOT, "tests", "golden", "npReads", "ZymoRef.txt"))
     # spawned numpy-only workers; identical to the serial loop (several ranks on one host share its CPUs: fewer workers each)
     gen_workers = None if world == 1 else max(1, min(4, int(os.environ.get("SA_HOST_THREADS", "2"))))
+    def mark_cpg(job_list):   # hdp_cpg: the C of every CG becomes X (the reads' references come from a pool of real sequence)
+        for job in job_list:
+            job["ref"] = job["ref"].replace("CG", "XG")
+
     def make_many(idx):
         idx = [int(i) for i in idx]
         key = (args.workload, args.events, tuple(idx[:2]), idx[-1] if idx else -1, len(idx))
@@ -384,6 +393,8 @@ def measure(args, ctx, compact=False):
     from signalalign_amd import shard
     mine = shard.shard_indices([args.events] * (world * args.reads), rank, world)
     jobs = make_many(mine)
+    if args.workload == "hdp_cpg":
+        mark_cpg(jobs)
     def thin_like_a_guide_alignment(job_list, indices):
         # the anchors a real guide alignment leaves: the run structure of the reference's own example cigar (an indel every
         # 10-50 bases), 14 bases trimmed off both ends of every match run as signalMachine -m 14 does
@@ -403,8 +414,9 @@ def measure(args, ctx, compact=False):
                     pos += ln
             job["ax"], job["ay"] = job["ax"][keep], job["ay"][keep]
 
-    if args.workload == "realistic":
+    if args.workload in ("realistic", "hdp_realistic"):
         thin_like_a_guide_alignment(jobs, [int(i) for i in mine])
+    if args.workload == "realistic":
         wl_name = ("BASELINE configs[1] reads with the anchor density of a real guide alignment "
                    "(tests/golden/cigars/ecoli_minus_strand.cigar, -m 14: a sixth of the bases)")
     # ---- read sets: every timed step aligns reads the library has not seen in the step before ----
@@ -417,8 +429,10 @@ def measure(args, ctx, compact=False):
     for q in range(1, n_sets):
         more = shard.shard_indices([args.events] * (world * args.reads), rank, world)
         extra = make_many([int(i) + q * world * args.reads for i in more])
-        if args.workload == "realistic":
+        if args.workload in ("realistic", "hdp_realistic"):
             thin_like_a_guide_alignment(extra, [int(i) + q * world * args.reads for i in more])
+        if args.workload == "hdp_cpg":
+            mark_cpg(extra)
         sets.append(extra)
     if args.event_stride == 1:
         for js in sets:
@@ -667,7 +681,7 @@ def measure(args, ctx, compact=False):
         fam = "fast" if st0.n_fast_regions == st0.n_regions else ("ring" if st0.n_ring_regions > 0 else "generic")
         if fam == "ring" and 2 * st0.n_strip_regions > st0.n_ring_regions:
             fam = "strip"
-        sfx = "_hdp" if (args.workload == "hdp" and fam == "fast") else ""
+        sfx = "_hdp" if (args.workload.startswith("hdp") and fam == "fast") else ""
         rf_f, rf_b = (single["ms_forward"], single["ms_backward"]) if single else (ms_f, ms_b)
         if ms_b >= ms_f:
             dom, dom_ms, dom_cells = "k_bwd_" + fam + sfx, rf_b, st0.cells_backward
@@ -805,12 +819,16 @@ def measure(args, ctx, compact=False):
             def make_sample(n_, first_):
                 idx_ = list(range(first_, first_ + n_))
                 js_ = synth.make_reads_parallel(spec, idx_, workers=1)
-                if args.workload == "realistic":
+                if args.workload in ("realistic", "hdp_realistic"):
                     thin_like_a_guide_alignment(js_, idx_)
+                if args.workload == "hdp_cpg":
+                    mark_cpg(js_)
                 return js_
             out["cpu_baseline"] = cpu_baseline(om, op_, make_sample, args.events, args.cpu_reads_per_thread, 10 ** 6,
-                                               ambig=oracle.ambig_map({"X": "CE"}) if args.workload == "cpg" else None,
+                                               ambig=oracle.ambig_map({"X": "CE"}) if args.workload in ("cpg", "hdp_cpg") else None,
                                                what={"cpg": ", every CpG cytosine C/E", "hdp": ", HDP emissions",
+                                                     "hdp_cpg": ", HDP emissions, every CpG cytosine C/E",
+                                                     "hdp_realistic": ", HDP emissions, anchors of a guide alignment",
                                                      "realistic": ", anchors of a guide alignment"}.get(args.workload, ""))
         return out
     return None
@@ -830,7 +848,8 @@ def main():
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU (default: 2000 = BASELINE configs[1]; "
                                                              "scaling: 12500 = configs[4]'s 100k reads / 8 GPUs)")
     ap.add_argument("--events", type=int, default=None, help="events per read (default 5000; scaling: 10000)")
-    ap.add_argument("--workload", choices=["gaussian", "scaling", "cpg", "hdp", "realistic", "event_align", "mea", "expectations"],
+    ap.add_argument("--workload", choices=["gaussian", "scaling", "cpg", "hdp", "hdp_cpg", "hdp_realistic", "realistic", "event_align",
+                                           "mea", "expectations"],
                     default="gaussian",
                     help="gaussian = BASELINE configs[1] (the headline); scaling = configs[4]'s per-GPU slice (12500 "
                          "10k-event reads per GPU, several forward-storage passes); cpg = configs[2] (ACEGT model, every "
@@ -864,11 +883,11 @@ def main():
     args = ap.parse_args()
     if args.reads is None:
         # the sizes BASELINE.json names: configs[2] (cpg) 10 000 reads, configs[3] (hdp) 5000, configs[4]'s slice 12 500
-        args.reads = {"scaling": 12500, "hdp": 5000, "cpg": 10000}.get(args.workload, 2000)
+        args.reads = {"scaling": 12500, "hdp": 5000, "hdp_cpg": 2000, "hdp_realistic": 2000, "cpg": 10000}.get(args.workload, 2000)
     if args.events is None:
         args.events = 10000 if args.workload == "scaling" else 5000
     if args.threshold is None:
-        args.threshold = 0.1 if args.workload == "hdp" else 0.01
+        args.threshold = 0.1 if args.workload.startswith("hdp") else 0.01
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not under a launcher: become one (nothing in this process has touched or will touch the GPU)
         sys.exit(self_launch(args.gpus))

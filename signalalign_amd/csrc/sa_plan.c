@@ -1161,7 +1161,9 @@ int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, co
             pl->ev = get(sizeof(double) * (size_t) (te > 0 ? te : 1));
             int want_prec = 0;
             for (int t = 0; t < T; t++) want_prec |= W[t].pl->prec_cap != 0;
-            want_prec = want_prec && !(flags & (SA_FLAG_EXACT | SA_FLAG_FORCE_GENERIC | SA_FLAG_EXPECT_INTERNAL)) && m->hdp == NULL &&
+            want_prec = want_prec && !(flags & (SA_FLAG_EXACT | SA_FLAG_FORCE_GENERIC | SA_FLAG_EXPECT_INTERNAL)) &&
+                        (m->hdp == NULL ||   /* (HDP regions take the ring kernels too when the emission plane can be built) */
+                         !(m->hdp->grid_length < 2 || m->hdp->n_slots * m->hdp->grid_length * 16 >= SA_HDP_FAST_MAX_BYTES)) &&
                         ring_env_on();
             if (want_prec) {
                 pl->prec = get(sizeof(sa_prec_t) * (size_t) (ti > 0 ? ti : 1));

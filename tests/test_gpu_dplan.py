@@ -75,6 +75,12 @@ def test_device_plan_equals_host_plan_with_ambiguous_positions(monkeypatch):
             ref[i] = "L"
         jobs.append(dict(job, ref="".join(ref)))
     assert sa.dplan_compare(pm7, p, jobs) == 0
+    # round 4: the same reads under the HDP model (ring kernels reading the emission plane), and HDP reads with sparse anchors
+    hd = sa.Model.load(cases.MODEL_R73, cases.NHDP)
+    hd.set_to_hdp_expected_values()
+    assert sa.dplan_compare(hd, p, jobs) == 0
+    thin = cases.realistic_anchor_jobs(cases.MODEL_R73, 3, 1500, 7)
+    assert sa.dplan_compare(hd, p, thin + [dict(thin[0], ref=thin[0]["ref"].replace("CG", "LG"))]) == 0
 
 
 def test_batches_the_device_planner_leaves_to_the_host(oracle):

@@ -385,6 +385,18 @@ def test_strip_kernels_wide_bands_bit_identical_to_the_ring_kernels(oracle, monk
     again, _ = _run(pm, p, jobs)                                      # same bytes on a second batch (seams, atomics, planes)
     for j in range(len(jobs)):
         assert np.array_equal(again[j], got[j]), j
+    # round 4: `got` came from the one-pass backward sweep (candidates against the traceback's speculative total, survivors put in
+    # order by k_gather_strip); the two-pass sweep of round 2 (SA_STRIP_PASSES=2) gives the same bytes -- at several thresholds
+    # (a low one multiplies the candidates per diagonal, threshold 0.5 leaves diagonals without any) and with short tracebacks
+    for kw in (dict(), dict(threshold=0.0005), dict(threshold=0.5), dict(expansion=20, trace_back=30, min_diags=150)):
+        q = sa.default_params(**kw)
+        one, st1 = _run(pm, q, jobs)
+        monkeypatch.setenv("SA_STRIP_PASSES", "2")
+        two, st2p = _run(pm, q, jobs)
+        monkeypatch.delenv("SA_STRIP_PASSES")
+        assert st1.n_strip_regions == st2p.n_strip_regions and st1.n_strip_regions >= 12
+        for j in range(len(jobs)):
+            assert np.array_equal(one[j], two[j]), (kw, j, len(one[j]), len(two[j]))
 
 
 def test_ring_kernels_ambiguous_positions_every_read_against_the_oracle(oracle, monkeypatch):

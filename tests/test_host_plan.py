@@ -173,6 +173,12 @@ def test_threaded_planner_is_deterministic():
     g1 = sa.plan_digest(pm, p, jobs, flags=sa.FLAG_FORCE_GENERIC, threads=1)[1]
     g4 = sa.plan_digest(pm, p, jobs, flags=sa.FLAG_FORCE_GENERIC, threads=4)[1]
     assert g1 == g4
+    # round 4: an HDP model with ambiguity letters plans ring-kernel regions with per-path records in every thread's range
+    hd = sa.Model.load(cases.MODEL_R73, cases.NHDP)
+    hj = [dict(j, ref=j["ref"].replace("CG", "LG")) for j in cases.synthetic_jobs(cases.MODEL_R73, 9, 500, 40)]
+    h1 = sa.plan_digest(hd, p, hj, threads=1)
+    h3 = sa.plan_digest(hd, p, hj, threads=3)
+    assert h1[1] == h3[1] and h1[0].n_ring_regions == len(hj)
 
 
 def test_planner_error_codes_and_empty_batch():
