@@ -22,6 +22,13 @@
  *   :851-852  banded, scaled and descaled model                 1076 / 1076
  *   :920-970  every C read as C / E / O, and as the code L      1076 x 3 / 7349
  *   :902-918  HDP emissions at threshold 0.1                    1217
+ * and by posteriors the reference itself printed (two shipped output files of bundled reads, tests/test_oracle_reference_outputs.py;
+ * what is left between the two is one factor per checkpoint group, tests/sa_cases.py:reference_residual).
+ * Which emission stands on what: every vector above runs the two-distribution emission
+ * (emissions_signal_strawManGetKmerEventMatchProbWithDescaling, impl/stateMachine.c:607-650) or the HDP one.  The MeanOnly
+ * emission signalMachine installs today (..._MeanOnly, impl/stateMachine.c:557-605; case SAO_EM_MEANONLY_DESCALED of the emission switch below) is PINNED BY
+ * RESTATEMENT ONLY: the reference's tests that install it (tests/eventAlignerTests.c:226-542) read fast5 files, which cannot be
+ * opened here.  It is the two-distribution function with the noise factor left out -- six lines, compared with the source by eye.
  * Still unpinned: the 3441 / 12784 / 13606 / 3420 counts (their E. coli reference blobs are missing from the tree,
  * .MISSING_LARGE_BLOBS) and the event-alignment function (its reference tests read fast5 files).  See DESIGN.md section 2.
  *

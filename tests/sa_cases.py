@@ -195,3 +195,22 @@ def reference_output_ecoli1d_inputs(oracle):
         push(2, b2 - b - mm)
     push(0, 1)
     return gold, window, r, (m[0][0], m[-1][0] + 1, m[0][1], m[-1][1] + 1), ops
+
+
+def reference_residual(mine, gold):
+    """How a run's posteriors compare with the ones the reference printed (round 4, probes/reference_output_residuals.py).
+    The rows that differ by more than 1e-4 do not sit at band edges: they come in groups of consecutive diagonals that share ONE
+    multiplicative factor, |log factor| <= 1.5e-3 -- the total probability a posterior is divided by.  The reference refreshes
+    that total on every tenth diagonal of a traceback, and its approximate logAdd makes the total depend on the diagonal it is
+    evaluated on (un-banded restatement on the Zymo read: totals ten diagonals apart differ by 6e-5 in the median, 5e-4 at the
+    95th percentile, 1.7e-3 at most); which diagonals those are depends on where the tracebacks fire, i.e. on the guide
+    alignment, which cannot be the reference's (bwa's is not shipped).  So the bar that the explanation supports is RELATIVE:
+    |dp| <= 1.5e-3 p + 2e-6 (the print precision).  Returns (share of the reference's rows found, median |dp|, share of the found
+    rows within that bar, share within 1e-4 absolute, the rows beyond the bar as (x + y, x, y, reference p, this run's p))."""
+    common = sorted(set(mine) & set(gold))
+    g = np.array([gold[k] for k in common])
+    m = np.array([mine[k] for k in common])
+    d = np.abs(m - g)
+    ok = d <= 1.5e-3 * np.maximum(g, m) + 2e-6
+    beyond = [(k[-2] + k[-1], k[-2], k[-1], float(gg), float(mm)) for k, gg, mm, o in zip(common, g, m, ok) if not o]
+    return len(common) / max(len(gold), 1), float(np.median(d)), float(ok.mean()), float((d <= 1e-4).mean()), beyond

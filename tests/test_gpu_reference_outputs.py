@@ -59,6 +59,8 @@ def test_gpu_reproduces_the_reference_posteriors_of_the_zymo_read(oracle):
     common = set(mine) & set(gold)
     d = np.array([abs(mine[k_] - gold[k_]) for k_ in common])
     assert len(common) >= 0.97 * len(gold) and np.median(d) <= 2e-6 and (d <= 1e-4).mean() >= 0.9
+    found, _, within_rel, _, beyond = cases.reference_residual(mine, gold)   # (the residual is one factor per checkpoint group)
+    assert within_rel >= 0.99 and all(row[0] <= 60 for row in beyond), (within_rel, beyond[:5])
     # a dense event vector cannot carry the noise
     with pytest.raises(sa.SaError):
         sa.Batch(pm, p, [dict(job, events=np.ascontiguousarray(job["events"][:, 0]))])
@@ -99,3 +101,4 @@ def test_gpu_reproduces_the_reference_posteriors_of_the_r9p4_read(oracle):
     common = set(mine) & set(gold)
     d = np.array([abs(mine[k_] - gold[k_]) for k_ in common])
     assert len(common) >= 0.8 * len(gold) and np.median(d) <= 5e-6 and (d <= 1e-4).mean() >= 0.8
+    assert cases.reference_residual(mine, gold)[2] >= 0.94
