@@ -36,12 +36,12 @@ T0=$(date +%s.%N)
 SA_CLI_TIMING=1 $BIN --batch $W/manifest.tsv -T $M -f $W/ref.fa -g 100 $SA_CLI_EXTRA > $W/stdout.txt 2> $W/stderr.txt
 T1=$(date +%s.%N)
 tail -2 $W/stderr.txt
-BYTES=$(cat $W/out*.tsv | wc -c)
+BYTES=$(find $W -name 'out*.tsv' -print0 | xargs -0 cat | wc -c)
 python3 - <<PY
 n, ev, dt, b = $N, int(open("$W/n_events").read()), $T1 - $T0, $BYTES
 print("front door: %d reads x %d events in %.2f s wall (process start to exit) = %.3g events/s, %.1f reads/s; %.2f GB of TSV = %.2f GB/s"
       % (n, ev, dt, n * ev / dt, n / dt, b / 1e9, b / 1e9 / dt))
 PY
 # the text-I/O bound of the same rows: how fast this host re-reads and re-writes them with no formatting at all
-T2=$(date +%s.%N); cat $W/out*.tsv > $W/all.tsv; T3=$(date +%s.%N)
+T2=$(date +%s.%N); find $W -name 'out*.tsv' -print0 | xargs -0 cat > $W/all.tsv; T3=$(date +%s.%N)
 python3 -c "print('plain copy of the same bytes (cat): %.2f s' % ($T3 - $T2))"

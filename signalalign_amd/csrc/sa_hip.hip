@@ -1863,194 +1863,256 @@ static int batch_finish_body(sa_batch *b) {
     TRY((*UPT).drain());
     up_lock.unlock();
     if (trace_c) fprintf(stderr, "[trace] create: inputs uploaded at %.1f ms\n", now_ms_c() - tc0);
-    // working buffers
-    double working_bytes = b->d_blk ? (double) b->d_blk_bytes : 0.0;   // (the image of the caller's block stays until the batch goes)
+    // Working buffers and launch lists.  What does not fit is planned again: a deferred batch's storage budget dates from its first
+    // half -- other batches may have taken the memory since --, SA_FLAG_DEVICE_TO_ITSELF is a promise the caller can break, and
+    // candidate / result slots (HDP models, low thresholds) are sized after the budget was set.  When an allocation fails, what
+    // this attempt took goes back, the forward storage is re-packed into more passes of half the size at most (regions keep
+    // everything else of their plan: only regions[].chunk / f_base change) and the attempt is repeated; SA_ENOMEM only when a
+    // single region's planes and the fixed buffers do not fit together.
+    double working_bytes = 0.0;
+    bool quiet_fail = false;
     auto dalloc = [&](void **p_, long long bytes) -> int {
-        HIPCHK(g_sa_pool.get(SaPool::DEVICE, p_, (size_t) (bytes > 0 ? bytes : 8), device));
+        const hipError_t e_ = g_sa_pool.get(SaPool::DEVICE, p_, (size_t) (bytes > 0 ? bytes : 8), device);
+        if (e_ != hipSuccess) {
+            (void) hipGetLastError();
+            if (!quiet_fail) fprintf(stderr, "[signalalign_hip] working storage: %lld bytes: %s\n", bytes, hipGetErrorString(e_));
+            return e_ == hipErrorOutOfMemory ? SA_ENOMEM : SA_ENODEVICE;
+        }
         working_bytes += (double) (bytes > 0 ? bytes : 8);
         return SA_OK;
     };
-    TRY(dalloc((void **) &b->d_F, 24 * pl->max_chunk_cellpaths));
-    // HDP: the emission plane of the register-, ring- and strip-kernel regions (one value per cell-path, laid out like the match plane)
-    if (m->hdp && pl->n_fast_regions + pl->n_ring_regions > 0) TRY(dalloc((void **) &b->d_E, 8 * pl->max_chunk_cellpaths));
-    TRY(dalloc((void **) &b->d_vbuf, 8 * pl->n_vbuf));
-    TRY(dalloc((void **) &b->d_cands, (long long) sizeof(sa_cand_t) * pl->n_cand));
-    TRY(dalloc((void **) &b->d_prob, 8 * pl->n_cand));
-    b->cand_alloc = pl->n_cand;
-    TRY(dalloc((void **) &b->d_cand_count, 4 * pl->n_segs));
-    TRY(dalloc((void **) &b->d_seg_pass, 4 * pl->n_segs));
-    TRY(dalloc((void **) &b->d_seg_off, 8 * (2 * pl->n_segs + 8)));  // n+1 offsets per group
-    TRY(dalloc((void **) &b->d_overflow, 4));
-    TRY(dalloc((void **) &b->d_totals, 8 * pl->n_cks));
-    TRY(dalloc((void **) &b->d_bscratch, 8 * pl->n_bscratch));
-    if (b->expect) {
-        TRY(dalloc((void **) &b->d_gsum, 64 * pl->n_cks));
-        TRY(dalloc((void **) &b->d_gmc, 8 * pl->n_cks));
-    }
-    // launch lists: regions per chunk, traceback segments per group
-    {
-        const bool host_finalize = (flags & SA_FLAG_EXACT) || b->expect;
-        int want = 1;
-        const char *envg = getenv("SA_GROUPS");  // test hook
-        if (envg && atoi(envg) > 0) want = atoi(envg);
-        else if (!host_finalize) want = pl->n_chunks == 1 ? 8 : (pl->n_chunks < 4 ? 4 : 2);
-        // A caller that keeps batches in flight (sa_batch_start: another batch of this process is running while this one is
-        // created) already overlaps a batch's result copy with its neighbours' kernels; what it wants is few, large launches:
-        // 2000 x 5000-event reads, three in flight, step time with 1 / 2 / 3 / 8 groups: 13.9 / 13.1 / 12.9 / 14.9 ms.
-        if (!(envg && atoi(envg) > 0) && !host_finalize && g_batches_started.load() > 0 && want > 3) want = 3;
-        b->ids_flat.clear();
-        // One-path ring-kernel regions go to the strip kernels (sa_strip.inc): Gaussian emissions, default arithmetic,
-        // device-side finalisation, reference windows of fewer than 64 * STRIP_NS_MAX positions.  SA_STRIP=0: ring kernels.
-        b->strip_on = !host_finalize && !(getenv("SA_STRIP") && atoi(getenv("SA_STRIP")) == 0);   // (HDP regions too: they read the emission plane)
-        auto strip_region = [&](const sa_region_t &Rq) {
-            return b->strip_on && Rq.kind == SA_KIND_RING && Rq.max_p == 1 && Rq.lX < 64ll * STRIP_NS_MAX && Rq.N >= 1;
-        };
-        long long strip_max_n = 0, strip_max_seg = 0, strip_fwd_slots = 0, strip_bwd_slots = 0;
-        long long r = 0;
-        for (int c = 0; c < pl->n_chunks; c++) {
-            long long ra = r;
-            while (r < pl->n_regions && pl->regions[r].chunk == c) r++;
-            long long rb = r;
-            sa_launch_chunk C;
-            std::vector<int> gr, fr, sr_;
-            double work = 0;
-            std::vector<int> rr[16];
-            auto ring_class = [](const sa_region_t &Rq) {
-                const int cl = Rq.max_rowpaths <= 64 ? 0 : (int) ((Rq.max_rowpaths - 1) / 64);   // <= 7 (SA_RING_MAX_ROWPATHS)
-                return (Rq.max_p > 1 ? 8 : 0) + (cl > 7 ? 7 : cl);
+    // SA_TEST_FAIL_WORKING_ALLOC=n (test hook): an attempt fails as if out of memory while the plan has fewer than n passes
+    const int test_min_passes = getenv("SA_TEST_FAIL_WORKING_ALLOC") ? atoi(getenv("SA_TEST_FAIL_WORKING_ALLOC")) : 0;
+    auto build_working = [&]() -> int {
+        working_bytes = b->d_blk ? (double) b->d_blk_bytes : 0.0;   // (the image of the caller's block stays until the batch goes)
+        if (pl->n_chunks < test_min_passes && pl->n_regions > pl->n_chunks) return SA_ENOMEM;
+        TRY(dalloc((void **) &b->d_F, 24 * pl->max_chunk_cellpaths));
+        // HDP: the emission plane of the register-, ring- and strip-kernel regions (one value per cell-path, laid out like the match plane)
+        if (m->hdp && pl->n_fast_regions + pl->n_ring_regions > 0) TRY(dalloc((void **) &b->d_E, 8 * pl->max_chunk_cellpaths));
+        TRY(dalloc((void **) &b->d_vbuf, 8 * pl->n_vbuf));
+        TRY(dalloc((void **) &b->d_cands, (long long) sizeof(sa_cand_t) * pl->n_cand));
+        TRY(dalloc((void **) &b->d_prob, 8 * pl->n_cand));
+        b->cand_alloc = pl->n_cand;
+        TRY(dalloc((void **) &b->d_cand_count, 4 * pl->n_segs));
+        TRY(dalloc((void **) &b->d_seg_pass, 4 * pl->n_segs));
+        TRY(dalloc((void **) &b->d_seg_off, 8 * (2 * pl->n_segs + 8)));  // n+1 offsets per group
+        TRY(dalloc((void **) &b->d_overflow, 4));
+        TRY(dalloc((void **) &b->d_totals, 8 * pl->n_cks));
+        TRY(dalloc((void **) &b->d_bscratch, 8 * pl->n_bscratch));
+        if (b->expect) {
+            TRY(dalloc((void **) &b->d_gsum, 64 * pl->n_cks));
+            TRY(dalloc((void **) &b->d_gmc, 8 * pl->n_cks));
+        }
+        // launch lists: regions per chunk, traceback segments per group
+        {
+            const bool host_finalize = (flags & SA_FLAG_EXACT) || b->expect;
+            int want = 1;
+            const char *envg = getenv("SA_GROUPS");  // test hook
+            if (envg && atoi(envg) > 0) want = atoi(envg);
+            else if (!host_finalize) want = pl->n_chunks == 1 ? 8 : (pl->n_chunks < 4 ? 4 : 2);
+            // A caller that keeps batches in flight (sa_batch_start: another batch of this process is running while this one is
+            // created) already overlaps a batch's result copy with its neighbours' kernels; what it wants is few, large launches:
+            // 2000 x 5000-event reads, three in flight, step time with 1 / 2 / 3 / 8 groups: 13.9 / 13.1 / 12.9 / 14.9 ms.
+            if (!(envg && atoi(envg) > 0) && !host_finalize && g_batches_started.load() > 0 && want > 3) want = 3;
+            b->ids_flat.clear();
+            // One-path ring-kernel regions go to the strip kernels (sa_strip.inc): Gaussian emissions, default arithmetic,
+            // device-side finalisation, reference windows of fewer than 64 * STRIP_NS_MAX positions.  SA_STRIP=0: ring kernels.
+            b->strip_on = !host_finalize && !(getenv("SA_STRIP") && atoi(getenv("SA_STRIP")) == 0);   // (HDP regions too: they read the emission plane)
+            auto strip_region = [&](const sa_region_t &Rq) {
+                return b->strip_on && Rq.kind == SA_KIND_RING && Rq.max_p == 1 && Rq.lX < 64ll * STRIP_NS_MAX && Rq.N >= 1;
             };
-            for (long long q = ra; q < rb; q++) {
-                const sa_region_t &Rq = pl->regions[q];
-                if (strip_region(Rq)) { sr_.push_back((int) q); strip_max_n = Rq.N > strip_max_n ? Rq.N : strip_max_n; }
-                else if (Rq.kind == SA_KIND_RING) rr[ring_class(Rq)].push_back((int) q);
-                else if (Rq.kind != SA_KIND_FAST) gr.push_back((int) q);
-                else fr.push_back((int) q);
-                work += (double) Rq.N;
-            }
-            auto by_len_r = [&](int a, int d) { return pl->regions[a].N > pl->regions[d].N; };
-            // longest first inside each launch: the tail of a launch is then made of short waves
-            std::stable_sort(gr.begin(), gr.end(), by_len_r);
-            std::stable_sort(fr.begin(), fr.end(), by_len_r);
-            C.ids_gr = (long long) b->ids_flat.size(); C.ngr = (int) gr.size();
-            b->ids_flat.insert(b->ids_flat.end(), gr.begin(), gr.end());
-            C.ids_fr = (long long) b->ids_flat.size(); C.nfr = (int) fr.size();
-            b->ids_flat.insert(b->ids_flat.end(), fr.begin(), fr.end());
-            for (int cl = 0; cl < 16; cl++) {
-                std::stable_sort(rr[cl].begin(), rr[cl].end(), by_len_r);
-                C.ids_rr[cl] = (long long) b->ids_flat.size(); C.nrr[cl] = (int) rr[cl].size();
-                b->ids_flat.insert(b->ids_flat.end(), rr[cl].begin(), rr[cl].end());
-            }
-            std::stable_sort(sr_.begin(), sr_.end(), by_len_r);
-            C.ids_st = (long long) b->ids_flat.size(); C.nst = (int) sr_.size();
-            b->ids_flat.insert(b->ids_flat.end(), sr_.begin(), sr_.end());
-            strip_fwd_slots = (long long) sr_.size() > strip_fwd_slots ? (long long) sr_.size() : strip_fwd_slots;
-            long long chunk_bwd_slots = 0;
-            C.g0 = (int) b->groups.size();
-            // a group should still be a sizeable launch: at least 2048 segments each (measured optimum 6-8 groups
-            // for 18000 segments; 16 and more lose to launch gaps)
-            long long nseg_chunk = 0, nseg_wide = 0;
-            for (long long q = ra; q < rb; q++) {
-                nseg_chunk += pl->regions[q].n_seg;
-                if ((pl->regions[q].kind == SA_KIND_FAST && pl->regions[q].slots >= 2) ||
-                    (pl->regions[q].kind == SA_KIND_RING && pl->regions[q].max_rowpaths > 64))
-                    nseg_wide += pl->regions[q].n_seg;
-            }
-            // segments of wide-band regions live three to four times longer than those of dense anchors (4 ms against
-            // 1.2 ms), and so do the tails of their launches: fewer, larger groups.  2000 reads with realistic anchors,
-            // 17 300 segments, step time with 1 / 2 / 3 / 4 / 6 / 8 groups: 70.2 / 67.8 / 69.3 / 73.1 / 80.2 / 87 ms
-            // (strip-kernel segments: 1 / 2 / 3 / 4 groups give 39.5 / 38.3 / 37.5 / 42.9 ms per step of fresh reads)
-            const long long min_per_group = (2 * nseg_wide > nseg_chunk) ? (b->strip_on ? 5500 : 8192) : 2048;
-            int ng = want;
-            if (!(envg && atoi(envg) > 0))
-                while (ng > 1 && nseg_chunk / ng < min_per_group) ng--;
-            long long q = ra;
-            double acc = 0;
-            for (int g = 0; g < ng && q < rb; g++) {
-                long long qa = q;
-                double target = work * (double) (g + 1) / (double) ng;
-                while (q < rb && (g == ng - 1 || acc < target)) { acc += (double) pl->regions[q].N; q++; }
-                if (q == qa) continue;
-                // a read's regions stay in one group so that its pairs are contiguous in the output
-                while (q < rb && pl->regions[q].job == pl->regions[q - 1].job) { acc += (double) pl->regions[q].N; q++; }
-                sa_launch_group G;
-                G.seg0 = G.seg1 = G.ck0 = G.ck1 = 0;
-                std::vector<int> gs, fs, rs[16], ss;
-                bool any = false;
-                for (long long t = qa; t < q; t++) {
-                    const sa_region_t *R = &pl->regions[t];
-                    for (long long sg = R->seg_off; sg < R->seg_off + R->n_seg; sg++) {
-                        if (strip_region(*R)) {
-                            ss.push_back((int) sg);
-                            const long long span = pl->segs[sg].start - pl->segs[sg].to;
-                            strip_max_seg = span > strip_max_seg ? span : strip_max_seg;
-                        }
-                        else if (R->kind == SA_KIND_RING) rs[ring_class(*R)].push_back((int) sg);
-                        else (R->kind != SA_KIND_FAST ? gs : fs).push_back((int) sg);
-                        const sa_seg_t *S = &pl->segs[sg];
-                        if (!any) { G.seg0 = sg; G.ck0 = S->ck_base; any = true; }
-                        G.seg1 = sg + 1;
-                        G.ck1 = S->ck_base + S->n_ck;
-                    }
-                }
-                if (!any) continue;
-                auto by_len_s = [&](int a, int d) {
-                    return pl->segs[a].start - pl->segs[a].to > pl->segs[d].start - pl->segs[d].to;
+            long long strip_max_n = 0, strip_max_seg = 0, strip_fwd_slots = 0, strip_bwd_slots = 0;
+            long long r = 0;
+            for (int c = 0; c < pl->n_chunks; c++) {
+                long long ra = r;
+                while (r < pl->n_regions && pl->regions[r].chunk == c) r++;
+                long long rb = r;
+                sa_launch_chunk C;
+                std::vector<int> gr, fr, sr_;
+                double work = 0;
+                std::vector<int> rr[16];
+                auto ring_class = [](const sa_region_t &Rq) {
+                    const int cl = Rq.max_rowpaths <= 64 ? 0 : (int) ((Rq.max_rowpaths - 1) / 64);   // <= 7 (SA_RING_MAX_ROWPATHS)
+                    return (Rq.max_p > 1 ? 8 : 0) + (cl > 7 ? 7 : cl);
                 };
-                std::stable_sort(gs.begin(), gs.end(), by_len_s);
-                std::stable_sort(fs.begin(), fs.end(), by_len_s);
-                G.ids_gs = (long long) b->ids_flat.size(); G.ngs = (int) gs.size();
-                b->ids_flat.insert(b->ids_flat.end(), gs.begin(), gs.end());
-                G.ids_fs = (long long) b->ids_flat.size(); G.nfs = (int) fs.size();
-                b->ids_flat.insert(b->ids_flat.end(), fs.begin(), fs.end());
-                for (int cl = 0; cl < 16; cl++) {
-                    std::stable_sort(rs[cl].begin(), rs[cl].end(), by_len_s);
-                    G.ids_rs[cl] = (long long) b->ids_flat.size(); G.nrs[cl] = (int) rs[cl].size();
-                    b->ids_flat.insert(b->ids_flat.end(), rs[cl].begin(), rs[cl].end());
+                for (long long q = ra; q < rb; q++) {
+                    const sa_region_t &Rq = pl->regions[q];
+                    if (strip_region(Rq)) { sr_.push_back((int) q); strip_max_n = Rq.N > strip_max_n ? Rq.N : strip_max_n; }
+                    else if (Rq.kind == SA_KIND_RING) rr[ring_class(Rq)].push_back((int) q);
+                    else if (Rq.kind != SA_KIND_FAST) gr.push_back((int) q);
+                    else fr.push_back((int) q);
+                    work += (double) Rq.N;
                 }
-                std::stable_sort(ss.begin(), ss.end(), by_len_s);
-                G.ids_ss = (long long) b->ids_flat.size(); G.nss = (int) ss.size();
-                b->ids_flat.insert(b->ids_flat.end(), ss.begin(), ss.end());
-                G.seam_first = (unsigned) chunk_bwd_slots;   // (rebased behind the forward slots below)
-                chunk_bwd_slots += (long long) ss.size();
-                b->groups.push_back(G);
+                auto by_len_r = [&](int a, int d) { return pl->regions[a].N > pl->regions[d].N; };
+                // longest first inside each launch: the tail of a launch is then made of short waves
+                std::stable_sort(gr.begin(), gr.end(), by_len_r);
+                std::stable_sort(fr.begin(), fr.end(), by_len_r);
+                C.ids_gr = (long long) b->ids_flat.size(); C.ngr = (int) gr.size();
+                b->ids_flat.insert(b->ids_flat.end(), gr.begin(), gr.end());
+                C.ids_fr = (long long) b->ids_flat.size(); C.nfr = (int) fr.size();
+                b->ids_flat.insert(b->ids_flat.end(), fr.begin(), fr.end());
+                for (int cl = 0; cl < 16; cl++) {
+                    std::stable_sort(rr[cl].begin(), rr[cl].end(), by_len_r);
+                    C.ids_rr[cl] = (long long) b->ids_flat.size(); C.nrr[cl] = (int) rr[cl].size();
+                    b->ids_flat.insert(b->ids_flat.end(), rr[cl].begin(), rr[cl].end());
+                }
+                std::stable_sort(sr_.begin(), sr_.end(), by_len_r);
+                C.ids_st = (long long) b->ids_flat.size(); C.nst = (int) sr_.size();
+                b->ids_flat.insert(b->ids_flat.end(), sr_.begin(), sr_.end());
+                strip_fwd_slots = (long long) sr_.size() > strip_fwd_slots ? (long long) sr_.size() : strip_fwd_slots;
+                long long chunk_bwd_slots = 0;
+                C.g0 = (int) b->groups.size();
+                // a group should still be a sizeable launch: at least 2048 segments each (measured optimum 6-8 groups
+                // for 18000 segments; 16 and more lose to launch gaps)
+                long long nseg_chunk = 0, nseg_wide = 0;
+                for (long long q = ra; q < rb; q++) {
+                    nseg_chunk += pl->regions[q].n_seg;
+                    if ((pl->regions[q].kind == SA_KIND_FAST && pl->regions[q].slots >= 2) ||
+                        (pl->regions[q].kind == SA_KIND_RING && pl->regions[q].max_rowpaths > 64))
+                        nseg_wide += pl->regions[q].n_seg;
+                }
+                // segments of wide-band regions live three to four times longer than those of dense anchors (4 ms against
+                // 1.2 ms), and so do the tails of their launches: fewer, larger groups.  2000 reads with realistic anchors,
+                // 17 300 segments, step time with 1 / 2 / 3 / 4 / 6 / 8 groups: 70.2 / 67.8 / 69.3 / 73.1 / 80.2 / 87 ms
+                // (strip-kernel segments: 1 / 2 / 3 / 4 groups give 39.5 / 38.3 / 37.5 / 42.9 ms per step of fresh reads)
+                const long long min_per_group = (2 * nseg_wide > nseg_chunk) ? (b->strip_on ? 5500 : 8192) : 2048;
+                int ng = want;
+                if (!(envg && atoi(envg) > 0))
+                    while (ng > 1 && nseg_chunk / ng < min_per_group) ng--;
+                long long q = ra;
+                double acc = 0;
+                for (int g = 0; g < ng && q < rb; g++) {
+                    long long qa = q;
+                    double target = work * (double) (g + 1) / (double) ng;
+                    while (q < rb && (g == ng - 1 || acc < target)) { acc += (double) pl->regions[q].N; q++; }
+                    if (q == qa) continue;
+                    // a read's regions stay in one group so that its pairs are contiguous in the output
+                    while (q < rb && pl->regions[q].job == pl->regions[q - 1].job) { acc += (double) pl->regions[q].N; q++; }
+                    sa_launch_group G;
+                    G.seg0 = G.seg1 = G.ck0 = G.ck1 = 0;
+                    std::vector<int> gs, fs, rs[16], ss;
+                    bool any = false;
+                    for (long long t = qa; t < q; t++) {
+                        const sa_region_t *R = &pl->regions[t];
+                        for (long long sg = R->seg_off; sg < R->seg_off + R->n_seg; sg++) {
+                            if (strip_region(*R)) {
+                                ss.push_back((int) sg);
+                                const long long span = pl->segs[sg].start - pl->segs[sg].to;
+                                strip_max_seg = span > strip_max_seg ? span : strip_max_seg;
+                            }
+                            else if (R->kind == SA_KIND_RING) rs[ring_class(*R)].push_back((int) sg);
+                            else (R->kind != SA_KIND_FAST ? gs : fs).push_back((int) sg);
+                            const sa_seg_t *S = &pl->segs[sg];
+                            if (!any) { G.seg0 = sg; G.ck0 = S->ck_base; any = true; }
+                            G.seg1 = sg + 1;
+                            G.ck1 = S->ck_base + S->n_ck;
+                        }
+                    }
+                    if (!any) continue;
+                    auto by_len_s = [&](int a, int d) {
+                        return pl->segs[a].start - pl->segs[a].to > pl->segs[d].start - pl->segs[d].to;
+                    };
+                    std::stable_sort(gs.begin(), gs.end(), by_len_s);
+                    std::stable_sort(fs.begin(), fs.end(), by_len_s);
+                    G.ids_gs = (long long) b->ids_flat.size(); G.ngs = (int) gs.size();
+                    b->ids_flat.insert(b->ids_flat.end(), gs.begin(), gs.end());
+                    G.ids_fs = (long long) b->ids_flat.size(); G.nfs = (int) fs.size();
+                    b->ids_flat.insert(b->ids_flat.end(), fs.begin(), fs.end());
+                    for (int cl = 0; cl < 16; cl++) {
+                        std::stable_sort(rs[cl].begin(), rs[cl].end(), by_len_s);
+                        G.ids_rs[cl] = (long long) b->ids_flat.size(); G.nrs[cl] = (int) rs[cl].size();
+                        b->ids_flat.insert(b->ids_flat.end(), rs[cl].begin(), rs[cl].end());
+                    }
+                    std::stable_sort(ss.begin(), ss.end(), by_len_s);
+                    G.ids_ss = (long long) b->ids_flat.size(); G.nss = (int) ss.size();
+                    b->ids_flat.insert(b->ids_flat.end(), ss.begin(), ss.end());
+                    G.seam_first = (unsigned) chunk_bwd_slots;   // (rebased behind the forward slots below)
+                    chunk_bwd_slots += (long long) ss.size();
+                    b->groups.push_back(G);
+                }
+                strip_bwd_slots = chunk_bwd_slots > strip_bwd_slots ? chunk_bwd_slots : strip_bwd_slots;
+                C.g1 = (int) b->groups.size();
+                b->chunks.push_back(C);
             }
-            strip_bwd_slots = chunk_bwd_slots > strip_bwd_slots ? chunk_bwd_slots : strip_bwd_slots;
-            C.g1 = (int) b->groups.size();
-            b->chunks.push_back(C);
-        }
-        if (strip_fwd_slots + strip_bwd_slots > 0) {
-            // seam storage: per wave two arrays of (diagonals of the longest strip-kernel region / traceback segment + lead-in
-            // + sentinels) records; the groups of a pass run side by side, every segment has its own slot behind the forward
-            // launch's
-            b->seam_cap = (unsigned) (strip_max_n + 16);
-            b->seam_cap_bwd = (unsigned) (strip_max_seg + 16);
-            b->seam_bwd_off = strip_fwd_slots * 32ll * (long long) b->seam_cap;
-            TRY(dalloc((void **) &b->d_seam, b->seam_bwd_off + strip_bwd_slots * 32ll * (long long) b->seam_cap_bwd));
-            // side buffer of the (two-pass) backward strip kernel: the two backward gap sums of every checkpoint cell, laid out like vbuf
-            TRY(dalloc((void **) &b->d_ckxy, 16ll * (pl->n_vbuf > 0 ? pl->n_vbuf : 1)));
-            // the one-pass sweep (default; SA_STRIP_PASSES=2: the two-pass sweep of round 2): speculative totals per segment, sort keys
-            // per candidate slot.  Its 64-bit sort key holds 26 bits of diagonals below a traceback's start.
-            b->strip_one_pass = !(getenv("SA_STRIP_PASSES") && atoi(getenv("SA_STRIP_PASSES")) == 2) && strip_max_seg < (1ll << 26);
-            if (b->strip_one_pass) {
-                TRY(dalloc((void **) &b->d_spec, 8ll * (pl->n_segs > 0 ? pl->n_segs : 1)));
-                TRY(dalloc((void **) &b->d_sortkey, 8ll * (pl->n_cand > 0 ? pl->n_cand : 1)));
+            if (strip_fwd_slots + strip_bwd_slots > 0) {
+                // seam storage: per wave two arrays of (diagonals of the longest strip-kernel region / traceback segment + lead-in
+                // + sentinels) records; the groups of a pass run side by side, every segment has its own slot behind the forward
+                // launch's
+                b->seam_cap = (unsigned) (strip_max_n + 16);
+                b->seam_cap_bwd = (unsigned) (strip_max_seg + 16);
+                b->seam_bwd_off = strip_fwd_slots * 32ll * (long long) b->seam_cap;
+                TRY(dalloc((void **) &b->d_seam, b->seam_bwd_off + strip_bwd_slots * 32ll * (long long) b->seam_cap_bwd));
+                // side buffer of the (two-pass) backward strip kernel: the two backward gap sums of every checkpoint cell, laid out like vbuf
+                TRY(dalloc((void **) &b->d_ckxy, 16ll * (pl->n_vbuf > 0 ? pl->n_vbuf : 1)));
+                // the one-pass sweep (default; SA_STRIP_PASSES=2: the two-pass sweep of round 2): speculative totals per segment, sort keys
+                // per candidate slot.  Its 64-bit sort key holds 26 bits of diagonals below a traceback's start.
+                b->strip_one_pass = !(getenv("SA_STRIP_PASSES") && atoi(getenv("SA_STRIP_PASSES")) == 2) && strip_max_seg < (1ll << 26);
+                if (b->strip_one_pass) {
+                    TRY(dalloc((void **) &b->d_spec, 8ll * (pl->n_segs > 0 ? pl->n_segs : 1)));
+                    TRY(dalloc((void **) &b->d_sortkey, 8ll * (pl->n_cand > 0 ? pl->n_cand : 1)));
+                }
+            }
+            b->gev.resize(4 * b->groups.size(), nullptr);
+            b->cev.resize(2 * b->chunks.size(), nullptr);
+            for (auto &e : b->gev)
+                if (g_handles.event(&e, device) != hipSuccess) return SA_ENODEVICE;
+            for (auto &e : b->cev)
+                if (g_handles.event(&e, device) != hipSuccess) return SA_ENODEVICE;
+            if (g_sa_pool.get(SaPool::PINNED, (void **) &b->h_seg_off, 8 * (size_t) (pl->n_segs + (long long) b->groups.size() + 1),
+                              device) != hipSuccess ||
+                g_sa_pool.get(SaPool::PINNED, (void **) &b->h_overflow, 64, device) != hipSuccess) {
+                return SA_ENOMEM;
+            }
+            if (!host_finalize) {
+                TRY(dalloc((void **) &b->d_out, (long long) sizeof(sa_pair16_t) * pl->n_cand));
+                b->out_alloc = pl->n_cand;
             }
         }
-        b->gev.resize(4 * b->groups.size(), nullptr);
-        b->cev.resize(2 * b->chunks.size(), nullptr);
-        for (auto &e : b->gev)
-            if (g_handles.event(&e, device) != hipSuccess) return SA_ENODEVICE;
-        for (auto &e : b->cev)
-            if (g_handles.event(&e, device) != hipSuccess) return SA_ENODEVICE;
-        if (g_sa_pool.get(SaPool::PINNED, (void **) &b->h_seg_off, 8 * (size_t) (pl->n_segs + (long long) b->groups.size() + 1),
-                          device) != hipSuccess ||
-            g_sa_pool.get(SaPool::PINNED, (void **) &b->h_overflow, 64, device) != hipSuccess) {
-            return SA_ENOMEM;
+        return SA_OK;
+    };
+    auto release_working = [&]() {
+        void **ptrs[] = {(void **) &b->d_F, (void **) &b->d_E, (void **) &b->d_vbuf, (void **) &b->d_cands, (void **) &b->d_prob,
+                         (void **) &b->d_cand_count, (void **) &b->d_seg_pass, (void **) &b->d_seg_off, (void **) &b->d_overflow,
+                         (void **) &b->d_totals, (void **) &b->d_bscratch, (void **) &b->d_gsum, (void **) &b->d_gmc, (void **) &b->d_seam,
+                         (void **) &b->d_ckxy, (void **) &b->d_spec, (void **) &b->d_sortkey, (void **) &b->d_out};
+        for (void **q : ptrs)
+            if (*q) { g_sa_pool.put(SaPool::DEVICE, *q); *q = nullptr; }
+        if (b->h_seg_off) { g_sa_pool.put(SaPool::PINNED, b->h_seg_off); b->h_seg_off = nullptr; }
+        if (b->h_overflow) { g_sa_pool.put(SaPool::PINNED, b->h_overflow); b->h_overflow = nullptr; }
+        for (hipEvent_t e : b->gev) if (e) g_handles.park(e, device);
+        for (hipEvent_t e : b->cev) if (e) g_handles.park(e, device);
+        b->gev.clear(); b->cev.clear(); b->chunks.clear(); b->groups.clear(); b->ids_flat.clear();
+        b->seam_cap = 0; b->seam_cap_bwd = 0; b->seam_bwd_off = 0; b->strip_one_pass = false;
+    };
+    {
+        int rcw = SA_OK;
+        for (int attempt = 0; attempt < 6; attempt++) {
+            quiet_fail = true;
+            rcw = build_working();
+            if (rcw != SA_ENOMEM) break;
+            release_working();
+            long long largest = 1;
+            for (long long r = 0; r < pl->n_regions; r++) largest = pl->regions[r].f_cellpaths > largest ? pl->regions[r].f_cellpaths : largest;
+            if (pl->max_chunk_cellpaths <= largest) break;   // one region per pass already: nothing left to give
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void) hipGetLastError(); free_b = 0; }
+            free_b += g_sa_pool.idle_bytes(SaPool::DEVICE, device);
+            long long budget2 = pl->max_chunk_cellpaths / 2;
+            const long long by_free = (long long) (0.5 * (double) free_b / (m->hdp ? 32.0 : 24.0));
+            if (by_free > 0 && by_free < budget2) budget2 = by_free;
+            if (budget2 < largest) budget2 = largest;
+            sa_plan_repack(pl, budget2);
+            if (trace_c || !test_min_passes)
+                fprintf(stderr, "[signalalign_hip] working storage did not fit: forward storage re-packed into %d passes of at most %.1f GB\n",
+                        (int) pl->n_chunks, (m->hdp ? 32.0 : 24.0) * (double) pl->max_chunk_cellpaths / 1e9);
+            // the kernels read chunk / f_base from the device copy of the regions
+            if (pl->n_regions > 0 && hipMemcpy(b->d_regions, pl->regions, sizeof(sa_region_t) * (size_t) pl->n_regions, hipMemcpyHostToDevice) != hipSuccess) {
+                (void) hipGetLastError();
+                return SA_ENODEVICE;
+            }
         }
-        if (!host_finalize) {
-            TRY(dalloc((void **) &b->d_out, (long long) sizeof(sa_pair16_t) * pl->n_cand));
-            b->out_alloc = pl->n_cand;
-        }
+        if (rcw == SA_ENOMEM) fprintf(stderr, "[signalalign_hip] working storage does not fit the device\n");
+        if (rcw) return rcw;
     }
     {   // the launch lists (small)
         std::lock_guard<std::mutex> g_((*UPT).mu);

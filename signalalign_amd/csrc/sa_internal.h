@@ -189,6 +189,7 @@ typedef struct sa_plan {
 int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs, int64_t n_jobs,
                   const char *const *ambig256, unsigned flags, int64_t chunk_budget_cellpaths);
 void sa_plan_free(sa_plan_t *pl);
+void sa_plan_repack(sa_plan_t *pl, int64_t chunk_budget_cellpaths); /* regions[].chunk / f_base, max_chunk_cellpaths, n_chunks */
 void sa_plan_pool_release(void); /* frees the host blocks the planner keeps between batches */
 /* The calling thread's next sa_plan_build takes the big arrays of a threaded plan from `alloc` and returns them with
  * `release` (sa_batch_create: pinned memory from the caching allocator, so that the upload is a plain DMA); NULL, NULL

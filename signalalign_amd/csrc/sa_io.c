@@ -435,8 +435,82 @@ int sa_fasta_subsequence(const char *fasta_path, const char *name, int64_t start
     return SA_OK;
 }
 
+/* A batch front door fetches one window per read from the same FASTA: the record's index line (from <path>.fai, or from a scan
+ * of the file) is remembered per (path, record) -- validated against the file's size and modification time -- and the bases are
+ * read with one pread instead of a character at a time (100 000 short reads: 39.5 thread-seconds of 93 in the host stage were
+ * this function re-opening and re-parsing the index). */
+#include <fcntl.h>
+#include <pthread.h>
+#include <sys/stat.h>
+#include <unistd.h>
+typedef struct { char *key; long long len, off, bases, width; long long size; long long mtime_ns; } fai_memo_t;
+static fai_memo_t g_fai_memo[16];
+static int g_fai_next = 0;
+static pthread_mutex_t g_fai_mu = PTHREAD_MUTEX_INITIALIZER;
+static int fai_memo_get(const char *key, const struct stat *st, long long *len, long long *off, long long *bases, long long *width) {
+    int hit = 0;
+    pthread_mutex_lock(&g_fai_mu);
+    for (int i = 0; i < 16; i++)
+        if (g_fai_memo[i].key && strcmp(g_fai_memo[i].key, key) == 0 && g_fai_memo[i].size == (long long) st->st_size &&
+            g_fai_memo[i].mtime_ns == (long long) st->st_mtim.tv_sec * 1000000000ll + st->st_mtim.tv_nsec) {
+            *len = g_fai_memo[i].len; *off = g_fai_memo[i].off; *bases = g_fai_memo[i].bases; *width = g_fai_memo[i].width;
+            hit = 1;
+            break;
+        }
+    pthread_mutex_unlock(&g_fai_mu);
+    return hit;
+}
+static void fai_memo_put(const char *key, const struct stat *st, long long len, long long off, long long bases, long long width) {
+    pthread_mutex_lock(&g_fai_mu);
+    fai_memo_t *e = &g_fai_memo[g_fai_next];
+    g_fai_next = (g_fai_next + 1) % 16;
+    free(e->key);
+    e->key = strdup(key);
+    e->len = len; e->off = off; e->bases = bases; e->width = width;
+    e->size = (long long) st->st_size;
+    e->mtime_ns = (long long) st->st_mtim.tv_sec * 1000000000ll + st->st_mtim.tv_nsec;
+    pthread_mutex_unlock(&g_fai_mu);
+}
+static char *fasta_window(const char *fasta_path, long long len, long long off, long long bases, long long width, int64_t start,
+                          int64_t end_incl, int *err) {
+    if (start < 0) start = 0;
+    if (end_incl >= len) end_incl = len - 1;
+    const int64_t n = end_incl >= start ? end_incl - start + 1 : 0;
+    char *seq = malloc((size_t) n + 1);
+    if (!seq) { if (err) *err = -1; return NULL; }
+    int64_t got = 0;
+    if (n > 0 && bases > 0) {
+        const int fd = open(fasta_path, O_RDONLY);
+        if (fd < 0) { free(seq); if (err) *err = -1; return NULL; }
+        const long long pos = off + (start / bases) * width + (start % bases);
+        const long long extra = width > bases ? width - bases : 1;
+        const size_t want = (size_t) (n + (n / bases + 2) * extra + 2);
+        char *raw = malloc(want);
+        ssize_t have = raw ? pread(fd, raw, want, (off_t) pos) : -1;
+        close(fd);
+        for (ssize_t i = 0; i < have && got < n; i++)
+            if (raw[i] != '\n' && raw[i] != '\r') seq[got++] = raw[i];
+        free(raw);
+    }
+    seq[got] = 0;
+    return seq;
+}
+
 char *sa_fasta_fetch(const char *fasta_path, const char *name, int64_t start, int64_t end_incl, int *err) {
     if (err) *err = 0;
+    struct stat st_fa;
+    char *memo_key = NULL;
+    if (stat(fasta_path, &st_fa) == 0) {
+        memo_key = malloc(strlen(fasta_path) + strlen(name) + 2);
+        if (memo_key) {
+            sprintf(memo_key, "%s\n%s", fasta_path, name);
+            long long l_, o_, b_, w_;
+            if (fai_memo_get(memo_key, &st_fa, &l_, &o_, &b_, &w_)) {
+                free(memo_key);
+                return fasta_window(fasta_path, l_, o_, b_, w_, start, end_incl, err);
+            }
+        }
+    }
     size_t pl = strlen(fasta_path);
     char *fai = malloc(pl + 5);
     memcpy(fai, fasta_path, pl);
@@ -448,7 +522,7 @@ char *sa_fasta_fetch(const char *fasta_path, const char *name, int64_t start, in
         /* no index next to the FASTA: htslib's fai_load (impl/fasta_handler.c:19) would build one; here the record is
          * located by scanning, nothing is written */
         FILE *fs = fopen(fasta_path, "r");
-        if (!fs) { if (err) *err = -1; return NULL; }
+        if (!fs) { free(memo_key); if (err) *err = -1; return NULL; }
         const size_t name_len = strlen(name);
         long long pos = 0, rec_len = 0, rec_off = 0, rec_bases = 0, rec_width = 0, line_start = 0, line_bases = 0;
         int in_header = 0, match = 0, hdr_i = 0, hdr_ok = 1, first_line = 0, ch;
@@ -506,26 +580,9 @@ char *sa_fasta_fetch(const char *fasta_path, const char *name, int64_t start, in
     }
     fclose(fi);
     }
-    if (len < 0) { if (err) *err = -2; return NULL; }
-    if (start < 0) start = 0;
-    if (end_incl >= len) end_incl = len - 1;
-    int64_t n = end_incl >= start ? end_incl - start + 1 : 0;
-    char *seq = malloc((size_t) n + 1);
-    FILE *fa = fopen(fasta_path, "r");
-    if (!fa) { free(seq); if (err) *err = -1; return NULL; }
-    int64_t got = 0;
-    if (n > 0 && bases > 0) {
-        long long pos = off + (start / bases) * width + (start % bases);
-        fseek(fa, (long) pos, SEEK_SET);
-        int ch;
-        while (got < n && (ch = fgetc(fa)) != EOF) {
-            if (ch == '\n' || ch == '\r') continue;
-            seq[got++] = (char) ch;
-        }
-    }
-    fclose(fa);
-    seq[got] = 0;
-    return seq;
+    if (len < 0) { free(memo_key); if (err) *err = -2; return NULL; }
+    if (memo_key) { fai_memo_put(memo_key, &st_fa, len, off, bases, width); free(memo_key); }
+    return fasta_window(fasta_path, len, off, bases, width, start, end_incl, err);
 }
 
 static char comp_char(char c) {

@@ -1246,9 +1246,17 @@ int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, co
         sa_plan_free(pl);
         return rc;
     }
-    /* forward storage: pack regions into passes of at most chunk_budget cell-paths */
+    sa_plan_repack(pl, chunk_budget);
+    *out = pl;
+    return SA_OK;
+}
+
+/* forward storage: pack regions into passes of at most chunk_budget cell-paths (a region larger than the budget gets a pass of
+ * its own).  Also what a batch does again, with a smaller budget, when its working storage turns out not to fit the device. */
+void sa_plan_repack(sa_plan_t *pl, int64_t chunk_budget) {
     int32_t chunk = 0;
     int64_t used = 0;
+    pl->max_chunk_cellpaths = 0;
     for (int64_t r = 0; r < pl->n_regions; r++) {
         sa_region_t *R = &pl->regions[r];
         if (used > 0 && chunk_budget > 0 && used + R->f_cellpaths > chunk_budget) {
@@ -1261,8 +1269,6 @@ int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, co
         if (used > pl->max_chunk_cellpaths) pl->max_chunk_cellpaths = used;
     }
     pl->n_chunks = pl->n_regions ? chunk + 1 : 0;
-    *out = pl;
-    return SA_OK;
 }
 
 void sa_plan_grow_candidates(sa_plan_t *pl, int factor) {

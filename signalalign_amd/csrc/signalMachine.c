@@ -636,6 +636,20 @@ static void *pfor_worker(void *arg) {
 static void parallel_for(int64_t n, void (*fn)(int64_t, void *), void *ctx) {
     const char *e = getenv("SA_HOST_THREADS");
     long t = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+    if (!e) {   /* a container's CPU quota (cgroup v2 cpu.max): more runnable threads than that only get the whole group throttled */
+        static long quota = -1;
+        if (quota < 0) {
+            quota = 0;
+            FILE *fq = fopen("/sys/fs/cgroup/cpu.max", "r");
+            if (fq) {
+                char a[32];
+                long per = 0;
+                if (fscanf(fq, "%31s %ld", a, &per) == 2 && strcmp(a, "max") != 0 && per > 0) quota = (atol(a) + per - 1) / per;
+                fclose(fq);
+            }
+        }
+        if (quota > 0 && t > quota) t = quota;
+    }
     if (t > 32) t = 32;
     if (t > n) t = n;
     if (t <= 1) {
@@ -767,8 +781,28 @@ static void *slice_prepare(void *arg) {
     return NULL;
 }
 
-static int64_t run_slice(run_t *Rp, read_t *reads, int64_t n_reads, int batch_mode, int device) {
+/* What the GPU stage of a slice leaves for its rendering: the outputs of slice k are written (on a thread of their own) while
+ * the GPU stage of slice k + 1 runs -- 30 000 long reads: GPU stage 3.8 s, rendering 3.9 s, one after the other before. */
+static void release_read(read_t *rd);
+typedef struct {
+    run_t *Rp;
+    read_t *reads;
+    int64_t n_reads, n_ok;
+    int64_t *who;
+    sa_job_t *bj;
+    sa_pair_t **pairs_s[2];
+    int64_t *n_pairs_s[2];
+    sa_mea_pair_t **mea_s[2];
+    int64_t *n_mea_s[2];
+    int64_t n_failed;     /* out */
+} render_job_t;
+static void *render_slice(void *arg);
+
+/* GPU stage of a slice; returns the rendering job (NULL: nothing left to render -- the expectations mode writes its files
+ * here -- with the number of failed reads in *n_failed_now) */
+static render_job_t *run_slice(run_t *Rp, read_t *reads, int64_t n_reads, int batch_mode, int device, int64_t *n_failed_now) {
 #define R (*Rp)
+    *n_failed_now = 0;
     /* (the host side of the slice's reads has run: slice_prepare, a slice ahead of this function) */
     int64_t n_ok = 0;
     for (int64_t i = 0; i < n_reads; i++) n_ok += reads[i].failed ? 0 : 1;
@@ -815,7 +849,9 @@ static int64_t run_slice(run_t *Rp, read_t *reads, int64_t n_reads, int batch_mo
         for (int64_t j = 0; j < n_ok; j++)
             fprintf(stderr, "signalAlign - SUCCESS: finished alignment of query %s, exiting\n", reads[who[j]].label);
         free(bj); free(who);
-        return n_reads - n_ok;
+        *n_failed_now = n_reads - n_ok;
+        for (int64_t i = 0; i < n_reads; i++) release_read(&reads[i]);
+        return NULL;
     }
 
     sa_pair_t **pairs_s[2] = {NULL, NULL};
@@ -881,8 +917,29 @@ static int64_t run_slice(run_t *Rp, read_t *reads, int64_t n_reads, int batch_mo
     }
 
     /* ---- outputs: rendered in parallel (one file per read), summary lines in read order ---- */
+    g_t_gpu += now_s() - ts1;
+    render_job_t *job = calloc(1, sizeof(*job));
+    job->Rp = Rp; job->reads = reads; job->n_reads = n_reads; job->n_ok = n_ok; job->who = who; job->bj = bj;
+    for (int s = 0; s < 2; s++) { job->pairs_s[s] = pairs[s]; job->n_pairs_s[s] = n_pairs[s]; job->mea_s[s] = mea[s]; job->n_mea_s[s] = n_mea[s]; }
+    return job;
+#undef R
+}
+
+/* rendering of a slice (one file per read, in parallel), summary lines in read order, then the reads' memory goes back */
+static void *render_slice(void *arg) {
+    render_job_t *job = arg;
+    run_t *Rp = job->Rp;
+#define R (*Rp)
+    read_t *reads = job->reads;
+    const int64_t n_reads = job->n_reads, n_ok = job->n_ok;
+    int64_t *who = job->who;
+    sa_job_t *bj = job->bj;
+    sa_pair_t ***pairs = job->pairs_s;
+    int64_t **n_pairs = job->n_pairs_s;
+    sa_mea_pair_t ***mea = job->mea_s;
+    int64_t **n_mea = job->n_mea_s;
+    const int n_strands = R.two_d ? 2 : 1;
     const double ts2 = now_s();
-    g_t_gpu += ts2 - ts1;
     double (*score)[2] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(*score));
     {
         out_job_t oc = {&R, reads, who, pairs, n_pairs, score, mea, n_mea};
@@ -901,12 +958,14 @@ static int64_t run_slice(run_t *Rp, read_t *reads, int64_t n_reads, int batch_mo
             if (R.mea) sa_free(mea[s][j]);
         }
     }
-    g_t_render += now_s() - ts2;
+    t_add(&g_t_render, now_s() - ts2);
     int64_t n_failed = 0;
     for (int64_t i = 0; i < n_reads; i++) n_failed += reads[i].failed ? 1 : 0;
     for (int s = 0; s < n_strands; s++) { free(pairs[s]); free(n_pairs[s]); if (R.mea) { free(mea[s]); free(n_mea[s]); } }
     free(score); free(bj); free(who);
-    return n_failed;
+    for (int64_t i = 0; i < n_reads; i++) release_read(&reads[i]);
+    job->n_failed = n_failed;
+    return NULL;
 #undef R
 }
 
@@ -1077,8 +1136,12 @@ int main(int argc, char **argv) {
     }
     /* the reads go through in slices of --batch-reads (default 2048): bounded host and device memory for any manifest */
     /* Two slices are in the air: while the GPU stage and the rendering of slice k run here, a second thread does the host side
-     * of slice k+1 (10 000 short reads: host stage 0.39 s, GPU 0.28 s, rendering 0.25 s, one after the other before) */
+     * of slice k+1 (10 000 short reads: host stage 0.39 s, GPU 0.28 s, rendering 0.25 s, one after the other before).  A third
+     * stage -- rendering on a thread of its own -- exists behind SA_CLI_RENDER_THREAD=1 and does not pay (see below). */
     int64_t n_failed = 0;
+    pthread_t render_th;
+    render_job_t *render_prev = NULL;
+    int rendering = 0;
     slice_prep_t cur = {&R, reads, n_reads < batch_reads ? n_reads : batch_reads, batch_mode}, nxt;
     slice_prepare(&cur);
     for (int64_t off = 0; off < n_reads; off += batch_reads) {
@@ -1091,9 +1154,35 @@ int main(int argc, char **argv) {
             started = pthread_create(&th, NULL, slice_prepare, &nxt) == 0;
             if (!started) slice_prepare(&nxt);
         }
-        n_failed += run_slice(&R, reads + off, n, batch_mode, device);
-        for (int64_t i = 0; i < n; i++) release_read(&reads[off + i]);
+        int64_t failed_now = 0;
+        render_job_t *job = run_slice(&R, reads + off, n, batch_mode, device, &failed_now);
+        n_failed += failed_now;
+        /* the previous slice's rendering has had this slice's GPU stage to finish in; slices are rendered one after the other,
+         * so the summary lines stay in read order */
+        if (rendering) {
+            pthread_join(render_th, NULL);
+            n_failed += render_prev->n_failed;
+            free(render_prev);
+            rendering = 0;
+        }
+        if (job) {
+            /* SA_CLI_RENDER_THREAD=1: the slice is rendered on a thread of its own while the next slice's GPU stage runs.
+             * Measured on the 16-CPU quota of a GPU box and found SLOWER (30 000 long reads: 9.9 against 8.5 s; 100 000 short
+             * reads: no difference): the front door is bound by host CPU time -- text parsing and TSV rendering, 110
+             * thread-seconds per 30 000 long reads on 16 CPUs -- not by the order of its stages. */
+            const char *ert = getenv("SA_CLI_RENDER_THREAD");
+            if (ert && atoi(ert) == 1) {
+                render_prev = job;
+                rendering = pthread_create(&render_th, NULL, render_slice, job) == 0;
+            }
+            if (!rendering) { render_slice(job); n_failed += job->n_failed; free(job); }
+        }
         if (started) pthread_join(th, NULL);
+    }
+    if (rendering) {
+        pthread_join(render_th, NULL);
+        n_failed += render_prev->n_failed;
+        free(render_prev);
     }
     if (batch_mode)
         fprintf(stderr, "[signalMachine] batch: %" PRId64 " of %" PRId64 " reads aligned\n", n_reads - n_failed, n_reads);

@@ -585,6 +585,37 @@ def test_reference_whole_read_jobs(name):
         assert len(got[0]) == z.N_PAIRS_HDP_AT_0p1
 
 
+def test_working_storage_that_does_not_fit_is_planned_again(monkeypatch):
+    """A batch whose working storage does not fit the device (a deferred batch whose budget dates from before another batch took
+    the memory; candidate slots of an HDP model at a low threshold) re-packs its forward storage into more passes and tries
+    again instead of returning SA_ENOMEM.  The failure is injected (SA_TEST_FAIL_WORKING_ALLOC: attempts fail while the plan has
+    fewer passes); a second batch is alive meanwhile.  Same bytes as the unconstrained run, for device- and host-planned batches
+    and for a batch created in two halves."""
+    pm = sa.Model.load(cases.MODEL_6MER)
+    p = sa.default_params()
+    jobs = cases.synthetic_jobs(cases.MODEL_6MER, 12, 1500, 900) + cases.realistic_anchor_jobs(cases.MODEL_6MER, 3, 2200, 950)
+    ref = sa.Batch(pm, p, jobs)
+    ref.run()
+    assert ref.stats().n_chunks == 1
+    want = [ref.pairs(j) for j in range(len(jobs))]
+    monkeypatch.setenv("SA_TEST_FAIL_WORKING_ALLOC", "3")
+    for kw in (dict(), dict(deferred=True, flags=sa.FLAG_DEVICE_TO_ITSELF)):
+        b = sa.Batch(pm, p, jobs, **kw)        # (`ref` is still alive and holds its storage)
+        b.run()
+        assert b.stats().n_chunks >= 3
+        for j in range(len(jobs)):
+            assert np.array_equal(b.pairs(j), want[j]), (kw, j)
+        b.close()
+    monkeypatch.setenv("SA_DEVICE_PLAN", "0")    # the host planner's batch
+    b = sa.Batch(pm, p, jobs)
+    b.run()
+    assert b.stats().n_chunks >= 3
+    for j in range(len(jobs)):
+        assert np.array_equal(b.pairs(j), want[j]), j
+    b.close()
+    ref.close()
+
+
 def test_storage_reuse_across_batches_and_release(oracle):
     """Batches take their storage from caching allocators: a second, DIFFERENT batch built from the blocks of a destroyed
     one (stale bytes in every buffer) gives the same pairs as in a fresh process state, and sa_pool_release() leaves the
