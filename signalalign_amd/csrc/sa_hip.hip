@@ -82,6 +82,8 @@ struct DevPlan {
     DevModel m;
     double log_thr;   // log(threshold)
     double threshold;
+    double *spec;     // ring / strip kernels: per traceback segment its speculative total (NaN: a segment of another kernel family)
+    double spec_slack;
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -810,6 +812,39 @@ __global__ __launch_bounds__(64) void k_fold(DevPlan P, long long ck0, long long
 // ---------------------------------------------------------------------------------------------------
 // finalize: posterior, threshold, floor; count survivors per segment
 // ---------------------------------------------------------------------------------------------------
+// The speculative total of every traceback segment of the ring / strip kernels (sa_strip.inc, "the speculative total of a
+// traceback"): log-sum-exp over the cell-paths and states of the segment's first diagonal of forward state + end state, from the
+// three planes the forward sweeps of these kernels keep on such diagonals.  One wave per segment, between the two sweeps of a pass;
+// segments of other kernel families keep their NaN.
+__global__ __launch_bounds__(64) void k_spec_match(DevPlan P, int seg0, int n_segs, double *__restrict__ spec) {
+    if ((int) blockIdx.x >= n_segs) return;
+    const int seg = seg0 + blockIdx.x;
+    const sa_seg_t *S = &P.segs[seg];
+    const sa_region_t *R = &P.regions[S->region];
+    if (R->kind != SA_KIND_RING) return;
+    const sa_row_t *rows = P.rows + R->row_off;
+    const long long start = S->start;
+    const long long o0 = rows[start].foff & 0xffffffffll, o1 = rows[start + 1].foff & 0xffffffffll;   // (g0 << 32 | offset; row N + 1 closes)
+    const long long C = R->f_cellpaths;
+    const double *Fm = P.F + 3 * R->f_base + o0;   // planes [match | gapX | gapY] of C cell-paths each
+    const int np = (int) (o1 - o0), lane = threadIdx.x;
+    const bool ragged_end = S->at_end && R->ragged_r;   // endStateProb / raggedEndStateProb (impl/stateMachine.c:1145-1173)
+    const double em = ragged_end ? (P.m.t_mx + P.m.t_my) / 2.0 : P.m.t_mm, ex = ragged_end ? P.m.t_xx : P.m.t_xm,
+                 ey = ragged_end ? P.m.t_yy : P.m.t_ym;
+    double mx = NEG_INF;
+    for (int j = lane; j < np; j += 64) {
+        const double a = Fm[j] + em, b_ = Fm[C + j] + ex, c = Fm[2 * C + j] + ey;
+        const double v = a > b_ ? (a > c ? a : c) : (b_ > c ? b_ : c);
+        mx = v > mx ? v : mx;
+    }
+    mx = wave_max(mx);
+    double sum = 0.0;
+    if (mx > NEG_INF)
+        for (int j = lane; j < np; j += 64) sum += exp(Fm[j] + em - mx) + exp(Fm[C + j] + ex - mx) + exp(Fm[2 * C + j] + ey - mx);
+    sum = wave_sum(sum);
+    if (lane == 0) spec[seg] = (mx > NEG_INF && sum > 0.0) ? mx + log(sum) : NEG_INF;
+}
+
 // spec (one-pass strip sweep, sa_strip.inc): per segment the speculative total its candidate bound was derived from, NaN for every
 // other segment.  The bound is only valid while no exact total of the segment lies below spec - slack: checked here, raised in
 // P.overflow[1] (the pass is then repeated with the two-pass sweep).
@@ -917,8 +952,18 @@ __global__ __launch_bounds__(1024) void k_scan(const int *in, long long *out, lo
 // gather survivors of a segment in REVERSE candidate order (=> ascending diagonals, x descending, path descending:
 // the order of stList_pop + stable sort by x+y, impl/pairwiseAligner.c:2043-2050, impl/signalMachine.c:872)
 // seg_off: exclusive scan over the n_segs segments starting at seg0 (indexed from 0); out: first slot of that range
+// strip segment: a one-path ring-kernel region that the strip kernels sweep (the host's strip_region(), sa_hip.hip)
+__device__ __forceinline__ bool seg_is_strip(const sa_region_t *R, int strip_on) {
+    return strip_on && R->kind == SA_KIND_RING && R->max_p == 1 && R->lX < 64ll * STRIP_NS_MAX && R->N >= 1;
+}
+// spec: per segment its speculative total where the ring / strip kernels produced the candidates (NaN elsewhere), or nullptr.
+//   * a strip segment's candidates arrive strip by strip: k_gather_sorted writes it;
+//   * a ring segment's candidates arrive diagonal by diagonal (the workgroup's barrier separates diagonals) but, inside a
+//     diagonal, in the order the waves got there: a survivor's place is the number of survivors ahead of it in the list, minus
+//     those of its own diagonal among them, plus those of its own diagonal with a smaller (column, path) -- its neighbours in the
+//     list, a handful.
 __global__ __launch_bounds__(64) void k_gather(DevPlan P, int seg0, int n_segs, const long long *prob_e7,
-                                               const long long *seg_off, sa_pair16_t *out, const double *__restrict__ spec) {
+                                               const long long *seg_off, sa_pair16_t *out, const double *__restrict__ spec, int strip_on) {
     if ((int) blockIdx.x >= n_segs) return;
     const int lseg = blockIdx.x;
     int seg = seg0 + lseg;
@@ -930,17 +975,42 @@ __global__ __launch_bounds__(64) void k_gather(DevPlan P, int seg0, int n_segs, 
     int lane = threadIdx.x;
     long long total = seg_off[lseg + 1] - seg_off[lseg];
     long long done = 0;
-    if (spec) { const double sp = spec[seg]; if (sp == sp) return; }   // a one-pass strip segment: k_gather_strip writes it
+    bool unordered = false;
+    if (spec) {
+        const double sp = spec[seg];
+        if (sp == sp) {
+            if (seg_is_strip(R, strip_on)) return;
+            unordered = true;
+        }
+    }
+    const sa_cand_t *cd = P.cands + S->cand_off;
+    const long long *pe = prob_e7 + S->cand_off;
     for (int base = 0; base < n; base += 64) {
         int i = base + lane;
-        bool pass = i < n && prob_e7[S->cand_off + i] >= 0;
+        bool pass = i < n && pe[i] >= 0;
         unsigned long long mask = __ballot(pass);
         int rank = __popcll(mask & ((1ull << lane) - 1ull));
         if (pass) {
-            sa_cand_t c = P.cands[S->cand_off + i];
+            sa_cand_t c = cd[i];
             long long k = done + rank;              // index in candidate order
+            if (unordered) {
+                const int e_i = c.x + c.y;
+                const long long key_i = ((long long) c.x << 20) | c.path;
+                int same_before = 0, less = 0;
+                for (int j = i - 1; j >= 0; j--) {
+                    const sa_cand_t q = cd[j];
+                    if (q.x + q.y != e_i) break;
+                    if (pe[j] >= 0) { same_before++; less += (((long long) q.x << 20) | q.path) < key_i ? 1 : 0; }
+                }
+                for (int j = i + 1; j < n; j++) {
+                    const sa_cand_t q = cd[j];
+                    if (q.x + q.y != e_i) break;
+                    if (pe[j] >= 0) less += (((long long) q.x << 20) | q.path) < key_i ? 1 : 0;
+                }
+                k += less - same_before;
+            }
             long long pos = seg_off[lseg] + (total - 1 - k);
-            out[pos] = sa_pair16_pack(prob_e7[S->cand_off + i], (int) (c.x + R->x1), (int) (c.y + R->y1), c.path,
+            out[pos] = sa_pair16_pack(pe[i], (int) (c.x + R->x1), (int) (c.y + R->y1), c.path,
                                       pid[poff[c.x + 1] + c.path]);
         }
         done += __popcll(mask);
@@ -948,29 +1018,32 @@ __global__ __launch_bounds__(64) void k_gather(DevPlan P, int seg0, int n_segs, 
 }
 
 
-// The same for the segments of the one-pass strip sweep (sa_strip.inc, k_bwd_strip1), whose candidates arrive strip by strip
-// (high columns first; inside a strip diagonals downwards, columns upwards) instead of in candidate order (diagonals downwards,
-// columns upwards): the survivors are put in candidate order first -- a counting sort by diagonal (histogram of the segment's
-// diagonals in LDS, GATHER_H at a time), then every diagonal's few survivors by column -- and written as k_gather writes them.
-// A survivor travels as one 64-bit key: diagonals below the start (26 bits) | column (14 bits: strip regions hold fewer than
-// 16384 columns) | prob_e7 (24 bits).  keys: 8 bytes of scratch per candidate slot.
+// The same for the segments of the ring kernels and of the one-pass strip sweep (sa_ring.inc, sa_strip.inc), whose candidates are
+// appended in the order the waves / strips get to them instead of in candidate order (diagonals downwards, columns upwards, a
+// cell's paths upwards): the survivors are put in candidate order first -- a counting sort by diagonal (histogram of the
+// segment's diagonals in LDS, GATHER_H at a time), then every diagonal's few survivors by (column, path) -- and written as k_gather
+// writes them.  A survivor's key: diagonals below the start << 40 | column << 12 | path (28 and 12 bits: the planners' limits are
+// 2^28 columns and 255 paths per cell on these kernels); its candidate slot travels beside the key.  keys / idx: 12 bytes of
+// scratch per candidate slot.  The result does not depend on the order the candidates arrived in.
 #define GATHER_H 8192
-__global__ __launch_bounds__(64) void k_gather_strip(DevPlan P, int seg0, int n_segs, const long long *prob_e7, const long long *seg_off,
-                                                     sa_pair16_t *out, const double *__restrict__ spec,
-                                                     unsigned long long *__restrict__ keys_all) {
+__global__ __launch_bounds__(64) void k_gather_sorted(DevPlan P, int seg0, int n_segs, const long long *prob_e7, const long long *seg_off,
+                                                      sa_pair16_t *out, const double *__restrict__ spec,
+                                                      unsigned long long *keys_all, unsigned *idx_all) {
     __shared__ int H[GATHER_H + 64];
     if ((int) blockIdx.x >= n_segs) return;
     const int lseg = blockIdx.x, seg = seg0 + lseg;
-    { const double sp = spec[seg]; if (!(sp == sp)) return; }   // not a one-pass strip segment
+    { const double sp = spec[seg]; if (!(sp == sp)) return; }   // not a segment of these kernels: k_gather wrote it
     const sa_seg_t *S = &P.segs[seg];
     const sa_region_t *R = &P.regions[S->region];
+    if (!seg_is_strip(R, 1)) return;                            // a ring segment: k_gather wrote it
     const int *poff = P.poff + R->poff_off;
     const int *pid = P.pid + R->pid_off;
     const int n = P.cand_count[seg];
     const int lane = threadIdx.x;
     const long long total = seg_off[lseg + 1] - seg_off[lseg];
     if (total <= 0) return;
-    unsigned long long *keys = keys_all + S->cand_off;
+    volatile unsigned long long *keys = keys_all + S->cand_off;   // (written and read by different lanes: not through this CU's L1)
+    volatile unsigned *idx = idx_all + S->cand_off;
     const long long start = S->start, span = S->start - S->to;   // diagonals below the start: 0 .. span - 1
     long long placed = 0;   // survivors on diagonals above the current range (all in place)
     for (long long r0 = 0; r0 < span && placed < total; r0 += GATHER_H) {
@@ -1003,25 +1076,26 @@ __global__ __launch_bounds__(64) void k_gather_strip(DevPlan P, int seg0, int n_
         if (in_range > 0) {
             // placement: any order inside a diagonal (sorted below); the cursor of diagonal i runs from H[i] up to the old H[i + 1]
             for (int i = lane; i < n; i += 64) {
-                const long long pe = prob_e7[S->cand_off + i];
-                if (pe < 0) continue;
+                if (prob_e7[S->cand_off + i] < 0) continue;
                 const sa_cand_t c = P.cands[S->cand_off + i];
                 const long long de = start - ((long long) c.x + c.y + 2);
                 if (de < r0 || de >= r0 + hn) continue;
                 const int slot = atomicAdd(&H[(int) (de - r0)], 1);
-                keys[placed + slot] = ((unsigned long long) de << 38) | ((unsigned long long) (unsigned) c.x << 24) | (unsigned long long) pe;
+                keys[placed + slot] = ((unsigned long long) de << 40) | ((unsigned long long) (unsigned) c.x << 12) | (unsigned long long) (unsigned) c.path;
+                idx[placed + slot] = (unsigned) i;
             }
             __threadfence_block();
             __syncthreads();
-            // H[i] is now the END of diagonal i's group (= the old start of i + 1): sort every group by column (a handful of entries)
-            volatile unsigned long long *vk = keys;   // (written by other lanes a moment ago: not through this CU's L1)
+            // H[i] is now the END of diagonal i's group (= the old start of i + 1): sort every group (a handful of entries)
             for (int i = lane; i < hn; i += 64) {
                 const int ge = H[i], gs = i == 0 ? 0 : H[i - 1];
                 for (int a = gs + 1; a < ge; a++) {
-                    const unsigned long long k = vk[placed + a];
+                    const unsigned long long k = keys[placed + a];
+                    const unsigned ki = idx[placed + a];
                     int b = a - 1;
-                    while (b >= gs && vk[placed + b] > k) { vk[placed + b + 1] = vk[placed + b]; b--; }
-                    vk[placed + b + 1] = k;
+                    while (b >= gs && keys[placed + b] > k) { keys[placed + b + 1] = keys[placed + b]; idx[placed + b + 1] = idx[placed + b]; b--; }
+                    keys[placed + b + 1] = k;
+                    idx[placed + b + 1] = ki;
                 }
             }
             __threadfence_block();
@@ -1031,13 +1105,10 @@ __global__ __launch_bounds__(64) void k_gather_strip(DevPlan P, int seg0, int n_
     }
     // candidate order is ascending key order; written in reverse, as k_gather does
     for (long long k = lane; k < total; k += 64) {
-        const unsigned long long key = ((volatile unsigned long long *) keys)[k];
-        const long long de = (long long) (key >> 38);
-        const int cx = (int) ((key >> 24) & 0x3fffu);
-        const long long pe = (long long) (key & 0xffffffull);
-        const long long e = start - de;
-        const int cy = (int) (e - 2 - cx);
-        out[seg_off[lseg] + (total - 1 - k)] = sa_pair16_pack(pe, (int) (cx + R->x1), (int) (cy + R->y1), 0, pid[poff[cx + 1]]);
+        const unsigned i = idx[k];
+        const sa_cand_t c = P.cands[S->cand_off + i];
+        out[seg_off[lseg] + (total - 1 - k)] = sa_pair16_pack(prob_e7[S->cand_off + i], (int) (c.x + R->x1), (int) (c.y + R->y1), c.path,
+                                                              pid[poff[c.x + 1] + c.path]);
     }
 }
 
@@ -1137,8 +1208,10 @@ struct sa_batch {
     bool strip_on;           // one-path ring-kernel regions run on the strip kernels (default; SA_STRIP=0: ring kernels)
     double *d_ckxy;          // ... and the (two-pass) backward kernel's side buffer (2 x n_vbuf doubles)
     bool strip_one_pass;     // strip segments run the one-pass backward sweep (k_bwd_strip1; SA_STRIP_PASSES=2: the two-pass one)
-    double *d_spec;          // its speculative totals, one per segment (NaN: not a one-pass strip segment)
-    unsigned long long *d_sortkey;   // k_gather_strip's scratch, 8 bytes per candidate slot
+    double *d_spec;          // ring / strip kernels: speculative totals, one per segment (NaN: a segment of another kernel family)
+    double spec_slack;       // candidates: forward + backward >= spec - slack + log(threshold); grows when a pass has to be repeated
+    unsigned long long *d_sortkey;   // k_gather_sorted's scratch: 8 + 4 bytes per candidate slot
+    unsigned *d_sortidx;
     char *d_seam;            // their seam storage: per wave two arrays of seam_cap records of 16 bytes
     unsigned seam_cap;
     unsigned seam_cap_bwd;   // records per seam array of the backward launches (a traceback segment is shorter than a region)
@@ -1236,6 +1309,8 @@ static DevPlan make_devplan(const sa_batch *b) {
     }
     P.threshold = pl->params.threshold;
     P.log_thr = log(pl->params.threshold);
+    P.spec = b->d_spec;
+    P.spec_slack = b->spec_slack;
     return P;
 }
 
@@ -1533,7 +1608,7 @@ void sa_batch_destroy(sa_batch_t *b) {
     void *ptrs[] = {b->d_regions, b->d_rows, b->d_pk, b->d_poff, b->d_pid, b->d_px, b->d_xc, b->d_prec, b->d_ev, b->d_segs, b->d_cks, b->d_F, b->d_E,
                     b->d_vbuf, b->d_cands, b->d_cand_count, b->d_overflow, b->d_totals, b->d_bscratch, b->d_tab6, b->d_noise3, b->d_evn,
                     b->d_hdp_slot, b->d_hdp_y, b->d_hdp_slope, b->d_hdp_grid, b->d_hdp_tab, b->d_prob, b->d_seg_pass, b->d_seg_off,
-                    b->d_out, b->d_ids, b->d_gsum, b->d_gmc, b->d_seam, b->d_ckxy, b->d_blk, b->d_spec, b->d_sortkey};
+                    b->d_out, b->d_ids, b->d_gsum, b->d_gmc, b->d_seam, b->d_ckxy, b->d_blk, b->d_spec, b->d_sortkey, b->d_sortidx};
     for (void *p : ptrs)
         if (p) g_sa_pool.put(SaPool::DEVICE, p);
     for (int i = 0; i < 8; i++)
@@ -1609,7 +1684,7 @@ static int batch_create_impl(sa_batch_t **out, const sa_model_t *m, const sa_par
     b->d_ev = nullptr; b->d_segs = nullptr; b->d_cks = nullptr; b->d_F = nullptr; b->d_E = nullptr; b->d_vbuf = nullptr;
     b->d_cands = nullptr; b->d_cand_count = nullptr; b->d_overflow = nullptr; b->d_totals = nullptr;
     b->d_seam = nullptr; b->d_ckxy = nullptr; b->seam_cap = 0; b->seam_cap_bwd = 0; b->seam_bwd_off = 0; b->strip_on = false;
-    b->strip_one_pass = false; b->d_spec = nullptr; b->d_sortkey = nullptr;
+    b->strip_one_pass = false; b->d_spec = nullptr; b->d_sortkey = nullptr; b->d_sortidx = nullptr; b->spec_slack = STRIP_SPEC_SLACK;
     b->d_bscratch = nullptr; b->d_tab6 = nullptr; b->d_noise3 = nullptr; b->d_evn = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr;
     b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr; b->d_hdp_tab = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr;
     b->d_seg_off = nullptr; b->d_out = nullptr; b->d_ids = nullptr; b->d_gsum = nullptr; b->d_gmc = nullptr;
@@ -2046,11 +2121,14 @@ static int batch_finish_body(sa_batch *b) {
                 TRY(dalloc((void **) &b->d_ckxy, 16ll * (pl->n_vbuf > 0 ? pl->n_vbuf : 1)));
                 // the one-pass sweep (default; SA_STRIP_PASSES=2: the two-pass sweep of round 2): speculative totals per segment, sort keys
                 // per candidate slot.  Its 64-bit sort key holds 26 bits of diagonals below a traceback's start.
-                b->strip_one_pass = !(getenv("SA_STRIP_PASSES") && atoi(getenv("SA_STRIP_PASSES")) == 2) && strip_max_seg < (1ll << 26);
-                if (b->strip_one_pass) {
-                    TRY(dalloc((void **) &b->d_spec, 8ll * (pl->n_segs > 0 ? pl->n_segs : 1)));
-                    TRY(dalloc((void **) &b->d_sortkey, 8ll * (pl->n_cand > 0 ? pl->n_cand : 1)));
-                }
+                b->strip_one_pass = !(getenv("SA_STRIP_PASSES") && atoi(getenv("SA_STRIP_PASSES")) == 2);
+            }
+            if (pl->n_ring_regions > 0 && !host_finalize) {
+                // ring and (one-pass) strip kernels: candidates against the traceback's speculative total, survivors put in order by
+                // k_gather_sorted -- speculative totals per segment, sort keys per candidate slot
+                TRY(dalloc((void **) &b->d_spec, 8ll * (pl->n_segs > 0 ? pl->n_segs : 1)));
+                TRY(dalloc((void **) &b->d_sortkey, 8ll * (pl->n_cand > 0 ? pl->n_cand : 1)));
+                TRY(dalloc((void **) &b->d_sortidx, 4ll * (pl->n_cand > 0 ? pl->n_cand : 1)));
             }
             b->gev.resize(4 * b->groups.size(), nullptr);
             b->cev.resize(2 * b->chunks.size(), nullptr);
@@ -2074,7 +2152,8 @@ static int batch_finish_body(sa_batch *b) {
         void **ptrs[] = {(void **) &b->d_F, (void **) &b->d_E, (void **) &b->d_vbuf, (void **) &b->d_cands, (void **) &b->d_prob,
                          (void **) &b->d_cand_count, (void **) &b->d_seg_pass, (void **) &b->d_seg_off, (void **) &b->d_overflow,
                          (void **) &b->d_totals, (void **) &b->d_bscratch, (void **) &b->d_gsum, (void **) &b->d_gmc, (void **) &b->d_seam,
-                         (void **) &b->d_ckxy, (void **) &b->d_spec, (void **) &b->d_sortkey, (void **) &b->d_out};
+                         (void **) &b->d_ckxy, (void **) &b->d_spec, (void **) &b->d_sortkey, (void **) &b->d_sortidx,
+                         (void **) &b->d_out};
         for (void **q : ptrs)
             if (*q) { g_sa_pool.put(SaPool::DEVICE, *q); *q = nullptr; }
         if (b->h_seg_off) { g_sa_pool.put(SaPool::PINNED, b->h_seg_off); b->h_seg_off = nullptr; }
@@ -2181,7 +2260,7 @@ int sa_dplan_compare(const sa_model_t *m, const sa_params_t *p, const sa_job_t *
     b->d_tab6 = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr; b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr;
     b->d_hdp_tab = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr; b->d_seg_off = nullptr; b->d_out = nullptr;
     b->d_ids = nullptr; b->d_gsum = nullptr; b->d_gmc = nullptr; b->d_seam = nullptr; b->d_ckxy = nullptr;
-    b->d_spec = nullptr; b->d_sortkey = nullptr;
+    b->d_spec = nullptr; b->d_sortkey = nullptr; b->d_sortidx = nullptr;
     int rcd;
     {
         std::unique_lock<std::mutex> lk(g_uploader.mu);
@@ -2263,6 +2342,7 @@ static int submit_group(sa_batch *b, const DevPlan &P, int g, int which_stream, 
         ST.ev_total = pl->n_ev + 8; ST.seam_cap = b->seam_cap_bwd; ST.seam_stride = 32ull * b->seam_cap_bwd; ST.seam_first = G.seam_first;
         ST.ck_half = pl->n_vbuf;
         ST.spec = b->strip_one_pass ? b->d_spec : nullptr;
+        ST.slack = b->spec_slack;
         if (b->strip_one_pass) launch_bwd_strip1(P, b->d_ids + G.ids_ss, G.nss, st, b->d_seam + b->seam_bwd_off, ST);
         else launch_bwd_strip(P, b->d_ids + G.ids_ss, G.nss, st, b->d_seam + b->seam_bwd_off, b->d_ckxy, ST);
     }
@@ -2275,15 +2355,18 @@ static int submit_group(sa_batch *b, const DevPlan &P, int g, int which_stream, 
     if (finalize) {
         const int n = (int) (G.seg1 - G.seg0);
         long long *soff = b->d_seg_off + G.seg0 + g;
-        const double *spec = (b->strip_one_pass && G.nss > 0) ? b->d_spec : nullptr;   // (groups without strip segments: no look at it)
+        bool any_ring = false;
+        for (int cl = 0; cl < 16; cl++) any_ring = any_ring || G.nrs[cl] > 0;
+        // (groups without ring / one-pass strip segments: no look at the speculative totals)
+        const double *spec = (b->d_spec && (any_ring || (b->strip_one_pass && G.nss > 0))) ? b->d_spec : nullptr;
         hipLaunchKernelGGL(k_finalize, dim3((unsigned) n), dim3(64), 0, st, P, (int) G.seg0, n, b->d_prob, b->d_seg_pass, spec,
-                           (double) STRIP_SPEC_SLACK);
+                           b->spec_slack);
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, b->d_seg_pass + G.seg0, soff, b->h_seg_off + G.seg0 + g, n);
         hipLaunchKernelGGL(k_gather, dim3((unsigned) n), dim3(64), 0, st, P, (int) G.seg0, n, b->d_prob, soff,
-                           b->d_out + pl->segs[G.seg0].cand_off, spec);
-        if (spec)
-            hipLaunchKernelGGL(k_gather_strip, dim3((unsigned) n), dim3(64), 0, st, P, (int) G.seg0, n, b->d_prob, soff,
-                               b->d_out + pl->segs[G.seg0].cand_off, spec, b->d_sortkey);
+                           b->d_out + pl->segs[G.seg0].cand_off, spec, b->strip_on ? 1 : 0);
+        if (spec && G.nss > 0)
+            hipLaunchKernelGGL(k_gather_sorted, dim3((unsigned) n), dim3(64), 0, st, P, (int) G.seg0, n, b->d_prob, soff,
+                               b->d_out + pl->segs[G.seg0].cand_off, spec, b->d_sortkey, b->d_sortidx);
         HIPCHK(hipEventRecord(b->gev[4 * g + 2], st));
     } else {
         HIPCHK(hipEventRecord(b->gev[4 * g + 2], st));
@@ -2297,7 +2380,7 @@ static int enqueue_pass(sa_batch *b, bool finalize, AfterGroup after_group) {
     DevPlan P = make_devplan(b);
     hipStream_t s0 = b->cstream[0], s1 = b->cstream[1];
     HIPCHK(hipMemsetAsync(b->d_cand_count, 0, 4 * (size_t) (pl->n_segs > 0 ? pl->n_segs : 1), s0));
-    if (b->strip_one_pass)   // all bits set = NaN: "not a one-pass strip segment" until a forward strip wave says otherwise
+    if (b->d_spec)   // all bits set = NaN: "not a segment of the ring / strip kernels" until their forward sweep says otherwise
         HIPCHK(hipMemsetAsync(b->d_spec, 0xff, 8 * (size_t) (pl->n_segs > 0 ? pl->n_segs : 1), s0));
     b->h_overflow[0] = 0;  // pinned host word the kernels raise directly
     b->h_overflow[1] = 0;  // ... and the one k_finalize raises when a speculative candidate bound turns out too high
@@ -2338,6 +2421,7 @@ static int enqueue_pass(sa_batch *b, bool finalize, AfterGroup after_group) {
                 StripT ST;
                 ST.ev_total = pl->n_ev + 8; ST.seam_cap = b->seam_cap; ST.seam_stride = 32ull * b->seam_cap; ST.seam_first = 0;
                 ST.spec = b->strip_one_pass ? b->d_spec : nullptr;
+                ST.slack = b->spec_slack;
                 launch_fwd_strip(P, b->d_ids + C.ids_st, C.nst, lanes[0], b->d_seam, ST);
                 which = n_lanes > 1 ? 1 : 0;
             }
@@ -2353,6 +2437,13 @@ static int enqueue_pass(sa_batch *b, bool finalize, AfterGroup after_group) {
         }
         if (C.nfr && P.m.hdp) launch_emit_hdp(P, b->d_ids + C.ids_fr, C.nfr, pl->regions[b->ids_flat[(size_t) C.ids_fr]].N, s0);
         if (C.nfr) launch_fwd_fast(P, b->d_ids + C.ids_fr, C.nfr, s0, b->wide_cap);
+        if (b->d_spec && C.g1 > C.g0) {   // the candidate bounds of this pass's ring / strip tracebacks (k_spec_match)
+            bool any = C.nst > 0;
+            for (int cl = 0; cl < 16; cl++) any = any || C.nrr[cl] > 0;
+            const long long sa_ = b->groups[(size_t) C.g0].seg0, sb_ = b->groups[(size_t) C.g1 - 1].seg1;
+            if (any && sb_ > sa_)
+                hipLaunchKernelGGL(k_spec_match, dim3((unsigned) (sb_ - sa_)), dim3(64), 0, s0, P, (int) sa_, (int) (sb_ - sa_), b->d_spec);
+        }
         HIPCHK(hipEventRecord(b->cev[2 * c + 1], s0));
         if (C.g1 - C.g0 > 1) HIPCHK(hipStreamWaitEvent(s1, b->cev[2 * c + 1], 0));
         int submitted = C.g0, completed = C.g0;
@@ -2420,8 +2511,10 @@ static int grow_after_overflow(sa_batch *b) {
     }
     if (b->d_sortkey) {
         g_sa_pool.put(SaPool::DEVICE, b->d_sortkey);
-        b->d_sortkey = nullptr;
+        g_sa_pool.put(SaPool::DEVICE, b->d_sortidx);
+        b->d_sortkey = nullptr; b->d_sortidx = nullptr;
         HIPCHK(g_sa_pool.get(SaPool::DEVICE, (void **) &b->d_sortkey, 8 * (size_t) pl->n_cand, b->device));
+        HIPCHK(g_sa_pool.get(SaPool::DEVICE, (void **) &b->d_sortidx, 4 * (size_t) pl->n_cand, b->device));
     }
     HIPCHK(hipMemcpy(b->d_segs, pl->segs, sizeof(sa_seg_t) * (size_t) pl->n_segs, hipMemcpyHostToDevice));
     return SA_OK;
@@ -2545,12 +2638,38 @@ static int batch_run_body(sa_batch_t *b) {
         if (trace) fprintf(stderr, "[trace] copies drained at %.3f ms (piped %d)\n", now_ms() - t0, (int) piped);
         rc = collect_times(b);
         if (rc) return rc;
-        if (b->h_overflow[1] && b->strip_one_pass) {
-            // a traceback's exact totals fell below its speculative bound minus the slack (never seen; the reference's totals of one
-            // traceback agree to ~1e-3): its candidates may be incomplete -- the pass is repeated with the two-pass sweep
-            fprintf(stderr, "[signalalign_hip] strip kernels: a speculative candidate bound was too high; repeating the pass with the "
-                            "two-pass sweep\n");
-            b->strip_one_pass = false;
+        if (b->d_spec && getenv("SA_SPEC_DEBUG")) {
+            // diagnostic: how far the exact totals of a traceback lie from its speculative total (expected: ~1e-3)
+            std::vector<double> sp((size_t) n_segs), tt((size_t) (pl->n_cks > 0 ? pl->n_cks : 1));
+            HIPCHK(hipMemcpy(sp.data(), b->d_spec, 8 * (size_t) n_segs, hipMemcpyDeviceToHost));
+            if (pl->n_cks) HIPCHK(hipMemcpy(tt.data(), b->d_totals, 8 * (size_t) pl->n_cks, hipMemcpyDeviceToHost));
+            double worst_lo = 0, worst_hi = 0;
+            long long n_spec = 0, shown = 0;
+            for (long long sg = 0; sg < n_segs; sg++) {
+                if (!(sp[(size_t) sg] == sp[(size_t) sg]) || !(sp[(size_t) sg] > -INFINITY)) continue;
+                n_spec++;
+                const sa_seg_t *S = &pl->segs[sg];
+                for (int c = 0; c < S->n_ck; c++) {
+                    const double dlt = tt[(size_t) (S->ck_base + c)] - sp[(size_t) sg];
+                    if (dlt < worst_lo) worst_lo = dlt;
+                    if (dlt > worst_hi) worst_hi = dlt;
+                    if (dlt < -b->spec_slack && shown < 6) {
+                        shown++;
+                        fprintf(stderr, "[spec] segment %lld (region %d, start %lld from %lld to %lld at_end %d) checkpoint %d of %d: total %.6f spec %.6f\n",
+                                sg, S->region, (long long) S->start, (long long) S->from, (long long) S->to, S->at_end, c, S->n_ck,
+                                tt[(size_t) (S->ck_base + c)], sp[(size_t) sg]);
+                    }
+                }
+            }
+            fprintf(stderr, "[spec] %lld segments with a speculative total; exact total - speculative total in [%.3e, %.3e]; slack %.3g\n",
+                    n_spec, worst_lo, worst_hi, b->spec_slack);
+        }
+        if (b->h_overflow[1] && b->d_spec && b->spec_slack < 1e6) {
+            // a traceback's exact totals fell below its speculative total minus the slack (never seen; the reference's totals of one
+            // traceback agree to ~1e-3): its candidates may be incomplete -- the pass is repeated with a bound far lower (more
+            // candidates, same survivors)
+            b->spec_slack *= 4.0;
+            fprintf(stderr, "[signalalign_hip] a speculative candidate bound was too high; repeating the pass with slack %.0f\n", b->spec_slack);
             continue;
         }
         if (b->h_overflow[0]) {
