@@ -821,7 +821,7 @@ __global__ __launch_bounds__(64) void k_spec_match(DevPlan P, int seg0, int n_se
     const int seg = seg0 + blockIdx.x;
     const sa_seg_t *S = &P.segs[seg];
     const sa_region_t *R = &P.regions[S->region];
-    if (R->kind != SA_KIND_RING) return;
+    if (R->kind != SA_KIND_RING && R->kind != SA_KIND_FAST) return;
     const sa_row_t *rows = P.rows + R->row_off;
     const long long start = S->start;
     const long long o0 = rows[start].foff & 0xffffffffll, o1 = rows[start + 1].foff & 0xffffffffll;   // (g0 << 32 | offset; row N + 1 closes)
@@ -980,7 +980,7 @@ __global__ __launch_bounds__(64) void k_gather(DevPlan P, int seg0, int n_segs, 
         const double sp = spec[seg];
         if (sp == sp) {
             if (seg_is_strip(R, strip_on)) return;
-            unordered = true;
+            unordered = R->kind == SA_KIND_RING;   // (a register-kernel segment is one wave: its candidates are in order)
         }
     }
     const sa_cand_t *cd = P.cands + S->cand_off;
@@ -2123,10 +2123,11 @@ static int batch_finish_body(sa_batch *b) {
                 // per candidate slot.  Its 64-bit sort key holds 26 bits of diagonals below a traceback's start.
                 b->strip_one_pass = !(getenv("SA_STRIP_PASSES") && atoi(getenv("SA_STRIP_PASSES")) == 2);
             }
-            if (pl->n_ring_regions > 0 && !host_finalize) {
-                // ring and (one-pass) strip kernels: candidates against the traceback's speculative total, survivors put in order by
-                // k_gather_sorted -- speculative totals per segment, sort keys per candidate slot
+            if (pl->n_ring_regions + pl->n_fast_regions > 0 && !host_finalize) {
+                // register, ring and (one-pass) strip kernels: candidates against the traceback's speculative total (one per segment)
                 TRY(dalloc((void **) &b->d_spec, 8ll * (pl->n_segs > 0 ? pl->n_segs : 1)));
+            }
+            if (b->strip_one_pass && strip_fwd_slots > 0 && !host_finalize) {   // k_gather_sorted: sort keys per candidate slot
                 TRY(dalloc((void **) &b->d_sortkey, 8ll * (pl->n_cand > 0 ? pl->n_cand : 1)));
                 TRY(dalloc((void **) &b->d_sortidx, 4ll * (pl->n_cand > 0 ? pl->n_cand : 1)));
             }
@@ -2355,16 +2356,16 @@ static int submit_group(sa_batch *b, const DevPlan &P, int g, int which_stream, 
     if (finalize) {
         const int n = (int) (G.seg1 - G.seg0);
         long long *soff = b->d_seg_off + G.seg0 + g;
-        bool any_ring = false;
+        bool any_ring = G.nfs > 0;
         for (int cl = 0; cl < 16; cl++) any_ring = any_ring || G.nrs[cl] > 0;
-        // (groups without ring / one-pass strip segments: no look at the speculative totals)
+        // (groups without register / ring / one-pass strip segments: no look at the speculative totals)
         const double *spec = (b->d_spec && (any_ring || (b->strip_one_pass && G.nss > 0))) ? b->d_spec : nullptr;
         hipLaunchKernelGGL(k_finalize, dim3((unsigned) n), dim3(64), 0, st, P, (int) G.seg0, n, b->d_prob, b->d_seg_pass, spec,
                            b->spec_slack);
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, b->d_seg_pass + G.seg0, soff, b->h_seg_off + G.seg0 + g, n);
         hipLaunchKernelGGL(k_gather, dim3((unsigned) n), dim3(64), 0, st, P, (int) G.seg0, n, b->d_prob, soff,
-                           b->d_out + pl->segs[G.seg0].cand_off, spec, b->strip_on ? 1 : 0);
-        if (spec && G.nss > 0)
+                           b->d_out + pl->segs[G.seg0].cand_off, spec, (b->strip_on && b->strip_one_pass && b->d_sortkey) ? 1 : 0);
+        if (spec && G.nss > 0 && b->d_sortkey)
             hipLaunchKernelGGL(k_gather_sorted, dim3((unsigned) n), dim3(64), 0, st, P, (int) G.seg0, n, b->d_prob, soff,
                                b->d_out + pl->segs[G.seg0].cand_off, spec, b->d_sortkey, b->d_sortidx);
         HIPCHK(hipEventRecord(b->gev[4 * g + 2], st));
@@ -2438,7 +2439,7 @@ static int enqueue_pass(sa_batch *b, bool finalize, AfterGroup after_group) {
         if (C.nfr && P.m.hdp) launch_emit_hdp(P, b->d_ids + C.ids_fr, C.nfr, pl->regions[b->ids_flat[(size_t) C.ids_fr]].N, s0);
         if (C.nfr) launch_fwd_fast(P, b->d_ids + C.ids_fr, C.nfr, s0, b->wide_cap);
         if (b->d_spec && C.g1 > C.g0) {   // the candidate bounds of this pass's ring / strip tracebacks (k_spec_match)
-            bool any = C.nst > 0;
+            bool any = C.nst > 0 || C.nfr > 0;
             for (int cl = 0; cl < 16; cl++) any = any || C.nrr[cl] > 0;
             const long long sa_ = b->groups[(size_t) C.g0].seg0, sb_ = b->groups[(size_t) C.g1 - 1].seg1;
             if (any && sb_ > sa_)

@@ -756,6 +756,9 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
         S->region = (int32_t) pl->n_regions;
         S->at_end = at_end;
         S->start = d;
+        /* the diagonal a traceback starts on keeps all three forward planes: its total there -- forward state x end state --
+         * is the backward sweep's candidate bound (k_spec_match, sa_hip.hip) */
+        pl->pk[R->pk_off + SA_PK_PAD + d] |= SA_PK_FULL;
         S->from = d - (at_end ? 0 : p->trace_back_diagonals + 1);
         S->to = traced_to;
         if (S->from <= S->to) { /* would violate traceBackDiagonals+1 < minDiagsBetweenTraceBack */
