@@ -249,39 +249,45 @@ def bench_expectations(args, compact=False):
     counted as for the alignment (forward + backward cell updates)."""
     import signalalign_amd as sa
     from signalalign_amd import synth
-    alpha, k, t10, tab = synth.parse_model_table(MODEL)
-    pm = sa.Model.load(MODEL)
+    cpg = args.workload == "expectations_cpg"   # EM training of a methylation model: every CpG cytosine C/E (configs[2]'s reads)
+    model_path = os.path.join(ROOT, "tests", "golden", "models", "testModelR9.4_450bps.cpg.6mer.template.model") if cpg else MODEL
+    ambig = sa.default_ambig({"X": "CE"}) if cpg else None
+    alpha, k, t10, tab = synth.parse_model_table(model_path)
+    pm = sa.Model.load(model_path)
     params = sa.default_params(threshold=args.threshold, expansion=50, trace_back=100)
-    jobs = job_list = synth.make_reads_parallel(dict(kind="gauss", model=MODEL, events=args.events, kw={}), range(args.reads))
-    b = sa.Batch(pm, params, jobs)
+    jobs = job_list = synth.make_reads_parallel(dict(kind="gauss", model=model_path, events=args.events,
+                                                     kw={"cpg_ambiguous": True} if cpg else {}), range(args.reads))
+    b = sa.Batch(pm, params, jobs, ambig=ambig)
     st = b.stats()
     cells = st.cells_forward + st.cells_backward
     b.close()
     jobs = sa.JobArray(jobs)   # marshalled once: a C caller holds sa_job_t arrays anyway
     for _ in range(max(1, args.warmup)):
-        sa.expect_batch(pm, params, jobs)
+        sa.expect_batch(pm, params, jobs, ambig=ambig)
+    est = sa.expect_last_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        trans, lik, _ = sa.expect_batch(pm, params, jobs)
+        trans, lik, _ = sa.expect_batch(pm, params, jobs, ambig=ambig)
     dt = (time.perf_counter() - t0) / args.steps
     dtg = float("nan")
     if not compact:   # (the memory-resident checker kernels beside it)
         tg0 = time.perf_counter()
         for _ in range(max(1, args.steps // 4)):
-            sa.expect_batch(pm, params, jobs, flags=sa.FLAG_FORCE_GENERIC)
+            sa.expect_batch(pm, params, jobs, ambig=ambig, flags=sa.FLAG_FORCE_GENERIC)
         dtg = (time.perf_counter() - tg0) / max(1, args.steps // 4)
     res = {"metric": "dp_cell_updates_per_s", "value": cells / dt, "unit": "cell_updates/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "expectation pass (sa_expect_batch) over BASELINE configs[1]'s reads: %d synthetic %d-event reads, "
-                                  "band=50" % (args.reads, args.events),
+           "config": {"workload": "expectation pass (sa_expect_batch) over BASELINE configs[%d]'s reads: %d synthetic %d-event reads%s, "
+                                  "band=50" % (2 if cpg else 1, args.reads, args.events, ", every CpG cytosine C/E" if cpg else ""),
+                      "regions": {"register": int(est.n_fast_regions), "ring": int(est.n_ring_regions), "all": int(est.n_regions)},
                       "step": "one sa_expect_batch call: create (host planner) + forward (all three states stored) + backward with "
                               "fused transition expectations + fold + host rescale + destroy",
                       "memory_resident_kernels_ms_per_step": None if compact else dtg * 1e3,
                       "memory_resident_kernels_value": None if compact else cells / dtg,
                       "mean_match_to_match_expectation": float(trans[:, 0].mean()), "mean_log_likelihood": float(lik.mean())},
            # 48 B per cell update: the forward sweep writes and the backward sweep reads all three states of every cell
-           "roofline": {"bound": "issue", "bound_of_the_formula": "hbm", "kernel": "k_bwd_fast_expect", "achieved": None,
+           "roofline": {"bound": "issue", "bound_of_the_formula": "hbm", "kernel": "k_bwd_ring<EXPECT>" if cpg else "k_bwd_fast_expect", "achieved": None,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                         "note": "whole-call rate; the per-kernel split is in profiles/ (rocprofv3 --kernel-trace --stats)"}}
     if not args.no_cpu_baseline:
@@ -295,7 +301,8 @@ def bench_expectations(args, compact=False):
         def one(j):
             m_ = oracle.Model(alpha, k, t10, tab)
             m_.set_read_params(j["scale"], j["shift"], j["var"])
-            return oracle.expectations(m_, j["ref"], j["events"], j["ax"], j["ay"], om_p)[1]
+            return oracle.expectations(m_, j["ref"], j["events"], j["ax"], j["ay"], om_p,
+                                       **({"ambig": oracle.ambig_map({"X": "CE"})} if cpg else {}))[1]
         t1 = time.perf_counter()
         with ThreadPoolExecutor(cores) as ex:
             list(ex.map(one, sample))
@@ -307,8 +314,8 @@ def bench_expectations(args, compact=False):
     # average duration of k_bwd_fast_expect over `bench.py --workload expectations` under rocprofv3 --kernel-trace --stats;
     # sa_expect_batch keeps no stage events of its own)
     try:
-        kt = json.load(open(os.path.join(ROOT, "profiles", "kernel_times.json"))).get("expectations", {})
-        kms = kt.get("k_bwd_fast_expect", {}).get("ms_per_step")
+        kt = json.load(open(os.path.join(ROOT, "profiles", "kernel_times.json"))).get(args.workload, {})
+        kms = kt.get("k_bwd_ring_expect" if cpg else "k_bwd_fast_expect", {}).get("ms_per_step")
         if kms and args.reads == 2000 and args.events == 5000:
             # 48 B per backward cell update: the backward sweep reads all three forward states of every cell
             ach = 48.0 * st.cells_backward / (kms * 1e-3) / 1e9
@@ -849,7 +856,7 @@ def main():
                                                              "scaling: 12500 = configs[4]'s 100k reads / 8 GPUs)")
     ap.add_argument("--events", type=int, default=None, help="events per read (default 5000; scaling: 10000)")
     ap.add_argument("--workload", choices=["gaussian", "scaling", "cpg", "hdp", "hdp_cpg", "hdp_realistic", "realistic", "event_align",
-                                           "mea", "expectations"],
+                                           "mea", "expectations", "expectations_cpg"],
                     default="gaussian",
                     help="gaussian = BASELINE configs[1] (the headline); scaling = configs[4]'s per-GPU slice (12500 "
                          "10k-event reads per GPU, several forward-storage passes); cpg = configs[2] (ACEGT model, every "
@@ -918,7 +925,7 @@ def main():
     import signalalign_amd as sa
     from signalalign_amd import synth
 
-    if args.workload in ("mea", "event_align", "expectations"):
+    if args.workload in ("mea", "event_align", "expectations", "expectations_cpg"):
         # the two "next" rows are single-GPU side benchmarks: under a multi-rank launch only rank 0 runs them
         if world > 1:
             dist.barrier()
@@ -926,7 +933,7 @@ def main():
                 dist.destroy_process_group()
                 return
         res = (bench_mea(args) if args.workload == "mea" else
-               bench_expectations(args) if args.workload == "expectations" else bench_event_align(args))
+               bench_expectations(args) if args.workload.startswith("expectations") else bench_event_align(args))
         if world > 1:
             dist.destroy_process_group()
         return res

@@ -267,6 +267,10 @@ int sa_expect_batch(const sa_model_t *m, const sa_params_t *p, const sa_job_t *j
                     const char *const *ambig256, int device, unsigned flags, double *trans9_out,
                     double *likelihood_out, sa_assignment_t **assign_out, int64_t *n_assign_out);
 
+/* Test / measurement hook: the batch statistics (regions per kernel family, kernel times, passes) of the calling thread's last
+ * sa_expect_batch. */
+int sa_expect_last_stats(sa_batch_stats_t *out);
+
 /* ---- planning introspection (host only, no GPU needed; used by the CPU test-suite) --------------
  * Builds the plan for ONE job and reports its geometry. */
 typedef struct sa_plan_info {

@@ -79,7 +79,7 @@ PAIR_DTYPE = np.dtype([("prob_e7", "<i8"), ("x", "<i4"), ("y", "<i4"), ("path", 
 EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alphabet", "sa_model_table5",
            "sa_model_set_to_hdp_expected_values", "sa_model_set_emission", "sa_model_clone_with_table", "sa_kmer_id", "sa_default_ambig", "sa_load_ambig",
            "sa_batch_create", "sa_batch_create_deferred", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_pairs16", "sa_batch_pairs16_all", "sa_batch_pairs_all", "sa_batch_stats",
-           "sa_batch_job_cells", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_plan_describe", "sa_plan_digest",
+           "sa_batch_job_cells", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_expect_last_stats", "sa_plan_describe", "sa_plan_digest",
            "sa_plan_check_path_records", "sa_dplan_compare",
            "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_pool_configure", "sa_host_alloc", "sa_host_free", "sa_pair_roundtrip", "sa_fasta_subsequence", "sa_format_f6", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_device_memory", "sa_strerror",
            "sa_version", "sa_free"]
@@ -163,6 +163,7 @@ def lib():
     L.sa_estimate_params.argtypes = [C.c_void_p, dp, ip, dp, C.c_int64, C.c_char_p, C.c_int64, dp]
     L.sa_expect_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Job), C.c_int64, C.POINTER(C.c_char_p),
                                   C.c_int, C.c_uint, dp, dp, C.POINTER(C.c_void_p), ip]
+    L.sa_expect_last_stats.argtypes = [C.POINTER(BatchStats)]
     L.sa_scalings_mom.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, dp, C.c_int64, C.c_uint, dp, dp]
     L.sa_event_align_batch.argtypes = [C.c_void_p, C.POINTER(EaJob), C.c_int64, C.c_int, C.c_uint, C.POINTER(C.c_void_p), ip,
                                        C.POINTER(C.c_int32), dp, dp]
@@ -494,6 +495,13 @@ def expect_batch(model, params, jobs, ambig=None, device=0, flags=0, pseudocount
         assigns.append(a)
     del keep
     return trans[:n], lik[:n], assigns
+
+
+def expect_last_stats():
+    """sa_expect_last_stats: BatchStats of this thread's last expect_batch call."""
+    s = BatchStats()
+    _chk(lib().sa_expect_last_stats(C.byref(s)), "sa_expect_last_stats")
+    return s
 
 
 def plan_describe(model, params, job, ambig=None, flags=0):

@@ -84,6 +84,7 @@ struct DevPlan {
     double threshold;
     double *spec;     // ring / strip kernels: per traceback segment its speculative total (NaN: a segment of another kernel family)
     double spec_slack;
+    int expect;       // the expectation pass (sa_expect_batch)
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -1311,6 +1312,7 @@ static DevPlan make_devplan(const sa_batch *b) {
     P.log_thr = log(pl->params.threshold);
     P.spec = b->d_spec;
     P.spec_slack = b->spec_slack;
+    P.expect = b->expect ? 1 : 0;
     return P;
 }
 
@@ -2123,7 +2125,7 @@ static int batch_finish_body(sa_batch *b) {
                 // per candidate slot.  Its 64-bit sort key holds 26 bits of diagonals below a traceback's start.
                 b->strip_one_pass = !(getenv("SA_STRIP_PASSES") && atoi(getenv("SA_STRIP_PASSES")) == 2);
             }
-            if (pl->n_ring_regions + pl->n_fast_regions > 0 && !host_finalize) {
+            if ((pl->n_ring_regions + pl->n_fast_regions > 0 && !host_finalize) || (b->expect && pl->n_ring_regions > 0)) {
                 // register, ring and (one-pass) strip kernels: candidates against the traceback's speculative total (one per segment)
                 TRY(dalloc((void **) &b->d_spec, 8ll * (pl->n_segs > 0 ? pl->n_segs : 1)));
             }
@@ -2348,7 +2350,7 @@ static int submit_group(sa_batch *b, const DevPlan &P, int g, int which_stream, 
         else launch_bwd_strip(P, b->d_ids + G.ids_ss, G.nss, st, b->d_seam + b->seam_bwd_off, b->d_ckxy, ST);
     }
     for (int cl = 15; cl >= 0; cl--)   // widest (longest-running) classes first
-        if (G.nrs[cl]) launch_bwd_ring(P, b->d_ids + G.ids_rs[cl], G.nrs[cl], st, 64 * ((cl & 7) + 1), cl >= 8);
+        if (G.nrs[cl]) launch_bwd_ring(P, b->d_ids + G.ids_rs[cl], G.nrs[cl], st, 64 * ((cl & 7) + 1), cl >= 8, b->expect);
     if (G.nfs) launch_bwd_fast(P, b->d_ids + G.ids_fs, G.nfs, st, b->expect);
     HIPCHK(hipEventRecord(b->gev[4 * g + 1], st));
     if (G.ck1 > G.ck0)
@@ -2856,6 +2858,12 @@ int sa_align_batch(const sa_model_t *m, const sa_params_t *p, const sa_job_t *jo
 
 // getExpectationsUsingAnchors for a batch of reads.  The pass runs on the memory-resident kernels (every region is
 // planned SA_KIND_GENERIC); the per-group sums are rescaled here with the exact totals of the fold kernel.
+static thread_local sa_batch_stats_t tl_expect_stats;   // of this thread's last sa_expect_batch (sa_expect_last_stats)
+int sa_expect_last_stats(sa_batch_stats_t *out) {
+    if (!out) return SA_EINVAL;
+    *out = tl_expect_stats;
+    return SA_OK;
+}
 int sa_expect_batch(const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs, int64_t n_jobs,
                     const char *const *ambig, int device, unsigned flags, double *trans9_out, double *likelihood_out,
                     sa_assignment_t **assign_out, int64_t *n_assign_out) {
@@ -2869,6 +2877,7 @@ int sa_expect_batch(const sa_model_t *m, const sa_params_t *p, const sa_job_t *j
     rc = run_passes(b);
     if (rc) { sa_batch_destroy(b); return rc; }
     const sa_plan_t *pl = b->plan;
+    tl_expect_stats = b->stats;
     // The per-read sums are taken on the device (k_expect_reduce): 8 doubles per read come back.  HDP models also return the
     // assignment candidates (24 B x slots per posterior diagonal) with the totals they are tested against -- into ONE pinned
     // block (a copy to pageable memory moves 3 GB/s), tested on all host threads.

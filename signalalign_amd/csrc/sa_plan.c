@@ -715,7 +715,11 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
     /* (HDP models: both read the emission plane k_emit_hdp_ring fills, one value per cell-path; same table limit as above) */
     const int hdp_plane_ok = m->hdp == NULL ||
                              !(m->hdp->grid_length < 2 || m->hdp->n_slots * m->hdp->grid_length * 16 >= SA_HDP_FAST_MAX_BYTES);
-    int ring_ok = !(pl->flags & (SA_FLAG_EXACT | SA_FLAG_FORCE_GENERIC | SA_FLAG_EXPECT_INTERNAL)) && hdp_plane_ok &&
+    /* (the expectation pass: ring kernels for regions with several paths per cell under a Gaussian model -- k_bwd_ring<EXPECT> --,
+     * never for one-path regions, which keep the register kernels' expectation variant) */
+    const int expect_ = (pl->flags & SA_FLAG_EXPECT_INTERNAL) != 0;
+    int ring_ok = !(pl->flags & (SA_FLAG_EXACT | SA_FLAG_FORCE_GENERIC)) && hdp_plane_ok &&
+                  (!expect_ || (maxP > 1 && m->hdp == NULL)) &&
                   max_rowpaths <= SA_RING_MAX_ROWPATHS && foff + 1 <= SA_FAST_MAX_CELLS && ring_env_on() &&
                   (maxP == 1 || (maxP <= 255 && ambig_options_distinct(ambig)));
     int use_ring = 0;
@@ -1164,7 +1168,8 @@ int sa_plan_build(sa_plan_t **out, const sa_model_t *m, const sa_params_t *p, co
             pl->ev = get(sizeof(double) * (size_t) (te > 0 ? te : 1));
             int want_prec = 0;
             for (int t = 0; t < T; t++) want_prec |= W[t].pl->prec_cap != 0;
-            want_prec = want_prec && !(flags & (SA_FLAG_EXACT | SA_FLAG_FORCE_GENERIC | SA_FLAG_EXPECT_INTERNAL)) &&
+            want_prec = want_prec && !(flags & (SA_FLAG_EXACT | SA_FLAG_FORCE_GENERIC)) &&
+                        (!(flags & SA_FLAG_EXPECT_INTERNAL) || m->hdp == NULL) &&
                         (m->hdp == NULL ||   /* (HDP regions take the ring kernels too when the emission plane can be built) */
                          !(m->hdp->grid_length < 2 || m->hdp->n_slots * m->hdp->grid_length * 16 >= SA_HDP_FAST_MAX_BYTES)) &&
                         ring_env_on();

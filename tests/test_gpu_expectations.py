@@ -54,15 +54,44 @@ def test_expectations_add_to_pseudocounts(oracle):
 
 
 def test_expectations_ambiguous_cpg(oracle):
+    """Several paths per cell (EM training of a methylation model): round 4 runs these regions on the ring kernels' expectation
+    variant (k_bwd_ring<EXPECT>: forward states from the planes, legal predecessors from the per-path records) -- against the
+    oracle and against the memory-resident checker; dense and sparse anchors, short tracebacks, a three-way code."""
     pm, om = _models(oracle, cases.MODEL_CPG)
+    amb_p, amb_o = sa.default_ambig({"X": "CE"}), oracle.ambig_map({"X": "CE"})
+    jobs = cases.synthetic_jobs(cases.MODEL_CPG, 3, 1400, 20, cpg_ambiguous=True)
+    sparse = cases.realistic_anchor_jobs(cases.MODEL_CPG, 2, 1200, 77)
+    jobs += [dict(j, ref=j["ref"].replace("CG", "XG")) for j in sparse]
+    jobs += cases.synthetic_jobs(cases.MODEL_CPG, 1, 60, 5, cpg_ambiguous=True)
+    for kw in (dict(), dict(expansion=20, trace_back=30, min_diags=150)):
+        p = sa.default_params(**kw)
+        op = cases.oracle_params(oracle, p)
+        trans, lik, _ = sa.expect_batch(pm, p, jobs, ambig=amb_p)
+        st = sa.expect_last_stats()
+        assert st.n_ring_regions >= len(jobs) - 1, (st.n_regions, st.n_fast_regions, st.n_ring_regions)
+        chk, chk_lik, _ = sa.expect_batch(pm, p, jobs, ambig=amb_p, flags=sa.FLAG_FORCE_GENERIC)
+        assert sa.expect_last_stats().n_ring_regions == 0
+        for j, job in enumerate(jobs):
+            t, l, _, _, _ = _oracle_expect(oracle, om, job, op, ambig=amb_o)
+            np.testing.assert_allclose(trans[j], t, rtol=1e-9, atol=1e-10)
+            np.testing.assert_allclose(chk[j], t, rtol=1e-9, atol=1e-10)
+            assert abs(lik[j] - l) <= 1e-12 * abs(l) and abs(chk_lik[j] - l) <= 1e-12 * abs(l)
+    # the default table's three-way code on the R7.3 ACEGOT model
+    pm7, om7 = _models(oracle, cases.MODEL_R73)
     p = sa.default_params()
     op = cases.oracle_params(oracle, p)
-    jobs = cases.synthetic_jobs(cases.MODEL_CPG, 2, 600, 20, cpg_ambiguous=True)
-    trans, lik, _ = sa.expect_batch(pm, p, jobs, ambig=sa.default_ambig({"X": "CE"}))
-    for j, job in enumerate(jobs):
-        t, l, _, _, _ = _oracle_expect(oracle, om, job, op, ambig=oracle.ambig_map({"X": "CE"}))
-        np.testing.assert_allclose(trans[j], t, rtol=1e-9, atol=1e-12)
-        assert abs(lik[j] - l) <= 1e-12 * abs(l)
+    job = cases.synthetic_jobs(cases.MODEL_R73, 1, 700, 50)[0]
+    ref = list(job["ref"])
+    for i in range(9, len(ref) - 6, 23):
+        ref[i] = "L" if (i // 23) % 2 == 0 else "P"
+    for i in (200, 201, 202):
+        ref[i] = "L"
+    job = dict(job, ref="".join(ref))
+    trans, lik, _ = sa.expect_batch(pm7, p, [job])
+    assert sa.expect_last_stats().n_ring_regions == 1
+    t, l, _, _, _ = _oracle_expect(oracle, om7, job, op, ambig=oracle.ambig_map())
+    np.testing.assert_allclose(trans[0], t, rtol=1e-9, atol=1e-10)
+    assert abs(lik[0] - l) <= 1e-12 * abs(l)
 
 
 def test_hdp_assignments(oracle):
