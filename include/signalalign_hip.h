@@ -229,6 +229,11 @@ int sa_batch_run(sa_batch_t *b);
  * with repeated options, SA_FLAG_EXACT, ...) is created completely, as by sa_batch_create. */
 int sa_batch_create_deferred(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs,
                              int64_t n_jobs, const char *const *ambig256, int device, unsigned flags);
+/* Optional, between the two halves: waits for the plan and builds the launch lists -- the part of the second half that needs no
+ * working storage -- so that a caller whose batches take the device one at a time (SA_FLAG_DEVICE_TO_ITSELF) can have it done
+ * while the batch before is still running; the batch's first use then only takes its buffers.  Counts as a first use for the
+ * lifetime of `jobs` / `ambig256`; returns what that part of the second half returns (and the first use returns it again). */
+int sa_batch_prepare(sa_batch_t *b);
 /* The same on a thread of the library's own: sa_batch_start returns at once, sa_batch_wait returns sa_batch_run's code.
  * Lets one caller thread plan the next batch (sa_batch_create is host work) while this one is on the GPU. */
 int sa_batch_start(sa_batch_t *b);

@@ -78,7 +78,7 @@ PAIR_DTYPE = np.dtype([("prob_e7", "<i8"), ("x", "<i4"), ("y", "<i4"), ("path", 
 
 EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alphabet", "sa_model_table5",
            "sa_model_set_to_hdp_expected_values", "sa_model_set_emission", "sa_model_clone_with_table", "sa_kmer_id", "sa_default_ambig", "sa_load_ambig",
-           "sa_batch_create", "sa_batch_create_deferred", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_pairs16", "sa_batch_pairs16_all", "sa_batch_pairs_all", "sa_batch_stats",
+           "sa_batch_create", "sa_batch_create_deferred", "sa_batch_prepare", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_pairs16", "sa_batch_pairs16_all", "sa_batch_pairs_all", "sa_batch_stats",
            "sa_batch_job_cells", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_expect_last_stats", "sa_plan_describe", "sa_plan_digest",
            "sa_plan_check_path_records", "sa_dplan_compare",
            "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_pool_configure", "sa_host_alloc", "sa_host_free", "sa_pair_roundtrip", "sa_fasta_subsequence", "sa_format_f6", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_device_memory", "sa_strerror",
@@ -150,6 +150,7 @@ def lib():
     L.sa_batch_destroy.argtypes = [C.c_void_p]
     L.sa_fasta_subsequence.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
     L.sa_batch_start.argtypes = [C.c_void_p]
+    L.sa_batch_prepare.argtypes = [C.c_void_p]
     L.sa_batch_wait.argtypes = [C.c_void_p]
     L.sa_plan_describe.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Job), C.POINTER(C.c_char_p), C.c_uint,
                                    C.POINTER(PlanInfo), ip, C.c_int64, ip, C.c_int64, ip, C.c_int64]
@@ -372,6 +373,10 @@ class Batch:
 
     def run(self):
         _chk(lib().sa_batch_run(self._h), "sa_batch_run")
+
+    def prepare(self):
+        """sa_batch_prepare: a deferred batch's plan and launch lists now (while the batch before it runs)."""
+        _chk(lib().sa_batch_prepare(self._h), "sa_batch_prepare")
 
     def start(self):
         """sa_batch_start: run on a library thread; wait() joins it."""

@@ -1261,6 +1261,9 @@ struct sa_batch {
     bool c_deferred;
     char *held_stage;      // (deferred batches: see dplan_back)
     bool finished;
+    int prepare_rc;
+    bool prepared;           // plan collected and launch lists built (sa_batch_prepare, or the first step of finishing)
+    long long lw_strip_max_n, lw_strip_max_seg, lw_strip_fwd_slots, lw_strip_bwd_slots;   // from the launch lists: seam storage
     int finish_rc;
     std::mutex fin_mu;
 };
@@ -1686,6 +1689,7 @@ static int batch_create_impl(sa_batch_t **out, const sa_model_t *m, const sa_par
     b->d_ev = nullptr; b->d_segs = nullptr; b->d_cks = nullptr; b->d_F = nullptr; b->d_E = nullptr; b->d_vbuf = nullptr;
     b->d_cands = nullptr; b->d_cand_count = nullptr; b->d_overflow = nullptr; b->d_totals = nullptr;
     b->d_seam = nullptr; b->d_ckxy = nullptr; b->seam_cap = 0; b->seam_cap_bwd = 0; b->seam_bwd_off = 0; b->strip_on = false;
+    b->prepared = false; b->prepare_rc = SA_OK; b->lw_strip_max_n = b->lw_strip_max_seg = b->lw_strip_fwd_slots = b->lw_strip_bwd_slots = 0;
     b->strip_one_pass = false; b->d_spec = nullptr; b->d_sortkey = nullptr; b->d_sortidx = nullptr; b->spec_slack = STRIP_SPEC_SLACK;
     b->d_bscratch = nullptr; b->d_tab6 = nullptr; b->d_noise3 = nullptr; b->d_evn = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr;
     b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr; b->d_hdp_tab = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr;
@@ -1739,10 +1743,12 @@ int sa_batch_create_deferred(sa_batch_t **out, const sa_model_t *m, const sa_par
 // working buffers and the launch lists.  Runs once, on the batch's first use (run, statistics, accessors) or at the end of
 // sa_batch_create; a failure is remembered and returned to every later caller.
 static int batch_finish_body(sa_batch *b);
+static int batch_prepare_body(sa_batch *b);
 static int batch_finish(sa_batch *b) {
     std::lock_guard<std::mutex> g(b->fin_mu);
     if (!b->finished) {
-        b->finish_rc = batch_finish_body(b);
+        b->finish_rc = b->prepared ? b->prepare_rc : batch_prepare_body(b);
+        if (b->finish_rc == SA_OK) b->finish_rc = batch_finish_body(b);
         b->finished = true;
         if (b->finish_rc != SA_OK) {
             // Memsets, uploads and k_fill_xc of this batch may still be queued on the upload stream it used; sa_batch_destroy
@@ -1754,7 +1760,147 @@ static int batch_finish(sa_batch *b) {
     }
     return b->finish_rc;
 }
-static int batch_finish_body(sa_batch *b) {
+// Launch lists: regions per forward-storage pass, traceback segments per result group (needs the plan, no device memory)
+static int batch_build_lists(sa_batch *b) {
+    sa_plan_t *pl = b->plan;
+    const unsigned flags = b->flags;
+    const bool host_finalize = (flags & SA_FLAG_EXACT) || b->expect;
+    int want = 1;
+    const char *envg = getenv("SA_GROUPS");  // test hook
+    if (envg && atoi(envg) > 0) want = atoi(envg);
+    else if (!host_finalize) want = pl->n_chunks == 1 ? 8 : (pl->n_chunks < 4 ? 4 : 2);
+    // A caller that keeps batches in flight (sa_batch_start: another batch of this process is running while this one is
+    // created) already overlaps a batch's result copy with its neighbours' kernels; what it wants is few, large launches:
+    // 2000 x 5000-event reads, three in flight, step time with 1 / 2 / 3 / 8 groups: 13.9 / 13.1 / 12.9 / 14.9 ms.
+    if (!(envg && atoi(envg) > 0) && !host_finalize && g_batches_started.load() > 0 && !(flags & SA_FLAG_DEVICE_TO_ITSELF) && want > 3) want = 3;
+    b->ids_flat.clear(); b->chunks.clear(); b->groups.clear();
+    // One-path ring-kernel regions go to the strip kernels (sa_strip.inc): Gaussian emissions, default arithmetic,
+    // device-side finalisation, reference windows of fewer than 64 * STRIP_NS_MAX positions.  SA_STRIP=0: ring kernels.
+    b->strip_on = !host_finalize && !(getenv("SA_STRIP") && atoi(getenv("SA_STRIP")) == 0);   // (HDP regions too: they read the emission plane)
+    auto strip_region = [&](const sa_region_t &Rq) {
+        return b->strip_on && Rq.kind == SA_KIND_RING && Rq.max_p == 1 && Rq.lX < 64ll * STRIP_NS_MAX && Rq.N >= 1;
+    };
+    long long strip_max_n = 0, strip_max_seg = 0, strip_fwd_slots = 0, strip_bwd_slots = 0;
+    long long r = 0;
+    for (int c = 0; c < pl->n_chunks; c++) {
+        long long ra = r;
+        while (r < pl->n_regions && pl->regions[r].chunk == c) r++;
+        long long rb = r;
+        sa_launch_chunk C;
+        std::vector<int> gr, fr, sr_;
+        double work = 0;
+        std::vector<int> rr[16];
+        auto ring_class = [](const sa_region_t &Rq) {
+            const int cl = Rq.max_rowpaths <= 64 ? 0 : (int) ((Rq.max_rowpaths - 1) / 64);   // <= 7 (SA_RING_MAX_ROWPATHS)
+            return (Rq.max_p > 1 ? 8 : 0) + (cl > 7 ? 7 : cl);
+        };
+        for (long long q = ra; q < rb; q++) {
+            const sa_region_t &Rq = pl->regions[q];
+            if (strip_region(Rq)) { sr_.push_back((int) q); strip_max_n = Rq.N > strip_max_n ? Rq.N : strip_max_n; }
+            else if (Rq.kind == SA_KIND_RING) rr[ring_class(Rq)].push_back((int) q);
+            else if (Rq.kind != SA_KIND_FAST) gr.push_back((int) q);
+            else fr.push_back((int) q);
+            work += (double) Rq.N;
+        }
+        auto by_len_r = [&](int a, int d) { return pl->regions[a].N > pl->regions[d].N; };
+        // longest first inside each launch: the tail of a launch is then made of short waves
+        std::stable_sort(gr.begin(), gr.end(), by_len_r);
+        std::stable_sort(fr.begin(), fr.end(), by_len_r);
+        C.ids_gr = (long long) b->ids_flat.size(); C.ngr = (int) gr.size();
+        b->ids_flat.insert(b->ids_flat.end(), gr.begin(), gr.end());
+        C.ids_fr = (long long) b->ids_flat.size(); C.nfr = (int) fr.size();
+        b->ids_flat.insert(b->ids_flat.end(), fr.begin(), fr.end());
+        for (int cl = 0; cl < 16; cl++) {
+            std::stable_sort(rr[cl].begin(), rr[cl].end(), by_len_r);
+            C.ids_rr[cl] = (long long) b->ids_flat.size(); C.nrr[cl] = (int) rr[cl].size();
+            b->ids_flat.insert(b->ids_flat.end(), rr[cl].begin(), rr[cl].end());
+        }
+        std::stable_sort(sr_.begin(), sr_.end(), by_len_r);
+        C.ids_st = (long long) b->ids_flat.size(); C.nst = (int) sr_.size();
+        b->ids_flat.insert(b->ids_flat.end(), sr_.begin(), sr_.end());
+        strip_fwd_slots = (long long) sr_.size() > strip_fwd_slots ? (long long) sr_.size() : strip_fwd_slots;
+        long long chunk_bwd_slots = 0;
+        C.g0 = (int) b->groups.size();
+        // a group should still be a sizeable launch: at least 2048 segments each (measured optimum 6-8 groups
+        // for 18000 segments; 16 and more lose to launch gaps)
+        long long nseg_chunk = 0, nseg_wide = 0;
+        for (long long q = ra; q < rb; q++) {
+            nseg_chunk += pl->regions[q].n_seg;
+            if ((pl->regions[q].kind == SA_KIND_FAST && pl->regions[q].slots >= 2) ||
+                (pl->regions[q].kind == SA_KIND_RING && pl->regions[q].max_rowpaths > 64))
+                nseg_wide += pl->regions[q].n_seg;
+        }
+        // segments of wide-band regions live three to four times longer than those of dense anchors (4 ms against
+        // 1.2 ms), and so do the tails of their launches: fewer, larger groups.  2000 reads with realistic anchors,
+        // 17 300 segments, step time with 1 / 2 / 3 / 4 / 6 / 8 groups: 70.2 / 67.8 / 69.3 / 73.1 / 80.2 / 87 ms
+        // (strip-kernel segments: 1 / 2 / 3 / 4 groups give 39.5 / 38.3 / 37.5 / 42.9 ms per step of fresh reads)
+        const long long min_per_group = (2 * nseg_wide > nseg_chunk) ? (b->strip_on ? 5500 : 8192) : 2048;
+        int ng = want;
+        if (!(envg && atoi(envg) > 0))
+            while (ng > 1 && nseg_chunk / ng < min_per_group) ng--;
+        long long q = ra;
+        double acc = 0;
+        for (int g = 0; g < ng && q < rb; g++) {
+            long long qa = q;
+            double target = work * (double) (g + 1) / (double) ng;
+            while (q < rb && (g == ng - 1 || acc < target)) { acc += (double) pl->regions[q].N; q++; }
+            if (q == qa) continue;
+            // a read's regions stay in one group so that its pairs are contiguous in the output
+            while (q < rb && pl->regions[q].job == pl->regions[q - 1].job) { acc += (double) pl->regions[q].N; q++; }
+            sa_launch_group G;
+            G.seg0 = G.seg1 = G.ck0 = G.ck1 = 0;
+            std::vector<int> gs, fs, rs[16], ss;
+            bool any = false;
+            for (long long t = qa; t < q; t++) {
+                const sa_region_t *R = &pl->regions[t];
+                for (long long sg = R->seg_off; sg < R->seg_off + R->n_seg; sg++) {
+                    if (strip_region(*R)) {
+                        ss.push_back((int) sg);
+                        const long long span = pl->segs[sg].start - pl->segs[sg].to;
+                        strip_max_seg = span > strip_max_seg ? span : strip_max_seg;
+                    }
+                    else if (R->kind == SA_KIND_RING) rs[ring_class(*R)].push_back((int) sg);
+                    else (R->kind != SA_KIND_FAST ? gs : fs).push_back((int) sg);
+                    const sa_seg_t *S = &pl->segs[sg];
+                    if (!any) { G.seg0 = sg; G.ck0 = S->ck_base; any = true; }
+                    G.seg1 = sg + 1;
+                    G.ck1 = S->ck_base + S->n_ck;
+                }
+            }
+            if (!any) continue;
+            auto by_len_s = [&](int a, int d) {
+                return pl->segs[a].start - pl->segs[a].to > pl->segs[d].start - pl->segs[d].to;
+            };
+            std::stable_sort(gs.begin(), gs.end(), by_len_s);
+            std::stable_sort(fs.begin(), fs.end(), by_len_s);
+            G.ids_gs = (long long) b->ids_flat.size(); G.ngs = (int) gs.size();
+            b->ids_flat.insert(b->ids_flat.end(), gs.begin(), gs.end());
+            G.ids_fs = (long long) b->ids_flat.size(); G.nfs = (int) fs.size();
+            b->ids_flat.insert(b->ids_flat.end(), fs.begin(), fs.end());
+            for (int cl = 0; cl < 16; cl++) {
+                std::stable_sort(rs[cl].begin(), rs[cl].end(), by_len_s);
+                G.ids_rs[cl] = (long long) b->ids_flat.size(); G.nrs[cl] = (int) rs[cl].size();
+                b->ids_flat.insert(b->ids_flat.end(), rs[cl].begin(), rs[cl].end());
+            }
+            std::stable_sort(ss.begin(), ss.end(), by_len_s);
+            G.ids_ss = (long long) b->ids_flat.size(); G.nss = (int) ss.size();
+            b->ids_flat.insert(b->ids_flat.end(), ss.begin(), ss.end());
+            G.seam_first = (unsigned) chunk_bwd_slots;   // (rebased behind the forward slots below)
+            chunk_bwd_slots += (long long) ss.size();
+            b->groups.push_back(G);
+        }
+        strip_bwd_slots = chunk_bwd_slots > strip_bwd_slots ? chunk_bwd_slots : strip_bwd_slots;
+        C.g1 = (int) b->groups.size();
+        b->chunks.push_back(C);
+    }
+    b->lw_strip_max_n = strip_max_n; b->lw_strip_max_seg = strip_max_seg;
+    b->lw_strip_fwd_slots = strip_fwd_slots; b->lw_strip_bwd_slots = strip_bwd_slots;
+    return SA_OK;
+}
+
+// First step of finishing a batch, everything that needs no working storage: the plan (from the device planner, or built on the host)
+// and the launch lists.  sa_batch_prepare runs it ahead of time for a deferred batch, while the batch before it is on the device.
+static int batch_prepare_body(sa_batch *b) {
     const sa_model_t *m = b->c_m;
     const sa_params_t *p = &b->c_p;
     const sa_job_t *jobs = b->c_jobs;
@@ -1820,6 +1966,28 @@ static int batch_finish_body(sa_batch *b) {
         if (lim > 900) lim = 900;                   // 64 KB of dynamic LDS
         b->ring_cap = (int) (cap < lim ? cap : lim);
     }
+    TRY(batch_build_lists(b));
+    if (trace_c) fprintf(stderr, "[trace] create: launch lists at %.1f ms\n", now_ms_c() - tc0);
+    return SA_OK;
+#undef TRY
+}
+
+static int batch_finish_body(sa_batch *b) {
+    const sa_model_t *m = b->c_m;
+    const sa_params_t *p = &b->c_p;
+    const sa_job_t *jobs = b->c_jobs;
+    const int64_t n_jobs = b->c_n;
+    const unsigned flags = b->flags;
+    const int device = b->device;
+    const bool trace_c = getenv("SA_TRACE") != nullptr;
+    auto now_ms_c = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double tc0 = b->c_t0;
+    (void) p;
+    HIPCHK(hipSetDevice(device));
+    SaUploader *const UPT = b->c_deferred ? &g_uploader_tail : &g_uploader;
+    struct UseTail { SaUploader *prev; UseTail(SaUploader *u) : prev(tl_uploader) { tl_uploader = u; } ~UseTail() { tl_uploader = prev; } } use_tail_(UPT);
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+    sa_plan_t *pl = b->plan;
     std::unique_lock<std::mutex> up_lock((*UPT).mu);
     TRY((*UPT).bind(device));
     if (trace_c) fprintf(stderr, "[trace] create: upload ring ready at %.1f ms\n", now_ms_c() - tc0);
@@ -1980,137 +2148,11 @@ static int batch_finish_body(sa_batch *b) {
             TRY(dalloc((void **) &b->d_gsum, 64 * pl->n_cks));
             TRY(dalloc((void **) &b->d_gmc, 8 * pl->n_cks));
         }
-        // launch lists: regions per chunk, traceback segments per group
+        // launch lists (batch_build_lists: with the plan): seam storage, speculative totals, sort keys, events
         {
             const bool host_finalize = (flags & SA_FLAG_EXACT) || b->expect;
-            int want = 1;
-            const char *envg = getenv("SA_GROUPS");  // test hook
-            if (envg && atoi(envg) > 0) want = atoi(envg);
-            else if (!host_finalize) want = pl->n_chunks == 1 ? 8 : (pl->n_chunks < 4 ? 4 : 2);
-            // A caller that keeps batches in flight (sa_batch_start: another batch of this process is running while this one is
-            // created) already overlaps a batch's result copy with its neighbours' kernels; what it wants is few, large launches:
-            // 2000 x 5000-event reads, three in flight, step time with 1 / 2 / 3 / 8 groups: 13.9 / 13.1 / 12.9 / 14.9 ms.
-            if (!(envg && atoi(envg) > 0) && !host_finalize && g_batches_started.load() > 0 && want > 3) want = 3;
-            b->ids_flat.clear();
-            // One-path ring-kernel regions go to the strip kernels (sa_strip.inc): Gaussian emissions, default arithmetic,
-            // device-side finalisation, reference windows of fewer than 64 * STRIP_NS_MAX positions.  SA_STRIP=0: ring kernels.
-            b->strip_on = !host_finalize && !(getenv("SA_STRIP") && atoi(getenv("SA_STRIP")) == 0);   // (HDP regions too: they read the emission plane)
-            auto strip_region = [&](const sa_region_t &Rq) {
-                return b->strip_on && Rq.kind == SA_KIND_RING && Rq.max_p == 1 && Rq.lX < 64ll * STRIP_NS_MAX && Rq.N >= 1;
-            };
-            long long strip_max_n = 0, strip_max_seg = 0, strip_fwd_slots = 0, strip_bwd_slots = 0;
-            long long r = 0;
-            for (int c = 0; c < pl->n_chunks; c++) {
-                long long ra = r;
-                while (r < pl->n_regions && pl->regions[r].chunk == c) r++;
-                long long rb = r;
-                sa_launch_chunk C;
-                std::vector<int> gr, fr, sr_;
-                double work = 0;
-                std::vector<int> rr[16];
-                auto ring_class = [](const sa_region_t &Rq) {
-                    const int cl = Rq.max_rowpaths <= 64 ? 0 : (int) ((Rq.max_rowpaths - 1) / 64);   // <= 7 (SA_RING_MAX_ROWPATHS)
-                    return (Rq.max_p > 1 ? 8 : 0) + (cl > 7 ? 7 : cl);
-                };
-                for (long long q = ra; q < rb; q++) {
-                    const sa_region_t &Rq = pl->regions[q];
-                    if (strip_region(Rq)) { sr_.push_back((int) q); strip_max_n = Rq.N > strip_max_n ? Rq.N : strip_max_n; }
-                    else if (Rq.kind == SA_KIND_RING) rr[ring_class(Rq)].push_back((int) q);
-                    else if (Rq.kind != SA_KIND_FAST) gr.push_back((int) q);
-                    else fr.push_back((int) q);
-                    work += (double) Rq.N;
-                }
-                auto by_len_r = [&](int a, int d) { return pl->regions[a].N > pl->regions[d].N; };
-                // longest first inside each launch: the tail of a launch is then made of short waves
-                std::stable_sort(gr.begin(), gr.end(), by_len_r);
-                std::stable_sort(fr.begin(), fr.end(), by_len_r);
-                C.ids_gr = (long long) b->ids_flat.size(); C.ngr = (int) gr.size();
-                b->ids_flat.insert(b->ids_flat.end(), gr.begin(), gr.end());
-                C.ids_fr = (long long) b->ids_flat.size(); C.nfr = (int) fr.size();
-                b->ids_flat.insert(b->ids_flat.end(), fr.begin(), fr.end());
-                for (int cl = 0; cl < 16; cl++) {
-                    std::stable_sort(rr[cl].begin(), rr[cl].end(), by_len_r);
-                    C.ids_rr[cl] = (long long) b->ids_flat.size(); C.nrr[cl] = (int) rr[cl].size();
-                    b->ids_flat.insert(b->ids_flat.end(), rr[cl].begin(), rr[cl].end());
-                }
-                std::stable_sort(sr_.begin(), sr_.end(), by_len_r);
-                C.ids_st = (long long) b->ids_flat.size(); C.nst = (int) sr_.size();
-                b->ids_flat.insert(b->ids_flat.end(), sr_.begin(), sr_.end());
-                strip_fwd_slots = (long long) sr_.size() > strip_fwd_slots ? (long long) sr_.size() : strip_fwd_slots;
-                long long chunk_bwd_slots = 0;
-                C.g0 = (int) b->groups.size();
-                // a group should still be a sizeable launch: at least 2048 segments each (measured optimum 6-8 groups
-                // for 18000 segments; 16 and more lose to launch gaps)
-                long long nseg_chunk = 0, nseg_wide = 0;
-                for (long long q = ra; q < rb; q++) {
-                    nseg_chunk += pl->regions[q].n_seg;
-                    if ((pl->regions[q].kind == SA_KIND_FAST && pl->regions[q].slots >= 2) ||
-                        (pl->regions[q].kind == SA_KIND_RING && pl->regions[q].max_rowpaths > 64))
-                        nseg_wide += pl->regions[q].n_seg;
-                }
-                // segments of wide-band regions live three to four times longer than those of dense anchors (4 ms against
-                // 1.2 ms), and so do the tails of their launches: fewer, larger groups.  2000 reads with realistic anchors,
-                // 17 300 segments, step time with 1 / 2 / 3 / 4 / 6 / 8 groups: 70.2 / 67.8 / 69.3 / 73.1 / 80.2 / 87 ms
-                // (strip-kernel segments: 1 / 2 / 3 / 4 groups give 39.5 / 38.3 / 37.5 / 42.9 ms per step of fresh reads)
-                const long long min_per_group = (2 * nseg_wide > nseg_chunk) ? (b->strip_on ? 5500 : 8192) : 2048;
-                int ng = want;
-                if (!(envg && atoi(envg) > 0))
-                    while (ng > 1 && nseg_chunk / ng < min_per_group) ng--;
-                long long q = ra;
-                double acc = 0;
-                for (int g = 0; g < ng && q < rb; g++) {
-                    long long qa = q;
-                    double target = work * (double) (g + 1) / (double) ng;
-                    while (q < rb && (g == ng - 1 || acc < target)) { acc += (double) pl->regions[q].N; q++; }
-                    if (q == qa) continue;
-                    // a read's regions stay in one group so that its pairs are contiguous in the output
-                    while (q < rb && pl->regions[q].job == pl->regions[q - 1].job) { acc += (double) pl->regions[q].N; q++; }
-                    sa_launch_group G;
-                    G.seg0 = G.seg1 = G.ck0 = G.ck1 = 0;
-                    std::vector<int> gs, fs, rs[16], ss;
-                    bool any = false;
-                    for (long long t = qa; t < q; t++) {
-                        const sa_region_t *R = &pl->regions[t];
-                        for (long long sg = R->seg_off; sg < R->seg_off + R->n_seg; sg++) {
-                            if (strip_region(*R)) {
-                                ss.push_back((int) sg);
-                                const long long span = pl->segs[sg].start - pl->segs[sg].to;
-                                strip_max_seg = span > strip_max_seg ? span : strip_max_seg;
-                            }
-                            else if (R->kind == SA_KIND_RING) rs[ring_class(*R)].push_back((int) sg);
-                            else (R->kind != SA_KIND_FAST ? gs : fs).push_back((int) sg);
-                            const sa_seg_t *S = &pl->segs[sg];
-                            if (!any) { G.seg0 = sg; G.ck0 = S->ck_base; any = true; }
-                            G.seg1 = sg + 1;
-                            G.ck1 = S->ck_base + S->n_ck;
-                        }
-                    }
-                    if (!any) continue;
-                    auto by_len_s = [&](int a, int d) {
-                        return pl->segs[a].start - pl->segs[a].to > pl->segs[d].start - pl->segs[d].to;
-                    };
-                    std::stable_sort(gs.begin(), gs.end(), by_len_s);
-                    std::stable_sort(fs.begin(), fs.end(), by_len_s);
-                    G.ids_gs = (long long) b->ids_flat.size(); G.ngs = (int) gs.size();
-                    b->ids_flat.insert(b->ids_flat.end(), gs.begin(), gs.end());
-                    G.ids_fs = (long long) b->ids_flat.size(); G.nfs = (int) fs.size();
-                    b->ids_flat.insert(b->ids_flat.end(), fs.begin(), fs.end());
-                    for (int cl = 0; cl < 16; cl++) {
-                        std::stable_sort(rs[cl].begin(), rs[cl].end(), by_len_s);
-                        G.ids_rs[cl] = (long long) b->ids_flat.size(); G.nrs[cl] = (int) rs[cl].size();
-                        b->ids_flat.insert(b->ids_flat.end(), rs[cl].begin(), rs[cl].end());
-                    }
-                    std::stable_sort(ss.begin(), ss.end(), by_len_s);
-                    G.ids_ss = (long long) b->ids_flat.size(); G.nss = (int) ss.size();
-                    b->ids_flat.insert(b->ids_flat.end(), ss.begin(), ss.end());
-                    G.seam_first = (unsigned) chunk_bwd_slots;   // (rebased behind the forward slots below)
-                    chunk_bwd_slots += (long long) ss.size();
-                    b->groups.push_back(G);
-                }
-                strip_bwd_slots = chunk_bwd_slots > strip_bwd_slots ? chunk_bwd_slots : strip_bwd_slots;
-                C.g1 = (int) b->groups.size();
-                b->chunks.push_back(C);
-            }
+            const long long strip_max_n = b->lw_strip_max_n, strip_max_seg = b->lw_strip_max_seg;
+            const long long strip_fwd_slots = b->lw_strip_fwd_slots, strip_bwd_slots = b->lw_strip_bwd_slots;
             if (strip_fwd_slots + strip_bwd_slots > 0) {
                 // seam storage: per wave two arrays of (diagonals of the longest strip-kernel region / traceback segment + lead-in
                 // + sentinels) records; the groups of a pass run side by side, every segment has its own slot behind the forward
@@ -2163,7 +2205,7 @@ static int batch_finish_body(sa_batch *b) {
         if (b->h_overflow) { g_sa_pool.put(SaPool::PINNED, b->h_overflow); b->h_overflow = nullptr; }
         for (hipEvent_t e : b->gev) if (e) g_handles.park(e, device);
         for (hipEvent_t e : b->cev) if (e) g_handles.park(e, device);
-        b->gev.clear(); b->cev.clear(); b->chunks.clear(); b->groups.clear(); b->ids_flat.clear();
+        b->gev.clear(); b->cev.clear();
         b->seam_cap = 0; b->seam_cap_bwd = 0; b->seam_bwd_off = 0; b->strip_one_pass = false;
     };
     {
@@ -2184,6 +2226,7 @@ static int batch_finish_body(sa_batch *b) {
             if (by_free > 0 && by_free < budget2) budget2 = by_free;
             if (budget2 < largest) budget2 = largest;
             sa_plan_repack(pl, budget2);
+            TRY(batch_build_lists(b));   // (the passes changed)
             if (trace_c || !test_min_passes)
                 fprintf(stderr, "[signalalign_hip] working storage did not fit: forward storage re-packed into %d passes of at most %.1f GB\n",
                         (int) pl->n_chunks, (m->hdp ? 32.0 : 24.0) * (double) pl->max_chunk_cellpaths / 1e9);
@@ -2757,6 +2800,15 @@ int sa_batch_device_view(sa_batch_t *b, const sa_pair16_t **pairs, std::vector<l
 
 // sa_batch_run on a thread of the library's own, so that the caller can plan the next batch (sa_batch_create is host
 // work) while this one is on the GPU; sa_batch_wait joins it and returns sa_batch_run's code.
+int sa_batch_prepare(sa_batch_t *b) {
+    if (!b) return SA_EINVAL;
+    std::lock_guard<std::mutex> g(b->fin_mu);
+    if (!b->finished && !b->prepared) {
+        b->prepare_rc = batch_prepare_body(b);
+        b->prepared = true;
+    }
+    return b->prepare_rc;
+}
 int sa_batch_start(sa_batch_t *b) {
     if (!b) return SA_EINVAL;
     if (b->runner) return SA_ESTATE;

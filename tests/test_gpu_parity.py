@@ -240,6 +240,8 @@ def test_deferred_creation_same_bytes(oracle):
     a = sa.Batch(pm, p, jobs, deferred=True, flags=sa.FLAG_DEVICE_TO_ITSELF)
     a.start()
     b = sa.Batch(pm, p, more, deferred=True, flags=sa.FLAG_DEVICE_TO_ITSELF)     # first half while `a` runs
+    b.prepare()                                       # sa_batch_prepare: plan and launch lists too, before `a` has finished
+    b.prepare()                                       # (once; the second call returns the same code)
     a.wait()
     sta = a.stats()
     assert (sta.cells_forward, sta.cells_backward, sta.n_regions, sta.n_strip_regions) == \
@@ -253,6 +255,9 @@ def test_deferred_creation_same_bytes(oracle):
         assert np.array_equal(b.pairs(j), got2[j]), j
     b.close()
     sa.Batch(pm, p, jobs, deferred=True).close()      # created, never used
+    c = sa.Batch(pm, p, jobs, deferred=True)
+    c.prepare()
+    c.close()                                         # prepared, never used
     e = sa.Batch(pm, p, more, deferred=True, flags=sa.FLAG_EXACT)   # not a batch for the planning kernels: complete at once
     e.run()
     exact, _ = _run(pm, p, more, flags=sa.FLAG_EXACT)
@@ -264,7 +269,13 @@ def test_deferred_creation_same_bytes(oracle):
     for deferred in (False, True):
         try:
             c = sa.Batch(pm, p, [more[0], bad], deferred=deferred)
-            c.run()
+            if deferred:
+                try:
+                    c.prepare()                       # the error arrives here already ...
+                    raise AssertionError("sa_batch_prepare accepted a read no planner takes")
+                except sa.SaError:
+                    pass
+            c.run()                                   # ... and again on the first use
             raised = None
         except sa.SaError as err:
             raised = err.code
