@@ -315,7 +315,7 @@ def bench_expectations(args, compact=False):
     # sa_expect_batch keeps no stage events of its own)
     try:
         kt = json.load(open(os.path.join(ROOT, "profiles", "kernel_times.json"))).get(args.workload, {})
-        kms = kt.get("k_bwd_ring_expect" if cpg else "k_bwd_fast_expect", {}).get("ms_per_step")
+        kms = kt.get("k_bwd_ring" if cpg else "k_bwd_fast_expect", {}).get("ms_per_step")
         if kms and args.reads == 2000 and args.events == 5000:
             # 48 B per backward cell update: the backward sweep reads all three forward states of every cell
             ach = 48.0 * st.cells_backward / (kms * 1e-3) / 1e9
@@ -704,6 +704,8 @@ def measure(args, ctx, compact=False):
         rf_f, rf_b = (single["ms_forward"], single["ms_backward"]) if single else (ms_f, ms_b)
         if ms_b >= ms_f:
             dom, dom_ms, dom_cells = "k_bwd_" + fam + sfx, rf_b, st0.cells_backward
+            if fam == "strip" and os.environ.get("SA_STRIP_PASSES") != "2":
+                dom = "k_bwd_strip1"   # the one-pass sweep (round 4; SA_STRIP_PASSES=2: k_bwd_strip)
             dom_parts = [dom]
         else:
             dom, dom_ms, dom_cells = "k_fwd_" + fam + sfx, rf_f, st0.cells_forward
@@ -807,6 +809,7 @@ def measure(args, ctx, compact=False):
             "roofline": {"bound": "issue" if issue and issue["frac"] > (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else 0.0)
                          else "hbm", "bound_of_the_formula": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_over_algorithmic": (traffic / (ALGO_BYTES_PER_CELL * dom_cells)) if traffic else None,
                          "frac_by_counters": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "limiter": "instruction issue (VALU + SALU of the serial per-diagonal chain), not HBM: see "
                                     "profiles/ and DESIGN.md section 4",

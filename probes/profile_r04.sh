@@ -18,8 +18,8 @@ cd "$GRAFT_REPO_ROOT"
 export SA_GROUPS=1 SA_SYNTH_CACHE=/tmp/sa_reads
 O=gpurun_out/prof_${T}_$W
 rm -rf $O && mkdir -p $O
-if [ "$W" = expectations ]; then
-  CMD="bench.py --workload expectations --steps 5 --warmup 1 --no-cpu-baseline $EXTRA"; PASSES=6
+if [ "$W" = expectations ] || [ "$W" = expectations_cpg ]; then
+  CMD="bench.py --workload $W --steps 5 --warmup 1 --no-cpu-baseline $EXTRA"; PASSES=6
 else
   CMD="bench.py --workload $W --kernels-only --no-secondary --steps 3 --warmup 1 --no-cpu-baseline $EXTRA"; PASSES=4
 fi
