@@ -435,6 +435,54 @@ int64_t sa_remap_anchors(const int64_t *ax, const int64_t *ay, int64_t n, const 
 int sa_estimate_params(const sa_model_t *m, double *table5_inout, const int64_t *strand_event_map, double *events4,
                        int64_t n_events, const char *strand_read, int64_t read_len, double *out7);
 
+/* ---- HDP rebuild, the deterministic pieces --------------------------------------------------------
+ * The state of a serialised NanoporeHDP as the reference's Gibbs sampler leaves it, and what is computed FROM a state without
+ * random numbers.  The sampling sweep itself (sample_dp_factors / gibbs_factor_iteration, impl/hdp.c:2110-2260, rand()-driven)
+ * is not part of this library.
+ *   sa_hdp_state_load / _write   deserialize_nhdp + deserialize_hdp / serialize_nhdp + serialize_hdp
+ *                                (impl/nanopore_hdp.c:1077-1115, impl/hdp.c:2868-3322): host code; a file the reference wrote
+ *                                goes through load + write byte for byte
+ *   sa_hdp_state_distr_sample    take_distr_sample (impl/hdp.c:2067-2092): what ONE sample of the state adds to every observed
+ *                                DP's collector -- the posterior predictive of every base factor on the sampling grid
+ *                                (evaluate_posterior_predictive :530-562), the prior's (evaluate_prior_predictive :564-585),
+ *                                mixed with the weights of cache_base_factor_weight / cache_prior_contribution (:2001-2044).
+ *                                Grid evaluation and mixing run on the GPU (observed DPs x grid points x factors).
+ *   sa_hdp_finalize_distributions  finalize_distributions (impl/hdp.c:2551-2584): collector / samples, then the slopes of the
+ *                                natural cubic spline through it (spline_knot_slopes, impl/hdp_math_utils.c:402-442), one DP
+ *                                per GPU thread, the reference's elimination order (bit-identical slopes for the densities of a
+ *                                file the reference wrote).
+ * Errors: SA_EIO (unreadable / malformed file), SA_ESTATE (a state without data has no factors), SA_ENODEVICE, SA_ENOMEM. */
+typedef struct sa_hdp_state sa_hdp_state_t;
+typedef struct sa_hdp_state_info {
+    int64_t num_dps, depth, grid_length, n_data, n_factors, n_base_factors, n_observed, base_dp, alphabet_size, kmer_length;
+    double mu, nu, alpha, beta, grid_start, grid_stop;
+    int splines_finalized, has_data, sample_gamma;
+    /* views into the state (valid until sa_hdp_state_free) */
+    const double *data;                 /* n_data                                                        */
+    const int64_t *data_dp;             /* n_data: the leaf DP of every data point                       */
+    const double *gamma;                /* depth: concentration by depth of the DP                       */
+    const double *grid;                 /* grid_length (linspace, impl/hdp_math_utils.c:497-510)         */
+    const int64_t *dp_parent;           /* num_dps, -1 for the base DP                                   */
+    const int64_t *dp_num_factor_children, *dp_depth;
+    const uint8_t *observed;            /* num_dps (mark_observed_dps, impl/hdp.c:1132-1160)             */
+    const int64_t *row_of_dp;           /* num_dps: row of an observed DP in post / slope, -1 otherwise  */
+    const double *post, *slope;         /* n_observed x grid_length                                      */
+    const int64_t *f_type, *f_parent;   /* n_factors, tree order: 0 base / 1 middle / 2 data point       */
+    const int64_t *f_ref;               /* the factor's DP, or its data index for a data point           */
+    const double *f_params;             /* 5 per factor (base factors): mu nu two_alpha beta log-term    */
+    const int64_t *f_n_children;
+} sa_hdp_state_info_t;
+int sa_hdp_state_load(sa_hdp_state_t **out, const char *nhdp_path);
+int sa_hdp_state_write(const sa_hdp_state_t *s, const char *nhdp_path);
+int sa_hdp_state_info(const sa_hdp_state_t *s, sa_hdp_state_info_t *info);
+void sa_hdp_state_free(sa_hdp_state_t *s);
+/* out: n_observed x grid_length (rows as sa_hdp_state_info_t.row_of_dp), overwritten */
+int sa_hdp_state_distr_sample(const sa_hdp_state_t *s, int device, double *out);
+/* sum: n_rows x grid_length collectors after `samples` samples; y_out = sum / samples, slope_out the spline slopes (both n_rows x
+ * grid_length; y_out may be NULL) */
+int sa_hdp_finalize_distributions(const double *grid, int64_t grid_length, const double *sum, int64_t n_rows, int64_t samples,
+                                  int device, double *y_out, double *slope_out);
+
 int sa_device_count(void);
 /* HBM of `device`: bytes free (what the library's caching allocator holds counts as free) and in total; a caller that keeps
  * several batches in flight sizes its pipeline with this (sa_batch_stats_t.f_bytes is the bulk of a batch) */

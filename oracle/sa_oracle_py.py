@@ -48,7 +48,7 @@ PAIR_DTYPE = np.dtype([("prob_e7", "<i8"), ("x", "<i8"), ("y", "<i8"), ("path", 
 
 def build(force=False):
     so = os.path.join(_HERE, "libsa_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("sa_oracle.c", "sa_mea_oracle.c", "sa_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("sa_oracle.c", "sa_mea_oracle.c", "sa_hdp_oracle.c", "sa_oracle.h")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
@@ -113,6 +113,15 @@ def lib():
     L.sao_align_batch_mt.argtypes = [C.c_void_p, C.POINTER(Job), C.c_int64, C.POINTER(Params), C.c_int, ip, dp]
     L.sao_align_batch_mt2.restype = C.c_int
     L.sao_align_batch_mt2.argtypes = [C.c_void_p, C.POINTER(Job), C.c_int64, C.POINTER(Params), C.c_int, ip, dp, C.POINTER(C.c_char_p)]
+    u8p = C.POINTER(C.c_uint8)
+    L.sao_hdp_linspace.argtypes = [C.c_double, C.c_double, C.c_int64, dp]
+    L.sao_hdp_spline_knot_slopes.argtypes = [dp, dp, C.c_int64, dp]
+    L.sao_hdp_posterior_predictive.argtypes = [dp, dp, dp, C.c_int64]
+    L.sao_hdp_prior_predictive.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, dp, dp, C.c_int64]
+    L.sao_hdp_nig_posterior.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, dp, C.c_int64, dp]
+    L.sao_hdp_distr_sample.restype = C.c_int
+    L.sao_hdp_distr_sample.argtypes = [C.c_int64, ip, ip, ip, u8p, dp, C.c_int64, ip, ip, ip, dp, C.c_double, C.c_double, C.c_double,
+                                       C.c_double, dp, C.c_int64, dp]
     _LIB = L
     return L
 
@@ -530,3 +539,57 @@ def align_batch_mt(model, jobs, params, n_threads, ambig=None):
     cells = np.zeros(n, dtype=np.float64)
     lib().sao_align_batch_mt2(model._h, arr, n, C.byref(params), n_threads, _ip(npairs), _dp(cells), ambig)
     return npairs, cells
+
+
+# ---- HDP rebuild, the deterministic pieces (sa_hdp_oracle.c) ----------------------------------------------------------
+def hdp_linspace(start, stop, length):
+    out = np.zeros(int(length), dtype=np.float64)
+    lib().sao_hdp_linspace(float(start), float(stop), int(length), _dp(out))
+    return out
+
+
+def hdp_spline_knot_slopes(x, y):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    k = np.zeros(len(x), dtype=np.float64)
+    lib().sao_hdp_spline_knot_slopes(_dp(x), _dp(y), len(x), _dp(k))
+    return k
+
+
+def hdp_posterior_predictive(params5, x):
+    p5 = np.ascontiguousarray(params5, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.zeros(len(x), dtype=np.float64)
+    lib().sao_hdp_posterior_predictive(_dp(p5), _dp(x), _dp(out), len(x))
+    return out
+
+
+def hdp_prior_predictive(mu, nu, two_alpha, beta, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.zeros(len(x), dtype=np.float64)
+    lib().sao_hdp_prior_predictive(float(mu), float(nu), float(two_alpha), float(beta), _dp(x), _dp(out), len(x))
+    return out
+
+
+def hdp_nig_posterior(mu, nu, two_alpha, beta, data):
+    d = np.ascontiguousarray(data, dtype=np.float64)
+    out = np.zeros(5, dtype=np.float64)
+    lib().sao_hdp_nig_posterior(float(mu), float(nu), float(two_alpha), float(beta), _dp(d), len(d), _dp(out))
+    return out
+
+
+def hdp_distr_sample(dp_parent, dp_nfc, dp_depth, observed, gamma, f_type, f_parent, f_dp, f_params, mu, nu, two_alpha, beta, grid):
+    """take_distr_sample from arrays: returns the collectors, num_dps x grid_length (rows of unobserved DPs are zero)"""
+    a = [np.ascontiguousarray(v, dtype=np.int64) for v in (dp_parent, dp_nfc, dp_depth)]
+    ob = np.ascontiguousarray(observed, dtype=np.uint8)
+    g = np.ascontiguousarray(gamma, dtype=np.float64)
+    f = [np.ascontiguousarray(v, dtype=np.int64) for v in (f_type, f_parent, f_dp)]
+    fp = np.ascontiguousarray(f_params, dtype=np.float64)
+    grid = np.ascontiguousarray(grid, dtype=np.float64)
+    out = np.zeros((len(a[0]), len(grid)), dtype=np.float64)
+    rc = lib().sao_hdp_distr_sample(len(a[0]), _ip(a[0]), _ip(a[1]), _ip(a[2]), ob.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(g), len(f[0]),
+                                    _ip(f[0]), _ip(f[1]), _ip(f[2]), _dp(fp), float(mu), float(nu), float(two_alpha), float(beta),
+                                    _dp(grid), len(grid), _dp(out))
+    if rc != 0:
+        raise RuntimeError("sao_hdp_distr_sample failed")
+    return out

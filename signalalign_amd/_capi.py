@@ -81,8 +81,22 @@ EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alp
            "sa_batch_create", "sa_batch_create_deferred", "sa_batch_prepare", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_pairs16", "sa_batch_pairs16_all", "sa_batch_pairs_all", "sa_batch_stats",
            "sa_batch_job_cells", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_expect_last_stats", "sa_plan_describe", "sa_plan_digest",
            "sa_plan_check_path_records", "sa_dplan_compare",
-           "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_pool_configure", "sa_host_alloc", "sa_host_free", "sa_pair_roundtrip", "sa_fasta_subsequence", "sa_format_f6", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_device_memory", "sa_strerror",
+           "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_pool_configure", "sa_host_alloc", "sa_host_free", "sa_pair_roundtrip", "sa_fasta_subsequence", "sa_format_f6", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_device_memory", "sa_strerror", "sa_hdp_state_load", "sa_hdp_state_write", "sa_hdp_state_info", "sa_hdp_state_free", "sa_hdp_state_distr_sample", "sa_hdp_finalize_distributions",
            "sa_version", "sa_free"]
+
+
+class HdpStateInfo(C.Structure):
+    """sa_hdp_state_info_t (include/signalalign_hip.h)"""
+    _fields_ = ([(n, C.c_int64) for n in ("num_dps", "depth", "grid_length", "n_data", "n_factors", "n_base_factors", "n_observed",
+                                          "base_dp", "alphabet_size", "kmer_length")] +
+                [(n, C.c_double) for n in ("mu", "nu", "alpha", "beta", "grid_start", "grid_stop")] +
+                [(n, C.c_int) for n in ("splines_finalized", "has_data", "sample_gamma")] +
+                [("data", C.POINTER(C.c_double)), ("data_dp", C.POINTER(C.c_int64)), ("gamma", C.POINTER(C.c_double)),
+                 ("grid", C.POINTER(C.c_double)), ("dp_parent", C.POINTER(C.c_int64)),
+                 ("dp_num_factor_children", C.POINTER(C.c_int64)), ("dp_depth", C.POINTER(C.c_int64)),
+                 ("observed", C.POINTER(C.c_uint8)), ("row_of_dp", C.POINTER(C.c_int64)), ("post", C.POINTER(C.c_double)),
+                 ("slope", C.POINTER(C.c_double)), ("f_type", C.POINTER(C.c_int64)), ("f_parent", C.POINTER(C.c_int64)),
+                 ("f_ref", C.POINTER(C.c_int64)), ("f_params", C.POINTER(C.c_double)), ("f_n_children", C.POINTER(C.c_int64))])
 
 
 def library_path():
@@ -177,6 +191,12 @@ def lib():
     L.sa_mea_params.restype = C.c_int64
     L.sa_mea_params.argtypes = [ip, ip, dp, C.c_int64, i32p, i32p, dp, i32p, ip]
     L.sa_free.argtypes = [C.c_void_p]
+    L.sa_hdp_state_load.argtypes = [C.POINTER(C.c_void_p), C.c_char_p]
+    L.sa_hdp_state_write.argtypes = [C.c_void_p, C.c_char_p]
+    L.sa_hdp_state_info.argtypes = [C.c_void_p, C.POINTER(HdpStateInfo)]
+    L.sa_hdp_state_free.argtypes = [C.c_void_p]
+    L.sa_hdp_state_distr_sample.argtypes = [C.c_void_p, C.c_int, dp]
+    L.sa_hdp_finalize_distributions.argtypes = [dp, C.c_int64, dp, C.c_int64, C.c_int64, C.c_int, dp, dp]
     _LIB = L
     return L
 
@@ -711,3 +731,60 @@ def device_memory(device=0):
     f, t = C.c_int64(), C.c_int64()
     _chk(lib().sa_device_memory(device, C.byref(f), C.byref(t)), "sa_device_memory")
     return f.value, t.value
+
+
+class HdpState:
+    """The whole state of a serialised NanoporeHDP (sa_hdp_state_*: the deterministic pieces of the HDP rebuild).  Arrays are
+    copies (numpy) of the views sa_hdp_state_info hands out."""
+
+    def __init__(self, path):
+        self._h = C.c_void_p()
+        _chk(lib().sa_hdp_state_load(C.byref(self._h), os.fsencode(path)), "sa_hdp_state_load")
+        self.info = HdpStateInfo()
+        _chk(lib().sa_hdp_state_info(self._h, C.byref(self.info)), "sa_hdp_state_info")
+
+    def close(self):
+        if self._h:
+            lib().sa_hdp_state_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def write(self, path):
+        _chk(lib().sa_hdp_state_write(self._h, os.fsencode(path)), "sa_hdp_state_write")
+
+    def array(self, name):
+        """a copy of one of the info views, shaped: per data point, per DP, per factor (f_params: n_factors x 5), post / slope:
+        n_observed x grid_length"""
+        i = self.info
+        n = {"data": i.n_data, "data_dp": i.n_data, "gamma": i.depth, "grid": i.grid_length, "dp_parent": i.num_dps,
+             "dp_num_factor_children": i.num_dps, "dp_depth": i.num_dps, "observed": i.num_dps, "row_of_dp": i.num_dps,
+             "post": i.n_observed * i.grid_length, "slope": i.n_observed * i.grid_length, "f_type": i.n_factors,
+             "f_parent": i.n_factors, "f_ref": i.n_factors, "f_params": 5 * i.n_factors, "f_n_children": i.n_factors}[name]
+        p = getattr(i, name)
+        a = np.ctypeslib.as_array(p, shape=(int(n),)).copy() if n > 0 else np.zeros(0)
+        if name in ("post", "slope"):
+            a = a.reshape(int(i.n_observed), int(i.grid_length))
+        if name == "f_params":
+            a = a.reshape(int(i.n_factors), 5)
+        return a
+
+    def distr_sample(self, device=0):
+        """sa_hdp_state_distr_sample: what one sample of this state adds to every observed DP's collector (GPU)"""
+        out = np.zeros((int(self.info.n_observed), int(self.info.grid_length)), dtype=np.float64)
+        _chk(lib().sa_hdp_state_distr_sample(self._h, device, _dp(out)), "sa_hdp_state_distr_sample")
+        return out
+
+
+def hdp_finalize_distributions(grid, collectors, samples, device=0):
+    """sa_hdp_finalize_distributions: (collectors / samples, spline slopes), both n_rows x grid_length (GPU)"""
+    grid = np.ascontiguousarray(grid, dtype=np.float64)
+    s = np.ascontiguousarray(collectors, dtype=np.float64).reshape(-1, len(grid))
+    y, k = np.zeros_like(s), np.zeros_like(s)
+    _chk(lib().sa_hdp_finalize_distributions(_dp(grid), len(grid), _dp(s), s.shape[0], int(samples), device, _dp(y), _dp(k)),
+         "sa_hdp_finalize_distributions")
+    return y, k
