@@ -756,12 +756,19 @@ __device__ __forceinline__ double la_exact_bf(const double *tab, double x, doubl
     return (d < 7.5) ? r : mx;
 }
 
-// One wave folds 64 consecutive checkpoints, one per lane.  Their per-cell terms are contiguous per checkpoint in
-// vbuf; they are brought in with coalesced loads (one checkpoint per load instruction) and transposed through LDS so
-// that every lane then walks its own checkpoint sequentially.
-#define FOLD_LD 65
+// One wave folds 64 consecutive checkpoints, one per lane.  A checkpoint's terms are contiguous in vbuf -- nA terms of its own
+// diagonal, then nB of the diagonal above -- and its total is logAdd(fold(A), fold(B)): the two folds are independent chains, walked
+// side by side (round 4: two logAdds in flight per lane instead of one; the chain is latency, ~25 dependent instructions and an LDS
+// read per term).  Terms come in with coalesced loads, FOLD_TW per checkpoint and chain (a load instruction serves 64 / FOLD_TW
+// checkpoints), and are transposed through LDS so that every lane then walks its own checkpoint.  Two tiles of 64 x (FOLD_TW + 1)
+// doubles: 9 KB per wave at FOLD_TW 8, seventeen waves per CU (FOLD_TW 4 / 8 / 16 / 32: 0.88 / 0.57 / 0.60 / 1.14 ms on the headline batch, 2.04 / 1.31 / 1.58 / 2.99 on the realistic one) (the 64-term tile of rounds 1-3 took 33 KB: four waves per CU, one
+// chain each -- k_fold 0.84 ms of the headline batch's 9.9 and 2.4 of the realistic batch's 29).
+#ifndef FOLD_TW
+#define FOLD_TW 8
+#endif
+#define FOLD_LD (FOLD_TW + 1)
 __global__ __launch_bounds__(64) void k_fold(DevPlan P, long long ck0, long long ck1) {
-    __shared__ double tile[64 * FOLD_LD];
+    __shared__ double tileA[64 * FOLD_LD], tileB[64 * FOLD_LD];
     __shared__ __attribute__((aligned(32))) double LT[16];
     const int lane = threadIdx.x;
     if (lane < 4) {
@@ -775,39 +782,35 @@ __global__ __launch_bounds__(64) void k_fold(DevPlan P, long long ck0, long long
     const long long ckid = ck0 + (long long) blockIdx.x * 64 + lane;
     sa_ck_t ck = {0, 0, 0};
     if (ckid < ck1) ck = P.cks[ckid];
-    const int len = ck.nA + ck.nB;
-    const int maxlen = wave_max_i(len);
+    const int nA = ck.nA, nB = ck.nB;
+    const int maxlen = wave_max_i(nA > nB ? nA : nB);
     const int vo_lo = (int) (ck.voff & 0xffffffffll), vo_hi = (int) (ck.voff >> 32);
     double tA = NEG_INF, tB = NEG_INF;
+    constexpr int CPL = 64 / FOLD_TW;              // checkpoints per load instruction
+    const int sub = lane / FOLD_TW, t = lane % FOLD_TW;
     __syncthreads();
-    for (int j0 = 0; j0 < maxlen; j0 += 64) {
-        for (int c0 = 0; c0 < 64; c0 += 8) {  // eight checkpoints' loads in flight before the first LDS write
-            double v[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int c = c0 + k;
-                const int ln = __builtin_amdgcn_readlane(len, c);
-                const long long vo = ((long long) __builtin_amdgcn_readlane(vo_hi, c) << 32) |
-                                     (unsigned int) __builtin_amdgcn_readlane(vo_lo, c);
-                v[k] = NEG_INF;
-                if (j0 + lane < ln) v[k] = P.vbuf[vo + j0 + lane];
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++) tile[lane * FOLD_LD + c0 + k] = v[k];
+    for (int j0 = 0; j0 < maxlen; j0 += FOLD_TW) {
+#pragma unroll 4
+        for (int c0 = 0; c0 < 64; c0 += CPL) {
+            const int c = c0 + sub;                // this lane's checkpoint of the load
+            const int cnA = __shfl(nA, c), cnB = __shfl(nB, c);
+            const long long vo = ((long long) __shfl(vo_hi, c) << 32) | (unsigned int) __shfl(vo_lo, c);
+            const int j = j0 + t;
+            double va = NEG_INF, vb = NEG_INF;     // -inf past the end: logAdd(t, -inf) == t
+            if (j < cnA) va = P.vbuf[vo + j];
+            if (j < cnB) vb = P.vbuf[vo + cnA + j];
+            tileA[c * FOLD_LD + t] = va;
+            tileB[c * FOLD_LD + t] = vb;
         }
         __syncthreads();
-        const int lim = maxlen - j0 < 64 ? maxlen - j0 : 64;
+        const int lim = maxlen - j0 < FOLD_TW ? maxlen - j0 : FOLD_TW;
         for (int i = 0; i < lim; i++) {
-            const double v = tile[i * FOLD_LD + lane];  // -inf past the end: logAdd(t, -inf) == t
-            const bool inA = (j0 + i) < ck.nA;
-            double acc = inA ? tA : tB;
-            acc = la_exact_bf(LT, acc, v);
-            tA = inA ? acc : tA;
-            tB = inA ? tB : acc;
+            tA = la_exact_bf(LT, tA, tileA[lane * FOLD_LD + i]);
+            tB = la_exact_bf(LT, tB, tileB[lane * FOLD_LD + i]);
         }
         __syncthreads();
     }
-    if (ckid < ck1) P.totals[ckid] = (ck.nB > 0) ? la_exact_bf(LT, tA, tB) : tA;
+    if (ckid < ck1) P.totals[ckid] = (nB > 0) ? la_exact_bf(LT, tA, tB) : tA;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1026,7 +1029,9 @@ __global__ __launch_bounds__(64) void k_gather(DevPlan P, int seg0, int n_segs, 
 // writes them.  A survivor's key: diagonals below the start << 40 | column << 12 | path (28 and 12 bits: the planners' limits are
 // 2^28 columns and 255 paths per cell on these kernels); its candidate slot travels beside the key.  keys / idx: 12 bytes of
 // scratch per candidate slot.  The result does not depend on the order the candidates arrived in.
-#define GATHER_H 8192
+#ifndef GATHER_H
+#define GATHER_H 1024   // (4 KB of LDS per wave: 8192 entries held a wave to four per CU and cost the realistic batch 0.97 ms)
+#endif
 __global__ __launch_bounds__(64) void k_gather_sorted(DevPlan P, int seg0, int n_segs, const long long *prob_e7, const long long *seg_off,
                                                       sa_pair16_t *out, const double *__restrict__ spec,
                                                       unsigned long long *keys_all, unsigned *idx_all) {
