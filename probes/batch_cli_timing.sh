@@ -35,7 +35,7 @@ BIN=$GRAFT_REPO_ROOT/signalalign_amd/bin/signalMachine
 T0=$(date +%s.%N)
 SA_CLI_TIMING=1 $BIN --batch $W/manifest.tsv -T $M -f $W/ref.fa -g 100 $SA_CLI_EXTRA > $W/stdout.txt 2> $W/stderr.txt
 T1=$(date +%s.%N)
-tail -2 $W/stderr.txt
+tail -2 $W/stderr.txt; if [ -n "$SA_CLI_KEEP_STDERR" ]; then cp $W/stderr.txt $SA_CLI_KEEP_STDERR; fi
 BYTES=$(find $W -name 'out*.tsv' -print0 | xargs -0 cat | wc -c)
 python3 - <<PY
 n, ev, dt, b = $N, int(open("$W/n_events").read()), $T1 - $T0, $BYTES
