@@ -22,10 +22,15 @@ def realistic_anchor_jobs(model_path, n_reads, n_events, first_index=0, trim=14)
     """Synthetic reads whose anchors are thinned the way a real guide alignment thins them: match runs taken from
     the bundled minus-strand cigar (tests/golden/cigars), `trim` anchors dropped at both ends of each run, nothing
     kept inside deletions.  About one base in six stays an anchor and most diagonals are wider than 64 lanes."""
+    return thin_anchors_like_a_guide_alignment(synthetic_jobs(model_path, n_reads, n_events, first_index), trim)
+
+
+def thin_anchors_like_a_guide_alignment(job_list, trim=14):
+    """the thinning of realistic_anchor_jobs for any list of jobs (HDP reads too)"""
     toks = open(os.path.join(GOLDEN, "cigars", "ecoli_minus_strand.cigar")).read().split()[10:]
     runs = [(toks[i], int(toks[i + 1])) for i in range(0, len(toks), 2)]
     jobs = []
-    for j, job in enumerate(synthetic_jobs(model_path, n_reads, n_events, first_index)):
+    for j, job in enumerate(job_list):
         ax, ay = job["ax"], job["ay"]
         keep = np.zeros(len(ax), dtype=bool)
         pos, r = 0, (7 * j) % len(runs)

@@ -107,3 +107,47 @@ def test_baseline_config_3_full_size(oracle, threshold):
         worst, n_only = cases.compare_pairs(small.pairs(q), exp, 100, threshold)
         assert worst <= 100 and n_only <= 20
     small.close()
+
+
+@pytest.mark.parametrize("flavour", ["cpg", "realistic"])
+def test_hdp_on_ring_and_strip_kernels_at_bench_size(oracle, flavour):
+    """Round 4: HDP emissions on the ring kernels (every CpG cytosine C / E: `bench.py --workload hdp_cpg`) and on the strip kernels
+    (anchors of a real guide alignment: `--workload hdp_realistic`), 2000 x 5000-event reads each, both fed by the per-cell-path
+    emission plane (k_emit_hdp_ring).  Same size-independent checks as above."""
+    n_reads, threshold = 2000, 0.1
+    pm = sa.Model.load(cases.MODEL_R73, cases.NHDP)
+    pm.set_to_hdp_expected_values()
+    p = sa.default_params(threshold=threshold)
+    jobs = cases.hdp_jobs(n_reads, N_EVENTS, table5=pm.table5())
+    amb_p = amb_o = None
+    if flavour == "cpg":
+        jobs = [dict(j, ref=j["ref"].replace("CG", "XG")) for j in jobs]
+        amb_p, amb_o = sa.default_ambig({"X": "CE"}), oracle.ambig_map({"X": "CE"})
+    else:
+        jobs = cases.thin_anchors_like_a_guide_alignment(jobs)
+    b = sa.Batch(pm, p, jobs, ambig=amb_p)
+    b.run()
+    st = b.stats()
+    if flavour == "cpg":
+        assert st.n_ring_regions == st.n_regions and st.n_strip_regions == 0
+    else:
+        assert st.n_strip_regions >= 0.95 * st.n_regions
+    _check_probabilities(b, jobs, threshold, 23, 0.01)
+    first, per_read = _digest(b, n_reads)
+    b.run()
+    assert _digest(b, n_reads)[0] == first
+    b.close()
+    pick = [3, 1999]
+    small = sa.Batch(pm, p, [jobs[j] for j in pick], ambig=amb_p)
+    small.run()
+    for q, j in enumerate(pick):
+        assert zlib.crc32(small.pairs(q).tobytes()) == per_read[j]
+    alpha, k, t10, tab = sa.synth.parse_model_table(cases.MODEL_R73)
+    om = oracle.Model(alpha, k, t10, tab)
+    om.load_hdp(cases.NHDP)
+    om.set_to_hdp_expected_values()
+    op = cases.oracle_params(oracle, p)
+    exp = cases.oracle_pairs(oracle, om, jobs[pick[0]], op, ambig=amb_o)
+    worst, n_only = cases.compare_pairs(small.pairs(0), exp, 100, threshold)
+    assert worst <= 100 and n_only <= 20
+    small.close()
