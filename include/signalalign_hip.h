@@ -478,6 +478,11 @@ int sa_hdp_state_info(const sa_hdp_state_t *s, sa_hdp_state_info_t *info);
 void sa_hdp_state_free(sa_hdp_state_t *s);
 /* out: n_observed x grid_length (rows as sa_hdp_state_info_t.row_of_dp), overwritten */
 int sa_hdp_state_distr_sample(const sa_hdp_state_t *s, int device, double *out);
+/* The host half of sa_hdp_state_distr_sample on its own: the weights of one sample as CSR over the observed DPs' rows --
+ * row r holds entries [row_start[r], row_start[r + 1]) of (col, w); col < n_base_factors names a base factor (in tree order),
+ * col == n_base_factors the prior; entries of a row are in the order the reference adds them.  The three arrays are the
+ * library's (sa_free). */
+int sa_hdp_state_sample_weights(const sa_hdp_state_t *s, int64_t **row_start, int64_t **col, double **w, int64_t *nnz);
 /* sum: n_rows x grid_length collectors after `samples` samples; y_out = sum / samples, slope_out the spline slopes (both n_rows x
  * grid_length; y_out may be NULL) */
 int sa_hdp_finalize_distributions(const double *grid, int64_t grid_length, const double *sum, int64_t n_rows, int64_t samples,

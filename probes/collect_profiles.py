@@ -38,6 +38,18 @@ for fname, src in (("instr_mix.json", "instr.json"), ("traffic.json", "traffic.j
         import subprocess, time
         head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
         merged.setdefault("_meta", {})[w] = {"head": head, "collected": time.strftime("%Y-%m-%d %H:%M"), "tag": tag}
+    # (the file's own description: which passes, which scripts -- per workload the round is in _meta)
+    merged["_comment"] = ({
+        "traffic.json": "HBM bytes per bench step (one sa_batch_run over the default batch of each workload, one launch per stage: "
+                        "SA_GROUPS=1) from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --kernels-only "
+                        "--no-secondary` (probes/profile_r04.sh, probes/traffic_from_pmc.py). Counter unit KB; FETCH_SIZE is doubled "
+                        "for gfx950 as MI355X_MICROARCH.md prescribes (fetch_corrected). Template instances of a kernel are summed under "
+                        "its bare name. _meta[workload] holds the commit, date and tag (round) of that workload's passes.",
+        "instr_mix.json": "Wave-instructions per bench step (one sa_batch_run over the default batch of each workload, one launch per "
+                          "stage) by class, from rocprofv3 --pmc SQ_INSTS_VALU/SALU/LDS and SQ_INSTS_VMEM/SMEM in two passes over "
+                          "`bench.py --kernels-only --no-secondary` (probes/profile_r04.sh, probes/instr_from_pmc.py), with the wave-level "
+                          "busy / wait fractions of the same passes. _meta[workload] holds the commit, date and tag (round) of the passes."}
+        [fname])
     json.dump(merged, open(path, "w"), indent=1)
     print("wrote", path)
 for w in workloads:

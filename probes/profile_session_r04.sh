@@ -9,7 +9,7 @@ if [ "$PART" = a ]; then
   bash probes/profile_r04.sh realistic $T full
   bash probes/profile_r04.sh hdp $T full
 else
-  bash probes/profile_r04.sh expectations $T stats-only
+  bash probes/profile_r04.sh expectations $T full
   bash probes/profile_r04.sh expectations_cpg $T stats-only
   bash probes/profile_r04.sh cpg $T full
   bash probes/profile_r04.sh scaling $T stats-only

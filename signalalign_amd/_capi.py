@@ -81,7 +81,7 @@ EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alp
            "sa_batch_create", "sa_batch_create_deferred", "sa_batch_prepare", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_pairs16", "sa_batch_pairs16_all", "sa_batch_pairs_all", "sa_batch_stats",
            "sa_batch_job_cells", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_expect_last_stats", "sa_plan_describe", "sa_plan_digest",
            "sa_plan_check_path_records", "sa_dplan_compare",
-           "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_pool_configure", "sa_host_alloc", "sa_host_free", "sa_pair_roundtrip", "sa_fasta_subsequence", "sa_format_f6", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_device_memory", "sa_strerror", "sa_hdp_state_load", "sa_hdp_state_write", "sa_hdp_state_info", "sa_hdp_state_free", "sa_hdp_state_distr_sample", "sa_hdp_finalize_distributions",
+           "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_pool_configure", "sa_host_alloc", "sa_host_free", "sa_pair_roundtrip", "sa_fasta_subsequence", "sa_format_f6", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_device_memory", "sa_strerror", "sa_hdp_state_load", "sa_hdp_state_write", "sa_hdp_state_info", "sa_hdp_state_free", "sa_hdp_state_distr_sample", "sa_hdp_state_sample_weights", "sa_hdp_finalize_distributions",
            "sa_version", "sa_free"]
 
 
@@ -196,6 +196,7 @@ def lib():
     L.sa_hdp_state_info.argtypes = [C.c_void_p, C.POINTER(HdpStateInfo)]
     L.sa_hdp_state_free.argtypes = [C.c_void_p]
     L.sa_hdp_state_distr_sample.argtypes = [C.c_void_p, C.c_int, dp]
+    L.sa_hdp_state_sample_weights.argtypes = [C.c_void_p, C.POINTER(ip), C.POINTER(ip), C.POINTER(dp), ip]
     L.sa_hdp_finalize_distributions.argtypes = [dp, C.c_int64, dp, C.c_int64, C.c_int64, C.c_int, dp, dp]
     _LIB = L
     return L
@@ -772,6 +773,18 @@ class HdpState:
         if name == "f_params":
             a = a.reshape(int(i.n_factors), 5)
         return a
+
+    def sample_weights(self):
+        """sa_hdp_state_sample_weights (host code): (row_start, col, w) of one sample's weights, CSR over the observed DPs' rows"""
+        rs, col, w, nnz = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.POINTER(C.c_double)(), C.c_int64()
+        _chk(lib().sa_hdp_state_sample_weights(self._h, C.byref(rs), C.byref(col), C.byref(w), C.byref(nnz)),
+             "sa_hdp_state_sample_weights")
+        n = int(nnz.value)
+        out = (np.ctypeslib.as_array(rs, shape=(int(self.info.n_observed) + 1,)).copy(),
+               np.ctypeslib.as_array(col, shape=(max(n, 1),))[:n].copy(), np.ctypeslib.as_array(w, shape=(max(n, 1),))[:n].copy())
+        for q in (rs, col, w):
+            lib().sa_free(C.cast(q, C.c_void_p))
+        return out
 
     def distr_sample(self, device=0):
         """sa_hdp_state_distr_sample: what one sample of this state adds to every observed DP's collector (GPU)"""

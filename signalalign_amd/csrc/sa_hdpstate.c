@@ -455,3 +455,7 @@ done:
     free(e_row); free(e_col); free(e_w); free(row_start); free(col); free(w);
     return rc;
 }
+
+int sa_hdp_state_sample_weights(const sa_hdp_state_t *s, int64_t **row_start, int64_t **col, double **w, int64_t *nnz) {
+    return sa_hdp_state_weights(s, row_start, col, w, nnz);
+}

@@ -97,3 +97,34 @@ def test_malformed_states_are_refused(tmp_path):
     refused(bad)
     with pytest.raises(sa.SaError):
         sa.HdpState(str(tmp_path / "missing.nhdp"))
+
+
+@pytest.mark.parametrize("which", ["reference_file", "three_levels"])
+def test_sample_weights_times_the_restatements_densities(oracle, tmp_path, which):
+    """The host half of sa_hdp_state_distr_sample (cache_base_factor_weight / cache_prior_contribution, impl/hdp.c:2001-2044, walked
+    with explicit stacks) against the CPU restatement's recursions: the CSR weights times the restatement's predictive densities,
+    added in CSR order, are the restatement's collectors -- bit for bit (same sums in the same order).  No GPU."""
+    if which == "reference_file":
+        s = sa.HdpState(cases.NHDP)
+    else:
+        p = str(tmp_path / "syn.nhdp")
+        hdp_cases.write_synthetic_nhdp(p, seed=21, n_mid=5, n_leaf=7, n_data=900, n_base=12)
+        s = sa.HdpState(p)
+    i = s.info
+    ft, fpar, grid = s.array("f_type"), s.array("f_params"), s.array("grid")
+    rs, col, w = s.sample_weights()
+    assert rs[0] == 0 and rs[-1] == len(col) == len(w) and np.all(np.diff(rs) >= 1)
+    for r in range(i.n_observed):
+        assert np.all(np.diff(col[rs[r]:rs[r + 1]]) > 0)          # a row's columns ascend: the order the reference adds them in
+        assert abs(w[rs[r]:rs[r + 1]].sum() - 1.0) < 1e-12        # ... and its weights sum to one
+    pdf = [oracle.hdp_posterior_predictive(fpar[F], grid) for F in np.nonzero(ft == 0)[0]]
+    pdf.append(oracle.hdp_prior_predictive(i.mu, i.nu, 2 * i.alpha, i.beta, grid))
+    want = oracle.hdp_distr_sample(s.array("dp_parent"), s.array("dp_num_factor_children"), s.array("dp_depth"), s.array("observed"),
+                                   s.array("gamma"), ft, s.array("f_parent"), np.where(ft == 2, -1, s.array("f_ref")), fpar,
+                                   i.mu, i.nu, 2 * i.alpha, i.beta, grid)[s.array("observed") == 1]
+    for r in range(i.n_observed):
+        acc = np.zeros(i.grid_length)
+        for e in range(rs[r], rs[r + 1]):
+            acc = acc + w[e] * pdf[col[e]]
+        assert np.array_equal(acc, want[r]), r
+    s.close()
