@@ -677,3 +677,30 @@ def test_start_wait_overlaps_batches(oracle):
     c.start()
     c.close()                                  # destroying a started batch joins it first
     b.close()
+
+
+def test_speculative_bound_that_is_too_high_repeats_the_pass(oracle, monkeypatch, capfd):
+    """The backward sweeps bound their candidates by the traceback's speculative total minus a slack (DESIGN.md section 4, round 4);
+    k_finalize checks every exact total against that bound and the pass is repeated with four times the slack when one falls
+    below.  Forced here with a slack (1e-4) the totals' drift exceeds (~1e-2 per traceback): register, strip and ring kernels, the
+    same bytes as with the default slack."""
+    pm, om = _models(oracle, cases.MODEL_6MER)
+    p = sa.default_params()
+    jobs = cases.synthetic_jobs(cases.MODEL_6MER, 4, 1500, 77) + cases.realistic_anchor_jobs(cases.MODEL_6MER, 2, 2500, 91)
+    want, st = _run(pm, p, jobs)
+    assert st.n_fast_regions >= 4 and st.n_strip_regions >= 1
+    pc = sa.Model.load(cases.MODEL_CPG)
+    amb = sa.default_ambig({"X": "CE"})
+    cjobs = cases.synthetic_jobs(cases.MODEL_CPG, 2, 1200, 5, cpg_ambiguous=True)
+    cwant, cst = _run(pc, p, cjobs, ambig=amb)
+    assert cst.n_ring_regions == 2
+    capfd.readouterr()
+    monkeypatch.setenv("SA_TEST_SPEC_SLACK", "1e-4")
+    got, _ = _run(pm, p, jobs)
+    cgot, _ = _run(pc, p, cjobs, ambig=amb)
+    err = capfd.readouterr().err
+    assert err.count("a speculative candidate bound was too high") >= 2, err[-400:]
+    for j in range(len(jobs)):
+        assert np.array_equal(got[j], want[j]), j
+    for j in range(len(cjobs)):
+        assert np.array_equal(cgot[j], cwant[j]), j
