@@ -357,7 +357,12 @@ def measure(args, ctx, compact=False):
     if args.workload == "cpg":
         model_path = os.path.join(gold, "testModelR9.4_450bps.cpg.6mer.template.model")
         ambig, read_kw = sa.default_ambig({"X": "CE"}), {"cpg_ambiguous": True}
+        if args.cpg_every > 1:   # sparse variant positions: only every n-th CpG cytosine is ambiguous
+            read_kw["cpg_every"] = int(args.cpg_every)
         wl_name = "BASELINE configs[2]: R9.4 6-mer CpG model (ACEGT), every CpG cytosine ambiguous (C/E)"
+        if args.cpg_every > 1:
+            wl_name = ("R9.4 6-mer CpG model (ACEGT), every %d-th CpG cytosine ambiguous (C/E): sparse variant positions "
+                       "(not a BASELINE config)" % args.cpg_every)
     elif args.workload == "scaling":
         wl_name = "BASELINE configs[4], one GPU's slice (100k reads / 8): R9.4 6-mer template Gaussian HMM"
     elif args.workload in ("hdp", "hdp_cpg", "hdp_realistic"):
@@ -892,6 +897,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernels-only", action="store_true", help="phase 1 only (sa_batch_run on one resident batch): for "
                                                                 "profiler runs that count per-kernel launches")
+    ap.add_argument("--cpg-every", type=int, default=1, help="--workload cpg: only every n-th CpG cytosine is ambiguous (sparse "
+                                                                 "variant positions; default 1 = BASELINE configs[2])")
     ap.add_argument("--no-secondary", action="store_true", help="gaussian at N = 1 also measures `realistic` and `cpg` compactly "
                                                                 "(config.secondary) and a long steady-state run (config.long_run); "
                                                                 "this skips both")

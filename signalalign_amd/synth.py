@@ -40,10 +40,11 @@ def single_match_anchors(event_map, read_len, trim=14):
     return x[keep], y[keep]
 
 
-def make_read(index, n_events, alphabet, k, table5, trim=14, cpg_ambiguous=False, thin_anchors=0.0):
+def make_read(index, n_events, alphabet, k, table5, trim=14, cpg_ambiguous=False, thin_anchors=0.0, cpg_every=1):
     """Returns dict(ref, events4, ax, ay, scale, shift, var, event_map, read) for read `index`.
 
-    cpg_ambiguous: replace every C that is followed by G with 'X' (config 3: CpG cytosines ambiguous).
+    cpg_ambiguous: replace every C that is followed by G with 'X' (config 3: CpG cytosines ambiguous); cpg_every = n > 1: only
+    every n-th of them (sparse variant positions: most cells of the read then hold one path).
     thin_anchors: fraction of the read covered by anchor-free windows (realistic guide alignments).
     """
     rng = np.random.Generator(np.random.PCG64(SEED0 + int(index)))
@@ -101,8 +102,13 @@ def make_read(index, n_events, alphabet, k, table5, trim=14, cpg_ambiguous=False
         ax, ay = ax[keep], ay[keep]
     lo, hi = int(emap[0]), int(emap[L - 1])
     ref = read
-    if cpg_ambiguous:
+    if cpg_ambiguous and cpg_every <= 1:
         ref = read.replace("CG", "XG")
+    elif cpg_ambiguous:
+        parts = read.split("CG")
+        ref = parts[0]
+        for q, part in enumerate(parts[1:]):
+            ref += ("XG" if q % cpg_every == 0 else "CG") + part
     return dict(ref=ref, read=read, events4=events4, events=np.ascontiguousarray(events4[lo:hi]), ax=ax, ay=ay,
                 scale=scale, shift=shift, var=var, event_map=emap)
 

@@ -419,6 +419,12 @@ def test_ring_kernels_ambiguous_positions_every_read_against_the_oracle(oracle, 
     for model, amb_tab, jobs in (
             (cases.MODEL_CPG, {"X": "CE"}, cases.synthetic_jobs(cases.MODEL_CPG, 6, 1400, 20, cpg_ambiguous=True) +
              cases.realistic_anchor_jobs(cases.MODEL_CPG, 2, 1200, 77)),
+            # sparse variant positions (every 9th / 30th CpG cytosine): regions below 1.3 paths per column take the ring kernels'
+            # other instance, which tests per wave whether a second predecessor / successor exists at all (round 4); one batch
+            # holds both kinds
+            (cases.MODEL_CPG, {"X": "CE"}, cases.synthetic_jobs(cases.MODEL_CPG, 3, 1400, 320, cpg_ambiguous=True, cpg_every=9) +
+             cases.synthetic_jobs(cases.MODEL_CPG, 2, 1100, 330, cpg_ambiguous=True, cpg_every=30) +
+             cases.synthetic_jobs(cases.MODEL_CPG, 1, 900, 340, cpg_ambiguous=True) + [None, None]),
             (cases.MODEL_R73, None, None)):
         pm, om = _models(oracle, model)
         amb_p = sa.default_ambig(amb_tab)
@@ -431,6 +437,8 @@ def test_ring_kernels_ambiguous_positions_every_read_against_the_oracle(oracle, 
                     if ref[i] == "C":
                         ref[i] = "L"
                 jobs.append(dict(job, ref="".join(ref)))
+        elif jobs[-1] is None:
+            jobs = jobs[:-2]
         else:
             jobs[-1] = dict(jobs[-1], ref=jobs[-1]["ref"].replace("CG", "XG"))
             jobs[-2] = dict(jobs[-2], ref=jobs[-2]["ref"].replace("CG", "XG"))
