@@ -16,6 +16,7 @@
 #ifndef SIGNALALIGN_HIP_H_
 #define SIGNALALIGN_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

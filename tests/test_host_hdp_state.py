@@ -128,3 +128,16 @@ def test_sample_weights_times_the_restatements_densities(oracle, tmp_path, which
             acc = acc + w[e] * pdf[col[e]]
         assert np.array_equal(acc, want[r]), r
     s.close()
+
+
+def test_public_header_is_self_contained(tmp_path):
+    """include/signalalign_hip.h compiles on its own as C11 and as C++ (round 4: it used size_t without <stddef.h>)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name, cc, std in (("t.c", "gcc", "-std=c11"), ("t.cpp", "g++", "-std=c++17")):
+        src = tmp_path / name
+        src.write_text('#include "signalalign_hip.h"\nint main(void) { sa_pair16_t r = sa_pair16_pack(5, 1, 2, 0, 3); '
+                       'return (int) sa_pair16_unpack(r).x - 1; }\n')
+        subprocess.run([cc, std, "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-o", str(tmp_path / "t.out"), str(src)],
+                       check=True)
+        assert subprocess.run([str(tmp_path / "t.out")]).returncode == 0
