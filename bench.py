@@ -345,6 +345,30 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def lane_use_of_ring_regions(sa, pm, params, job_list, ambig, k, options_of):
+    """Busy-lane fraction of the ring kernels on a sample of reads, from the plan's band geometry (sa_plan_describe: first and
+    last cell of every diagonal) and the path counts of the reference windows: a diagonal of np cell-paths keeps ceil(np / 64)
+    waves busy (waves beyond its last cell-path skip it), so the lanes that hold a cell-path are sum(np) / sum(64 ceil(np / 64))."""
+    tot_np = tot_slots = tot_cells = 0
+    for job in job_list:
+        ref = job["ref"]
+        lx = len(ref) - (k - 1)
+        opt = np.array([options_of(c) for c in ref], dtype=np.int64)
+        logp = np.concatenate([[0.0], np.cumsum(np.log2(opt))])
+        paths = np.ones(lx + 2, dtype=np.int64)              # cell x = 0 is the NULL k-mer; x >= 1 holds window x-1 .. x+k-2
+        paths[1:lx + 1] = np.rint(2.0 ** (logp[k:k + lx] - logp[0:lx])).astype(np.int64)
+        cum = np.concatenate([[0], np.cumsum(paths)])
+        info, reg, rows, segs = sa.plan_describe(pm, params, job, ambig=ambig)
+        d = np.arange(len(rows), dtype=np.int64)             # (one region per read here: diagonals 0 .. N in order)
+        x0 = (d + rows[:, 1]) // 2
+        w = (rows[:, 2] - rows[:, 1]) // 2 + 1
+        np_d = cum[np.clip(x0 + w, 0, lx + 1)] - cum[np.clip(x0, 0, lx + 1)]
+        tot_np += int(np_d.sum()); tot_slots += int((64 * ((np_d + 63) // 64)).sum()); tot_cells += int(w.sum())
+    return {"busy_lane_fraction": tot_np / max(tot_slots, 1), "cell_paths_per_cell": tot_np / max(tot_cells, 1),
+            "cell_paths_per_diagonal": tot_np / max(sum(len(j["ref"]) + len(j["events"]) for j in job_list), 1),
+            "sample": "%d reads; band geometry from sa_plan_describe, path counts from the reference windows" % len(job_list)}
+
+
 def measure(args, ctx, compact=False):
     """One workload through phase 1 (kernels on a resident batch) and phase 2 (fresh batches through the whole boundary);
     returns the result record on rank 0, None elsewhere.  compact: a secondary workload of the default run -- few steps, no
@@ -759,6 +783,13 @@ def measure(args, ctx, compact=False):
                          "all_instructions_per_s": (rec.get("instructions_per_step") or 0.0) / (dom_ms * 1e-3),
                          "wave_wait_frac": rec.get("SQ_WAIT_ANY_frac_of_wave_cycles"),
                          "source": "profiles/instr_mix.json (SQ_INSTS_* per kernel, rocprofv3 --pmc over bench.py --kernels-only)"}
+        lane_use = None
+        if ambig is not None and st0.n_ring_regions > st0.n_strip_regions:
+            try:
+                amb_opts = {"X": 2}
+                lane_use = lane_use_of_ring_regions(sa, pm, params, jobs[:8], ambig, k, lambda c: amb_opts.get(c, 1))
+            except Exception as ex:   # (never the line's problem)
+                lane_use = {"failed": "%s: %s" % (type(ex).__name__, ex)}
         out = {
             "metric": "dp_cell_updates_per_s",
             "value": cells_all / dt,
@@ -784,6 +815,7 @@ def measure(args, ctx, compact=False):
                 "regions_on_register_kernels": "%d/%d" % (st0.n_fast_regions, st0.n_regions),
                 "regions_on_ring_kernels": "%d/%d" % (st0.n_ring_regions - st0.n_strip_regions, st0.n_regions),
                 "regions_on_strip_kernels": "%d/%d" % (st0.n_strip_regions, st0.n_regions),
+                "ring_kernels_lane_use": lane_use,
                 "forward_storage_passes": int(st0.n_chunks),
                 "result_groups": {"resident_batch_phase": int(st0.n_groups), "timed_pipeline": groups_seen[0] or None},
                 "step": "one batch of fresh reads through the whole boundary: sa_batch_create (checks, planning, upload) + run + "
