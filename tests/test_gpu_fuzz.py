@@ -23,7 +23,9 @@ def _jobs_for(model_path, rng, n, ambiguous):
     jobs = []
     for i in range(n):
         n_events = int(rng.choice([3, 9, 25, 60, 150, 400, 900, 1700, 2600]))
-        job = synth.make_read(int(rng.integers(0, 10 ** 6)), n_events, alpha, k, tab, cpg_ambiguous=ambiguous)
+        # (ambiguous reads: every CpG cytosine, or only every 5th / 20th -- sparse variant positions take the ring kernels' other instance)
+        every = int(rng.choice([1, 1, 5, 20])) if ambiguous else 1
+        job = synth.make_read(int(rng.integers(0, 10 ** 6)), n_events, alpha, k, tab, cpg_ambiguous=ambiguous, cpg_every=every)
         keep = rng.random()
         if keep < 0.15:
             m = np.zeros(len(job["ax"]), dtype=bool)            # no anchors at all: the whole matrix is one band
@@ -41,7 +43,7 @@ def _jobs_for(model_path, rng, n, ambiguous):
 
 @pytest.mark.parametrize("model_path,ambiguous,seed", [(cases.MODEL_6MER, False, 11), (cases.MODEL_5MER, False, 12),
                                                         (cases.MODEL_CPG, True, 13)])
-def test_random_shapes(oracle, model_path, ambiguous, seed):
+def test_random_shapes(oracle, model_path, ambiguous, seed, require_strips=True):
     rng = np.random.default_rng(seed)
     alpha, k, t10, tab, jobs = _jobs_for(model_path, rng, 14, ambiguous)
     pm = sa.Model.load(model_path)
@@ -81,7 +83,8 @@ def test_random_shapes(oracle, model_path, ambiguous, seed):
         ref_b.close()
     # thinned and absent anchors leave wide one-path bands: those regions run on the strip kernels (sa_strip.inc), small
     # split rectangles and ragged ends included
-    assert ambiguous or strips_seen > 0
+    # (with the suite's seeds; probes/fuzz_campaign.py walks other seeds, whose reads need not include such a region)
+    assert ambiguous or strips_seen > 0 or not require_strips
 
 
 def test_random_shapes_hdp_and_expectations(oracle):
