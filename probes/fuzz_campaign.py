@@ -22,5 +22,15 @@ for seed in range(first, first + n):
             tb = traceback.extract_tb(ex.__traceback__)[-1]
             print("seed %d %s ambiguous=%s FAILED at %s:%d `%s`: %s" % (seed, os.path.basename(model), amb, os.path.basename(tb.filename),
                                                                          tb.lineno, tb.line, str(ex)[:300]), flush=True)
+for seed in range(first, first + n, 4):   # the HDP / expectation passes (with and without ambiguity letters): every fourth seed
+    try:
+        fz.test_random_shapes_hdp_and_expectations(oracle, seed0=seed)
+        print("seed %d hdp + expectations ok (%.0f s)" % (seed, time.time() - t0), flush=True)
+    except AssertionError as ex:
+        import traceback
+        bad += 1
+        tb = traceback.extract_tb(ex.__traceback__)[-1]
+        print("seed %d hdp + expectations FAILED at %s:%d `%s`: %s" % (seed, os.path.basename(tb.filename), tb.lineno, tb.line,
+                                                                      str(ex)[:300]), flush=True)
 print("fuzz campaign: seeds %d..%d, %d failures" % (first, first + n - 1, bad))
 sys.exit(1 if bad else 0)
