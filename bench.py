@@ -1029,6 +1029,7 @@ def main():
                 "kernel_ms": r2["config"]["kernel_ms"], "pairs_per_event": r2["config"]["pairs_per_event"],
                 "batches_in_flight": r2["config"]["batches_in_flight"], "read_sets_cycled": r2["config"]["read_sets_cycled"],
                 "forward_storage_passes": r2["config"]["forward_storage_passes"],
+                "ring_kernels_lane_use": r2["config"].get("ring_kernels_lane_use"),
                 "dominant_kernel": rf["kernel"], "roofline_frac": rf["frac"], "roofline_frac_by_counters": rf["frac_by_counters"],
                 "roofline_bound": rf["bound"], "stage_ms": rf["stage_ms"], "launches_per_step": rf["launches_per_step"],
                 "issue_frac": (r2.get("issue_roofline") or {}).get("frac"),
