@@ -1975,28 +1975,8 @@ static int batch_prepare_body(sa_batch *b) {
         if (lim > 900) lim = 900;                   // 64 KB of dynamic LDS
         b->ring_cap = (int) (cap < lim ? cap : lim);
     }
-    TRY(batch_build_lists(b));
-    if (trace_c) fprintf(stderr, "[trace] create: launch lists at %.1f ms\n", now_ms_c() - tc0);
-    return SA_OK;
-#undef TRY
-}
-
-static int batch_finish_body(sa_batch *b) {
-    const sa_model_t *m = b->c_m;
-    const sa_params_t *p = &b->c_p;
-    const sa_job_t *jobs = b->c_jobs;
-    const int64_t n_jobs = b->c_n;
-    const unsigned flags = b->flags;
-    const int device = b->device;
-    const bool trace_c = getenv("SA_TRACE") != nullptr;
-    auto now_ms_c = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
-    const double tc0 = b->c_t0;
-    (void) p;
-    HIPCHK(hipSetDevice(device));
-    SaUploader *const UPT = b->c_deferred ? &g_uploader_tail : &g_uploader;
-    struct UseTail { SaUploader *prev; UseTail(SaUploader *u) : prev(tl_uploader) { tl_uploader = u; } ~UseTail() { tl_uploader = prev; } } use_tail_(UPT);
-#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
-    sa_plan_t *pl = b->plan;
+    // (round 4: the model tables, the plan arrays of a host-built plan and the emission constants go up here too -- with
+    // sa_batch_prepare that is while the batch before this one still runs; nothing of it needs the working storage)
     std::unique_lock<std::mutex> up_lock((*UPT).mu);
     TRY((*UPT).bind(device));
     if (trace_c) fprintf(stderr, "[trace] create: upload ring ready at %.1f ms\n", now_ms_c() - tc0);
@@ -2117,6 +2097,26 @@ static int batch_finish_body(sa_batch *b) {
     TRY((*UPT).drain());
     up_lock.unlock();
     if (trace_c) fprintf(stderr, "[trace] create: inputs uploaded at %.1f ms\n", now_ms_c() - tc0);
+    TRY(batch_build_lists(b));
+    if (trace_c) fprintf(stderr, "[trace] create: launch lists at %.1f ms\n", now_ms_c() - tc0);
+    return SA_OK;
+#undef TRY
+}
+
+static int batch_finish_body(sa_batch *b) {
+    const sa_model_t *m = b->c_m;
+    const sa_params_t *p = &b->c_p;
+    const unsigned flags = b->flags;
+    const int device = b->device;
+    const bool trace_c = getenv("SA_TRACE") != nullptr;
+    auto now_ms_c = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double tc0 = b->c_t0;
+    (void) p;
+    HIPCHK(hipSetDevice(device));
+    SaUploader *const UPT = b->c_deferred ? &g_uploader_tail : &g_uploader;
+    struct UseTail { SaUploader *prev; UseTail(SaUploader *u) : prev(tl_uploader) { tl_uploader = u; } ~UseTail() { tl_uploader = prev; } } use_tail_(UPT);
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+    sa_plan_t *pl = b->plan;
     // Working buffers and launch lists.  What does not fit is planned again: a deferred batch's storage budget dates from its first
     // half -- other batches may have taken the memory since --, SA_FLAG_DEVICE_TO_ITSELF is a promise the caller can break, and
     // candidate / result slots (HDP models, low thresholds) are sized after the budget was set.  When an allocation fails, what
