@@ -104,7 +104,17 @@ typedef struct sa_job {
     const int64_t *anchor_y;
     int64_t n_anchors;
     double scale, shift, var; /* sM->scale/shift/var for this read (impl/signalMachine.c:755-757) */
+    unsigned ends;          /* SA_JOB_*_END_NOT_RAGGED bits: the last two arguments of getAlignedPairsUsingAnchors(...,
+                               bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd) (inc/pairwiseAligner.h:406-414,
+                               impl/pairwiseAligner.c:2052-2080), INVERTED so that a zeroed job is signalMachine's call (ragged on
+                               both sides, impl/signalMachine.c:436-437).  A bit set = that end is NOT ragged: the alignment starts
+                               in (0,0) in the match state / ends in (lX,lY) with the end-state transitions
+                               (stateMachine3_startStateProb / _endStateProb, impl/stateMachine.c:1134-1173) and getSplitPoints
+                               keeps the outer rectangle of a gap that is cut at that end (impl/pairwiseAligner.c:1910-1937);
+                               the reference's own known-answer tests call it with (0, 0) (tests/stateMachineTests.c:943-947) */
 } sa_job_t;
+#define SA_JOB_LEFT_END_NOT_RAGGED 1u   /* alignmentHasRaggedLeftEnd == false  */
+#define SA_JOB_RIGHT_END_NOT_RAGGED 2u  /* alignmentHasRaggedRightEnd == false */
 
 /* stIntTuple4(floor(p*1e7), x, y, (char*)pathKmer)  (impl/pairwiseAligner.c:1405-1408) */
 typedef struct sa_pair {
@@ -200,6 +210,12 @@ int64_t sa_kmer_id(const sa_model_t *m, const char *kmer); /* impl/nanopore_hdp.
  *                          model from the rescaled table sa_estimate_params leaves). */
 #define SA_EMISSION_MEAN_ONLY 0
 #define SA_EMISSION_TWO_DIST 1
+/*   SA_EMISSION_TWO_DIST_SCALED_MODEL  emissions_signal_strawManGetKmerEventMatchProb (:659-700): the same two distributions on the
+ *                          event mean AS IT IS -- no descaling, the job's scale / shift / var are not read; the model table was scaled
+ *                          to the read instead (emissions_signal_scaleModel :743-779).  What getStateMachine3 installs (:1757-1765):
+ *                          the emission of the reference's literal-data known answers (tests/stateMachineTests.c:441-698) and of its
+ *                          scaled-model whole-read test (:842-852).  Same kernels and conditions as SA_EMISSION_TWO_DIST. */
+#define SA_EMISSION_TWO_DIST_SCALED_MODEL 2
 int sa_model_set_emission(sa_model_t *m, int emission);
 /* A Gaussian model with the same alphabet, k-mer length, transitions and emission kind as `m` and the emission table `table5`
  * (5 * A^k doubles, copied): the per-read model the reference gets from emissions_signal_scaleNoise (impl/stateMachine.c:721-741)

@@ -1155,10 +1155,11 @@ int64_t sao_align(const sao_model_t *m, const char *ref, int64_t lX, const doubl
     return aligned.n;
 }
 
-int64_t sao_expectations(const sao_model_t *m, const char *ref, int64_t lX, const double *events, int64_t stride,
-                         int64_t lY, const int64_t *ax, const int64_t *ay, int64_t n_anchors, const sao_params_t *p,
-                         const char *const *ambig, double *trans9, double *likelihood, int64_t **assign_kmer,
-                         double **assign_event, sao_stats_t *stats) {
+/* getExpectationsUsingAnchors (impl/pairwiseAligner.c:2164-2184) with its two ragged-end arguments (inc/pairwiseAligner.h:416-429) */
+int64_t sao_expectations_ragged(const sao_model_t *m, const char *ref, int64_t lX, const double *events, int64_t stride,
+                                int64_t lY, const int64_t *ax, const int64_t *ay, int64_t n_anchors, const sao_params_t *p,
+                                const char *const *ambig, int ragged_left, int ragged_right, double *trans9, double *likelihood,
+                                int64_t **assign_kmer, double **assign_event, sao_stats_t *stats) {
     int64_t n_assign = 0, cap_assign = 0;
     expect_t ex;
     memset(&ex, 0, sizeof(ex));
@@ -1172,11 +1173,20 @@ int64_t sao_expectations(const sao_model_t *m, const char *ref, int64_t lX, cons
     ex.n_assign = &n_assign;
     ex.cap_assign = &cap_assign;
     if (stats) memset(stats, 0, sizeof(*stats));
-    int rc = split_and_align(m, ref, lX, events, stride, lY, ax, ay, n_anchors, p, ambig, 1, 1, 1, NULL, &ex,
+    int rc = split_and_align(m, ref, lX, events, stride, lY, ax, ay, n_anchors, p, ambig, ragged_left, ragged_right, 1, NULL, &ex,
                              likelihood, stats);
     if (assign_kmer) *assign_kmer = ak; else free(ak);
     if (assign_event) *assign_event = ae; else free(ae);
     return rc != 0 ? rc : n_assign;
+}
+
+/* as signalMachine calls it: ragged on both sides (impl/signalMachine.c:436-437) */
+int64_t sao_expectations(const sao_model_t *m, const char *ref, int64_t lX, const double *events, int64_t stride,
+                         int64_t lY, const int64_t *ax, const int64_t *ay, int64_t n_anchors, const sao_params_t *p,
+                         const char *const *ambig, double *trans9, double *likelihood, int64_t **assign_kmer,
+                         double **assign_event, sao_stats_t *stats) {
+    return sao_expectations_ragged(m, ref, lX, events, stride, lY, ax, ay, n_anchors, p, ambig, 1, 1, trans9, likelihood,
+                                   assign_kmer, assign_event, stats);
 }
 
 /* tests/stateMachineTests.c:441-565 */

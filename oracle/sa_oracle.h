@@ -134,6 +134,12 @@ int64_t sao_expectations(const sao_model_t *m, const char *ref, int64_t lX, cons
                          double *trans9, double *likelihood, int64_t **assign_refpos, double **assign_event,
                          sao_stats_t *stats);
 
+/* the same with getExpectationsUsingAnchors' two ragged-end arguments (inc/pairwiseAligner.h:416-429); sao_expectations passes 1, 1 */
+int64_t sao_expectations_ragged(const sao_model_t *m, const char *ref, int64_t lX, const double *events, int64_t stride,
+                                int64_t lY, const int64_t *ax, const int64_t *ay, int64_t n_anchors, const sao_params_t *p,
+                                const char *const *ambig256, int ragged_left, int ragged_right, double *trans9,
+                                double *likelihood, int64_t **assign_refpos, double **assign_event, sao_stats_t *stats);
+
 /* Un-banded forward/backward exactly as tests/stateMachineTests.c:441-565 drives it
  * (start/end state vectors, band_construct(no anchors, expansion 2)).
  * diag_totals gets lX+lY+1 values. */

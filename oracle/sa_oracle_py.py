@@ -96,6 +96,10 @@ def lib():
     L.sao_expectations.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, dp, C.c_int64, C.c_int64, ip, ip, C.c_int64,
                                    C.POINTER(Params), C.POINTER(C.c_char_p), dp, dp, C.POINTER(ip),
                                    C.POINTER(dp), C.POINTER(Stats)]
+    L.sao_expectations_ragged.restype = C.c_int64
+    L.sao_expectations_ragged.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, dp, C.c_int64, C.c_int64, ip, ip, C.c_int64,
+                                          C.POINTER(Params), C.POINTER(C.c_char_p), C.c_int, C.c_int, dp, dp, C.POINTER(ip),
+                                          C.POINTER(dp), C.POINTER(Stats)]
     L.sao_kat_unbanded.restype = C.c_int64
     L.sao_kat_unbanded.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, dp, C.c_int64, C.c_int64, C.c_double,
                                    C.POINTER(C.c_char_p), dp, dp, dp, C.POINTER(C.POINTER(Pair))]
@@ -424,7 +428,7 @@ def align(model, ref, events, ax, ay, params=None, ambig=None, ragged=(1, 1), so
     return (res, st) if want_stats else res
 
 
-def expectations(model, ref, events, ax, ay, params=None, ambig=None):
+def expectations(model, ref, events, ax, ay, params=None, ambig=None, ragged=(1, 1)):
     p = params or default_params()
     ev = _events4(events)
     lX = max(len(ref) - (model.k - 1), 0)
@@ -436,9 +440,9 @@ def expectations(model, ref, events, ax, ay, params=None, ambig=None):
     ak = C.POINTER(C.c_int64)()
     ae = C.POINTER(C.c_double)()
     st = Stats()
-    n = lib().sao_expectations(model._h, ref.encode(), lX, _dp(ev), ev.shape[1], ev.shape[0], _ip(axa), _ip(aya),
-                               len(axa), C.byref(p), amb, _dp(trans), C.byref(lik), C.byref(ak), C.byref(ae),
-                               C.byref(st))
+    n = lib().sao_expectations_ragged(model._h, ref.encode(), lX, _dp(ev), ev.shape[1], ev.shape[0], _ip(axa), _ip(aya),
+                                      len(axa), C.byref(p), amb, int(ragged[0]), int(ragged[1]), _dp(trans), C.byref(lik),
+                                      C.byref(ak), C.byref(ae), C.byref(st))
     if n < 0:
         raise RuntimeError("sao_expectations failed: %d" % n)
     pos = np.array([ak[i] for i in range(n)], dtype=np.int64)

@@ -37,7 +37,10 @@ class Job(C.Structure):
     _fields_ = [("ref", C.c_char_p), ("ref_len", C.c_int64), ("events", C.POINTER(C.c_double)),
                 ("event_stride", C.c_int64), ("n_events", C.c_int64), ("anchor_x", C.POINTER(C.c_int64)),
                 ("anchor_y", C.POINTER(C.c_int64)), ("n_anchors", C.c_int64), ("scale", C.c_double),
-                ("shift", C.c_double), ("var", C.c_double)]
+                ("shift", C.c_double), ("var", C.c_double), ("ends", C.c_uint)]
+
+
+JOB_LEFT_END_NOT_RAGGED, JOB_RIGHT_END_NOT_RAGGED = 1, 2   # sa_job_t.ends (alignmentHasRaggedLeftEnd / RightEnd, inverted)
 
 
 class Pair(C.Structure):
@@ -290,7 +293,8 @@ class Model:
 
 
 def _make_jobs(jobs):
-    """jobs: list of dicts(ref:str, events: (n,) or (n,4) float64, ax, ay, scale, shift, var)."""
+    """jobs: list of dicts(ref:str, events: (n,) or (n,4) float64, ax, ay, scale, shift, var[, ragged=(left, right)]);
+    ragged: the last two arguments of getAlignedPairsUsingAnchors, default (1, 1) as signalMachine passes them."""
     n = len(jobs)
     arr = (Job * max(n, 1))()
     keep = []
@@ -301,8 +305,10 @@ def _make_jobs(jobs):
         ay = np.ascontiguousarray(j["ay"], dtype=np.int64)
         rb = j["ref"].encode() if isinstance(j["ref"], str) else j["ref"]
         keep.append((ev, ax, ay, rb))
+        rl, rr = j.get("ragged", (1, 1))
         arr[i] = Job(rb, len(rb), _dp(ev), stride, ev.shape[0], _ip(ax), _ip(ay), len(ax), j.get("scale", 1.0),
-                     j.get("shift", 0.0), j.get("var", 1.0))
+                     j.get("shift", 0.0), j.get("var", 1.0),
+                     (0 if rl else JOB_LEFT_END_NOT_RAGGED) | (0 if rr else JOB_RIGHT_END_NOT_RAGGED))
     return arr, keep
 
 

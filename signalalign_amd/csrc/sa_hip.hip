@@ -46,7 +46,7 @@ struct DevModel {
     long long pow_km1;
     int n_alpha;
     int hdp;
-    int emission;           // 0: MeanOnly (what signalMachine installs); 1: the two-distribution emission (sa_model_set_emission)
+    int emission;           // 0: MeanOnly (what signalMachine installs); 1 / 2: the two-distribution emission with / without descaling (sa_model_set_emission)
     const double *noise3;   // emission 1: per k-mer noise mean, noise lambda, log(lambda)  (columns 2 and 4 of the model table)
     const int *hdp_slot;    // per k-mer: row of y/slope tables of the first observed ancestor, -1 if none
     const double *hdp_y, *hdp_slope, *hdp_grid;
@@ -138,9 +138,11 @@ __device__ __forceinline__ double emit_ref(const DevModel &m, const ReadPar &rp,
     const double *t = m.tab6 + 6ll * id;
     double mu = t[0];
     double en = (e + rp.var * mu - rp.scale * mu - rp.shift) / rp.var;
-    if (m.emission == 1) {
+    if (m.emission != 0) {
         // emissions_signal_strawManGetKmerEventMatchProbWithDescaling (impl/stateMachine.c:607-650): logGaussPdf of the descaled
-        // mean + logInvGaussPdf of the event noise (:296-306, :320-330), in the reference's order of operations
+        // mean + logInvGaussPdf of the event noise (:296-306, :320-330), in the reference's order of operations; emission 2 is
+        // emissions_signal_strawManGetKmerEventMatchProb (:659-700): the same on the event mean as it is (the MODEL was scaled)
+        if (m.emission == 2) en = e;
         double sd = match ? t[1] : t[3];
         double c = match ? t[2] : t[4];  // -log(sqrt(2 pi)) - log(sd); -inf when sd == 0
         double a = (en - mu) / sd;
@@ -2041,7 +2043,7 @@ static int batch_prepare_body(sa_batch *b) {
             tab6[6 * i + 5] = 0.0;
         }
         TRY(upload(&b->d_tab6, tab6.data(), (long long) tab6.size()));
-        if (m->emission == 1) {   // noise columns of the table, and every event's noise with its logarithm (C library's log)
+        if (m->emission != 0) {   // noise columns of the table, and every event's noise with its logarithm (C library's log)
             if (m->hdp) return SA_EUNSUPPORTED;
             std::vector<double> nz((size_t) m->n_kmers * 3);
             for (long long i = 0; i < m->n_kmers; i++) {
@@ -2057,7 +2059,7 @@ static int batch_prepare_body(sa_batch *b) {
                 const sa_jobinfo_t *J = &pl->jobs[j];
                 for (int64_t i = 0; i < J->n_events; i++) {
                     double n = jb->events[i * jb->event_stride + 1];
-                    if (n == 0) n = 0.000000001;   // (impl/stateMachine.c:619-621)
+                    if (n == 0 && m->emission == SA_EMISSION_TWO_DIST) n = 0.000000001;   // (impl/stateMachine.c:619-621; :659-700 has no such guard)
                     evn[(size_t) (2 * (J->ev_off + i))] = n;
                     evn[(size_t) (2 * (J->ev_off + i) + 1)] = log(n);
                 }

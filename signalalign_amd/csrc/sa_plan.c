@@ -215,8 +215,9 @@ int sa_model_clone_with_table(sa_model_t **out, const sa_model_t *m, const doubl
 }
 
 int sa_model_set_emission(sa_model_t *m, int emission) {
-    if (!m || (emission != SA_EMISSION_MEAN_ONLY && emission != SA_EMISSION_TWO_DIST)) return SA_EINVAL;
-    if (emission == SA_EMISSION_TWO_DIST && m->hdp) return SA_EUNSUPPORTED;
+    if (!m || (emission != SA_EMISSION_MEAN_ONLY && emission != SA_EMISSION_TWO_DIST && emission != SA_EMISSION_TWO_DIST_SCALED_MODEL))
+        return SA_EINVAL;
+    if (emission != SA_EMISSION_MEAN_ONLY && m->hdp) return SA_EUNSUPPORTED;
     m->emission = emission;
     return SA_OK;
 }
@@ -885,8 +886,12 @@ static int plan_job(sa_plan_t *pl, int64_t j, const sa_job_t *jb, const char *co
     const sa_model_t *m = pl->model;
     const sa_params_t *p = &pl->params;
     if (!jb->ref || jb->ref_len < 0 || jb->n_events < 0 || jb->n_anchors < 0 || (jb->n_events && !jb->events) ||
-        (jb->n_anchors && (!jb->anchor_x || !jb->anchor_y)) || !(jb->var > 0.0))
+        (jb->n_anchors && (!jb->anchor_x || !jb->anchor_y)) || !(jb->var > 0.0) ||
+        (jb->ends & ~(SA_JOB_LEFT_END_NOT_RAGGED | SA_JOB_RIGHT_END_NOT_RAGGED)))
         return SA_EINVAL;
+    /* alignmentHasRaggedLeftEnd / alignmentHasRaggedRightEnd of getAlignedPairsUsingAnchors (impl/pairwiseAligner.c:2052-2080);
+     * signalMachine passes 1, 1 (impl/signalMachine.c:436-437) = a zeroed `ends` */
+    const int ragged_l = !(jb->ends & SA_JOB_LEFT_END_NOT_RAGGED), ragged_r = !(jb->ends & SA_JOB_RIGHT_END_NOT_RAGGED);
     int64_t lX = jb->ref_len == 0 ? 0 : jb->ref_len - (m->k - 1); /* sequence_correctSeqLength */
     if (lX < 0) lX = 0;
     int64_t lY = jb->n_events;
@@ -919,9 +924,8 @@ static int plan_job(sa_plan_t *pl, int64_t j, const sa_job_t *jb, const char *co
         free(rects); free(sx); free(sy);
         return SA_ENOMEM;
     }
-    /* signalMachine always calls with ragged left and right ends (impl/signalMachine.c:436-437) */
-    int64_t nr = split_regions(jb->anchor_x, jb->anchor_y, jb->n_anchors, lX, lY, p->split_matrix_bigger_than_this, 1, 1,
-                               rects);
+    int64_t nr = split_regions(jb->anchor_x, jb->anchor_y, jb->n_anchors, lX, lY, p->split_matrix_bigger_than_this, ragged_l,
+                               ragged_r, rects);
     int rc = SA_OK;
     int64_t a = 0;
     for (int64_t i = 0; i < nr && rc == SA_OK; i++) {
@@ -931,7 +935,9 @@ static int plan_job(sa_plan_t *pl, int64_t j, const sa_job_t *jb, const char *co
             sx[t - a0] = jb->anchor_x[t] - rects[i].x1;
             sy[t - a0] = jb->anchor_y[t] - rects[i].y1;
         }
-        rc = add_region(pl, j, jb, rects[i], sx, sy, a - a0, 1, 1, ambig, pl->jobs[j].ev_off);
+        /* sub-regions behind / in front of a cut are ragged there whatever the caller said (impl/pairwiseAligner.c:2001-2002) */
+        rc = add_region(pl, j, jb, rects[i], sx, sy, a - a0, ragged_l || i > 0, ragged_r || i < nr - 1, ambig,
+                        pl->jobs[j].ev_off);
     }
     free(rects); free(sx); free(sy);
     pl->jobs[j].n_regions = (int32_t) (pl->n_regions - pl->jobs[j].region_off);
@@ -1001,7 +1007,7 @@ static void *count_worker(void *arg) {
         rect_t *rects = malloc(sizeof(rect_t) * (size_t) (jb->n_anchors + 2));
         if (!rects) { w->rc = SA_ENOMEM; return NULL; }
         const int64_t nr = split_regions(jb->anchor_x, jb->anchor_y, jb->n_anchors, lX, lY, p->split_matrix_bigger_than_this,
-                                         1, 1, rects);
+                                         !(jb->ends & SA_JOB_LEFT_END_NOT_RAGGED), !(jb->ends & SA_JOB_RIGHT_END_NOT_RAGGED), rects);
         for (int64_t i = 0; i < nr; i++) {
             const int64_t rX = rects[i].x2 - rects[i].x1, rY = rects[i].y2 - rects[i].y1, N = rX + rY;
             if (N == 0) continue;

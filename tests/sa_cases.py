@@ -51,7 +51,7 @@ def thin_anchors_like_a_guide_alignment(job_list, trim=14):
 
 def oracle_pairs(oracle, omodel, job, params, ambig=None):
     omodel.set_read_params(job["scale"], job["shift"], job["var"])
-    return oracle.align(omodel, job["ref"], job["events"], job["ax"], job["ay"], params, ambig=ambig)
+    return oracle.align(omodel, job["ref"], job["events"], job["ax"], job["ay"], params, ambig=ambig, ragged=job.get("ragged", (1, 1)))
 
 
 def oracle_params(oracle, p):

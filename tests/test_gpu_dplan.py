@@ -26,7 +26,8 @@ def _mixed_jobs():
     jobs.append(dict(ref=base["ref"][:60], events=base["events"][:0], ax=[], ay=[], scale=1.0, shift=0.0, var=1.0))   # no events
     jobs.append(dict(ref=base["ref"][:k - 1], events=base["events"][:9], ax=[], ay=[], scale=1.0, shift=0.0, var=1.0))  # no k-mers
     jobs.append(synth.make_read(77, 12000, alpha, k, tab))                                                         # 12 segments
-    return jobs
+    # getAlignedPairsUsingAnchors' ragged-end booleans (sa_job_t.ends): three reads in four with an end that is not ragged
+    return [dict(j, ragged=(i & 1, (i >> 1) & 1)) for i, j in enumerate(jobs)]
 
 
 def test_device_plan_equals_host_plan(monkeypatch):

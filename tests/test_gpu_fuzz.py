@@ -37,6 +37,9 @@ def _jobs_for(model_path, rng, n, ambiguous):
             lo = int(rng.integers(5, len(job["ax"]) // 2))       # a long anchor-free stretch
             m[lo:lo + int(rng.integers(20, len(job["ax"]) // 3))] = False
         job["ax"], job["ay"] = job["ax"][m], job["ay"][m]
+        # getAlignedPairsUsingAnchors' two ragged-end booleans (sa_job_t.ends): every combination, (1, 1) -- signalMachine's -- for
+        # one job in four (a function of the job's index: the seeds' reads stay what they were)
+        job["ragged"] = (i & 1, (i >> 1) & 1)
         jobs.append(job)
     return alpha, k, t10, tab, jobs
 
@@ -123,7 +126,7 @@ def test_random_shapes_hdp_and_expectations(oracle, seed0=31):
         gt, gl, _ = sa.expect_batch(pg, p, jobs, flags=sa.FLAG_FORCE_GENERIC)
         for j, job in enumerate(jobs):
             og.set_read_params(job["scale"], job["shift"], job["var"])
-            t, l, _, _, _ = oracle.expectations(og, job["ref"], job["events"], job["ax"], job["ay"], op)
+            t, l, _, _, _ = oracle.expectations(og, job["ref"], job["events"], job["ax"], job["ay"], op, ragged=job["ragged"])
             np.testing.assert_allclose(ft[j], t, rtol=1e-9, atol=1e-10)
             np.testing.assert_allclose(gt[j], t, rtol=1e-9, atol=1e-10)
             assert abs(fl[j] - l) <= 1e-12 * max(abs(l), 1.0) and abs(gl[j] - l) <= 1e-12 * max(abs(l), 1.0)
@@ -155,7 +158,7 @@ def test_random_shapes_hdp_and_expectations(oracle, seed0=31):
         gt, gl, _ = sa.expect_batch(pc, p, jobs, ambig=amb_p, flags=sa.FLAG_FORCE_GENERIC)
         for j, job in enumerate(jobs):
             oc.set_read_params(job["scale"], job["shift"], job["var"])
-            t, l, _, _, _ = oracle.expectations(oc, job["ref"], job["events"], job["ax"], job["ay"], op, ambig=amb_o)
+            t, l, _, _, _ = oracle.expectations(oc, job["ref"], job["events"], job["ax"], job["ay"], op, ambig=amb_o, ragged=job["ragged"])
             np.testing.assert_allclose(ft[j], t, rtol=1e-9, atol=1e-10)
             np.testing.assert_allclose(gt[j], t, rtol=1e-9, atol=1e-10)
             assert abs(fl[j] - l) <= 1e-12 * max(abs(l), 1.0) and abs(gl[j] - l) <= 1e-12 * max(abs(l), 1.0)

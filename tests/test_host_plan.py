@@ -103,6 +103,37 @@ def test_split_regions_large_gap(oracle):
     assert len(exp) == 2 and np.array_equal(regions, exp)
 
 
+def test_split_regions_follow_the_ragged_end_flags():
+    # tests/signalPairwiseAlignerTest.c:363-432 test_getSplitPoints, the reference's literal cases, through the PRODUCT's host
+    # planner (sa_job_t.ends = getAlignedPairsUsingAnchors' two ragged-end booleans, inverted): no oracle involved
+    alpha, k, t10, tab = synth.parse_model_table(cases.MODEL_6MER)
+    m = sa.Model.create(alpha, k, t10, tab)
+    p = sa.default_params(split=2000 * 2000)
+    rng = np.random.default_rng(3)
+
+    def regions(lX, lY, ax, ay, ragged):
+        job = dict(ref="".join(rng.choice(list("ACGT"), lX + k - 1)), events=np.full(lY, 80.0), ax=ax, ay=ay, ragged=ragged)
+        return sa.plan_describe(m, p, job)[1].tolist()
+
+    assert regions(3000, 1000, [], [], (0, 0)) == [[0, 0, 3000, 1000]]
+    lX, lY = 20000, 25000
+    assert regions(lX, lY, [], [], (1, 1)) == []
+    assert regions(lX, lY, [], [], (1, 0)) == [[18000, 23000, lX, lY]]
+    assert regions(lX, lY, [], [], (0, 1)) == [[0, 0, 2000, 2000]]
+    assert regions(lX, lY, [], [], (0, 0)) == [[0, 0, 2000, 2000], [18000, 23000, lX, lY]]
+    ax = [2000, 4002, 5000, 8000, 9000, 10000, 15000, 16000]
+    ay = [2000, 4001, 5000, 6000, 9000, 14000, 15000, 16000]
+    assert regions(lX, lY, ax, ay, (0, 0)) == [[0, 0, 3001, 3001], [3002, 3001, 9500, 11001], [9501, 12000, 12001, 14500],
+                                               [13000, 14501, 18000, 18001], [18001, 23000, 20000, 25000]]
+    # the default (a zeroed `ends`) is signalMachine's call, ragged on both sides: the rectangle behind the last cut goes (the gap
+    # behind the last anchor is cut), the first one stays (the gap in front of the FIRST anchor, 2000 x 2000, is not cut)
+    assert regions(lX, lY, ax, ay, (1, 1)) == [[0, 0, 3001, 3001], [3002, 3001, 9500, 11001], [9501, 12000, 12001, 14500],
+                                               [13000, 14501, 18000, 18001]]
+    assert regions(lX, lY, [4000] + ax[1:], [4000] + ay[1:], (1, 0))[0] == [2000, 2000, 9500, 11001]   # (the first anchor at 4000, 4000: its gap is cut and the ragged left end drops the rectangle in front of it)
+    job = dict(ref="A" * 30, events=np.full(9, 80.0), ax=[], ay=[])
+    assert sa.plan_describe(m, p, job)[0].n_regions == sa.plan_describe(m, p, dict(job, ragged=(1, 1)))[0].n_regions == 1
+
+
 def test_anchor_helpers_match_oracle(oracle):
     rng = np.random.default_rng(3)
     for trial in range(20):
