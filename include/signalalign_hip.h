@@ -505,6 +505,70 @@ int sa_hdp_state_sample_weights(const sa_hdp_state_t *s, int64_t **row_start, in
 int sa_hdp_finalize_distributions(const double *grid, int64_t grid_length, const double *sum, int64_t n_rows, int64_t samples,
                                   int device, double *y_out, double *slope_out);
 
+/* ---- the expectations objects of the EM loop, host only -----------------------------------------
+ * Hmm / ContinuousPairHmm / HdpHmm (inc/stateMachine.h:64-83, inc/continuousHmm.h:8-75, impl/continuousHmm.c): what
+ * getExpectationsUsingAnchors accumulates into, the .expectations files trainModels.py exchanges, and the M-step.
+ *   sa_hmm_create            hmmContinuous_getExpectationsHmm (:841-856): an empty accumulator that "fits" the model -- its event
+ *                            model loaded (hmmContinuous_loadEventModel), transitions at the transition pseudocount, and for
+ *                            SA_HMM_GAUSSIAN (continuousPairHmm_construct :83-144) k-mer posteriors at the emission pseudocount;
+ *                            SA_HMM_HDP (hdpHmm_constructEmpty :522-569) carries the assignment threshold and the assignment lists
+ *   sa_hmm_add_expectations  adds one read's transition sums and likelihood -- sa_expect_batch's trans9_out / likelihood_out --
+ *                            as hmm_addToTransitionsExpectation (:147) and `hmm->likelihood +=` do cell by cell
+ *   sa_hmm_add_emission_expectation  continuousPairHmm_addToEmissionExpectation (:159-168)
+ *   sa_hmm_add_assignment    hdpHmm_addToAssignment (:510-514): `kmer` points at k characters (not terminated)
+ *   sa_hmm_write             continuousPairHmm_writeToFile (:353-407) / hdpHmm_writeToFile (:571-628), byte for byte; a NaN
+ *                            transition leaves an empty file (hmmContinuous_checkTransitions)
+ *   sa_hmm_load              continuousPairHmm_loadFromFile (:409-507) / hdpHmm_loadFromFile (:630-785): header, transitions and
+ *                            likelihood, event model (the reference reads no further for a ContinuousPairHmm: the accumulators of
+ *                            a loaded object are empty, at the pseudocounts), and for SA_HMM_HDP the two assignment lines.  What the
+ *                            reference answers with st_errAbort is SA_EIO here
+ *   sa_hmm_add_expectations_file  HMM.add_expectations_file (src/signalalign/hiddenMarkovModel.py:424-486), trainModels.py's accumulating
+ *                            reader: a read's .expectations file added to this object -- transitions and likelihood, and all of a
+ *                            ContinuousPairHmm file's accumulator lines (expectations and posteriors summed, the mask or-ed) or an
+ *                            HdpHmm file's assignments; an empty or malformed file adds nothing (SA_EIO)
+ *   sa_hmm_normalize         continuousPairHmm_normalize (:282-308) = hmmDiscrete_normalizeTransitions (impl/discreteHmm.c:125-137)
+ *                            + the event model of every observed k-mer from its expectations; SA_HMM_HDP: the transitions
+ *   sa_hmm_load_into_model   the M-step, continuousPairHmm_loadTransitionsIntoStateMachine (:320-338) and (SA_HMM_GAUSSIAN, Gaussian
+ *                            model) continuousPairHmm_loadEmissionsIntoStateMachine (:340-351).  gapY -> gapX stays at log 0 as in a
+ *                            machine loaded from a .model file, and the gapY table stays 1.75 x the match sd (the reference's :347
+ *                            writes it to the wrong index): signalalign_amd/csrc/sa_hmm.c says why.  No batch created from `m`
+ *                            may be alive across the call.
+ * Views stay valid until the next call that adds an assignment or destroys the object. */
+typedef struct sa_hmm sa_hmm_t;
+#define SA_HMM_GAUSSIAN 0   /* ContinuousPairHmm, StateMachineType threeState    */
+#define SA_HMM_HDP 1        /* HdpHmm, threeStateHdp                             */
+typedef struct sa_hmm_view {
+    int type, n_states, n_alpha, k;
+    char alphabet[64];
+    int64_t n_kmers;
+    double *transitions;            /* 9: from * 3 + to (match, gapX, gapY), linear space        */
+    double *likelihood;
+    double *event_model;            /* 5 per k-mer                                               */
+    double *event_expectations;     /* SA_HMM_GAUSSIAN: 2 per k-mer                              */
+    double *posteriors;             /* SA_HMM_GAUSSIAN: per k-mer                                */
+    uint8_t *observed;              /* SA_HMM_GAUSSIAN: per k-mer                                */
+    double threshold;               /* SA_HMM_HDP                                                */
+    int64_t n_assignments;          /* SA_HMM_HDP                                                */
+    const double *assignment_events;
+    const char *assignment_kmers;   /* k characters per assignment, not terminated               */
+    int has_model;
+} sa_hmm_view_t;
+int sa_hmm_create(sa_hmm_t **out, const sa_model_t *m, int type, double threshold, double transitions_pseudocount,
+                  double emissions_pseudocount);
+void sa_hmm_destroy(sa_hmm_t *h);
+int sa_hmm_view(sa_hmm_t *h, sa_hmm_view_t *v);
+int sa_hmm_set_event_model(sa_hmm_t *h, const double *table5);
+int sa_hmm_add_expectations(sa_hmm_t *h, const double *trans9, double likelihood);
+int sa_hmm_add_emission_expectation(sa_hmm_t *h, int64_t kmer_index, double mean, double p);
+int sa_hmm_add_assignment(sa_hmm_t *h, const char *kmer, double event_mean);
+int sa_hmm_write(const sa_hmm_t *h, const char *path);
+int sa_hmm_load(sa_hmm_t **out, const char *path, int type, double transitions_pseudocount, double emissions_pseudocount);
+int sa_hmm_add_expectations_file(sa_hmm_t *h, const char *path);
+int sa_hmm_normalize(sa_hmm_t *h);
+int sa_hmm_load_into_model(sa_model_t *m, const sa_hmm_t *h);
+/* the model's transitions as the ten tokens of a .model file's second line (linear space; tokens 5, 7 and 9 are 0) */
+int sa_model_transitions10(const sa_model_t *m, double *out10);
+
 int sa_device_count(void);
 /* HBM of `device`: bytes free (what the library's caching allocator holds counts as free) and in total; a caller that keeps
  * several batches in flight sizes its pipeline with this (sa_batch_stats_t.f_bytes is the bulk of a batch) */

@@ -85,7 +85,20 @@ EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alp
            "sa_batch_job_cells", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_expect_last_stats", "sa_plan_describe", "sa_plan_digest",
            "sa_plan_check_path_records", "sa_dplan_compare",
            "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_pool_configure", "sa_host_alloc", "sa_host_free", "sa_pair_roundtrip", "sa_fasta_subsequence", "sa_format_f6", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_device_memory", "sa_strerror", "sa_hdp_state_load", "sa_hdp_state_write", "sa_hdp_state_info", "sa_hdp_state_free", "sa_hdp_state_distr_sample", "sa_hdp_state_sample_weights", "sa_hdp_finalize_distributions",
+           "sa_hmm_create", "sa_hmm_destroy", "sa_hmm_view", "sa_hmm_set_event_model", "sa_hmm_add_expectations",
+           "sa_hmm_add_emission_expectation", "sa_hmm_add_assignment", "sa_hmm_add_expectations_file", "sa_hmm_write", "sa_hmm_load", "sa_hmm_normalize",
+           "sa_hmm_load_into_model", "sa_model_transitions10",
            "sa_version", "sa_free"]
+
+
+class HmmView(C.Structure):
+    """sa_hmm_view_t (include/signalalign_hip.h)"""
+    _fields_ = [("type", C.c_int), ("n_states", C.c_int), ("n_alpha", C.c_int), ("k", C.c_int), ("alphabet", C.c_char * 64),
+                ("n_kmers", C.c_int64), ("transitions", C.POINTER(C.c_double)), ("likelihood", C.POINTER(C.c_double)),
+                ("event_model", C.POINTER(C.c_double)), ("event_expectations", C.POINTER(C.c_double)),
+                ("posteriors", C.POINTER(C.c_double)), ("observed", C.POINTER(C.c_uint8)), ("threshold", C.c_double),
+                ("n_assignments", C.c_int64), ("assignment_events", C.POINTER(C.c_double)),
+                ("assignment_kmers", C.POINTER(C.c_char)), ("has_model", C.c_int)]
 
 
 class HdpStateInfo(C.Structure):
@@ -139,6 +152,20 @@ def lib():
     L.sa_model_table5.argtypes = [C.c_void_p]
     L.sa_model_set_to_hdp_expected_values.argtypes = [C.c_void_p]
     L.sa_model_set_emission.argtypes = [C.c_void_p, C.c_int]
+    L.sa_model_transitions10.argtypes = [C.c_void_p, dp]
+    L.sa_hmm_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
+    L.sa_hmm_destroy.argtypes = [C.c_void_p]
+    L.sa_hmm_destroy.restype = None
+    L.sa_hmm_view.argtypes = [C.c_void_p, C.POINTER(HmmView)]
+    L.sa_hmm_set_event_model.argtypes = [C.c_void_p, dp]
+    L.sa_hmm_add_expectations.argtypes = [C.c_void_p, dp, C.c_double]
+    L.sa_hmm_add_emission_expectation.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_double]
+    L.sa_hmm_add_assignment.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+    L.sa_hmm_write.argtypes = [C.c_void_p, C.c_char_p]
+    L.sa_hmm_load.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.c_double, C.c_double]
+    L.sa_hmm_normalize.argtypes = [C.c_void_p]
+    L.sa_hmm_add_expectations_file.argtypes = [C.c_void_p, C.c_char_p]
+    L.sa_hmm_load_into_model.argtypes = [C.c_void_p, C.c_void_p]
     L.sa_kmer_id.restype = C.c_int64
     L.sa_kmer_id.argtypes = [C.c_void_p, C.c_char_p]
     L.sa_default_ambig.argtypes = [C.POINTER(C.c_char_p)]
@@ -272,6 +299,12 @@ class Model:
 
     def kmer_id(self, kmer):
         return lib().sa_kmer_id(self._h, kmer.encode())
+
+    def transitions10(self):
+        """the model's transitions as the ten tokens of a .model file's second line (linear space)"""
+        out = np.zeros(10, dtype=np.float64)
+        _chk(lib().sa_model_transitions10(self._h, _dp(out)), "sa_model_transitions10")
+        return out
 
     def set_emission(self, emission):
         """0: MeanOnly (signalMachine's), 1: the two-distribution emission (sa_model_set_emission)."""
@@ -738,6 +771,115 @@ def device_memory(device=0):
     f, t = C.c_int64(), C.c_int64()
     _chk(lib().sa_device_memory(device, C.byref(f), C.byref(t)), "sa_device_memory")
     return f.value, t.value
+
+
+HMM_GAUSSIAN, HMM_HDP = 0, 1
+
+
+class Hmm:
+    """sa_hmm_t: the expectations object of the EM loop (Hmm / ContinuousPairHmm / HdpHmm, impl/continuousHmm.c).  The numpy arrays
+    `transitions`, `event_model`, `event_expectations`, `posteriors`, `observed` are VIEWS of the object's own storage."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def create(cls, model, kind=HMM_GAUSSIAN, threshold=0.0, transitions_pseudocount=0.0, emissions_pseudocount=0.0):
+        h = C.c_void_p()
+        _chk(lib().sa_hmm_create(C.byref(h), model._h, kind, threshold, transitions_pseudocount, emissions_pseudocount),
+             "sa_hmm_create")
+        return cls(h)
+
+    @classmethod
+    def load(cls, path, kind=HMM_GAUSSIAN, transitions_pseudocount=0.0, emissions_pseudocount=0.0):
+        h = C.c_void_p()
+        _chk(lib().sa_hmm_load(C.byref(h), os.fsencode(path), kind, transitions_pseudocount, emissions_pseudocount), "sa_hmm_load")
+        return cls(h)
+
+    def view(self):
+        v = HmmView()
+        _chk(lib().sa_hmm_view(self._h, C.byref(v)), "sa_hmm_view")
+        return v
+
+    def _arr(self, ptr, n, dtype=np.float64):
+        if not ptr or n == 0:
+            return np.zeros(0, dtype=dtype)
+        return np.ctypeslib.as_array(ptr, shape=(int(n),))
+
+    @property
+    def transitions(self):
+        return self._arr(self.view().transitions, 9).reshape(3, 3)
+
+    @property
+    def likelihood(self):
+        return float(self.view().likelihood[0])
+
+    @property
+    def event_model(self):
+        v = self.view()
+        return self._arr(v.event_model, 5 * v.n_kmers).reshape(-1, 5)
+
+    @property
+    def event_expectations(self):
+        v = self.view()
+        return self._arr(v.event_expectations, 2 * v.n_kmers).reshape(-1, 2)
+
+    @property
+    def posteriors(self):
+        v = self.view()
+        return self._arr(v.posteriors, v.n_kmers)
+
+    @property
+    def observed(self):
+        v = self.view()
+        return self._arr(v.observed, v.n_kmers, np.uint8)
+
+    def assignments(self):
+        """(k-mers as a list of str, event means as an array) of an HdpHmm"""
+        v = self.view()
+        n, k = int(v.n_assignments), int(v.k)
+        if n == 0:
+            return [], np.zeros(0)
+        raw = C.string_at(v.assignment_kmers, n * k).decode()
+        return [raw[i * k:(i + 1) * k] for i in range(n)], np.ctypeslib.as_array(v.assignment_events, shape=(n,)).copy()
+
+    def set_event_model(self, table5):
+        t = np.ascontiguousarray(table5, dtype=np.float64)
+        _chk(lib().sa_hmm_set_event_model(self._h, _dp(t)), "sa_hmm_set_event_model")
+
+    def add_expectations(self, trans9, likelihood):
+        t = np.ascontiguousarray(trans9, dtype=np.float64).reshape(-1)
+        _chk(lib().sa_hmm_add_expectations(self._h, _dp(t), float(likelihood)), "sa_hmm_add_expectations")
+
+    def add_emission_expectation(self, kmer_index, mean, p):
+        _chk(lib().sa_hmm_add_emission_expectation(self._h, int(kmer_index), float(mean), float(p)), "sa_hmm_add_emission_expectation")
+
+    def add_assignment(self, kmer, event_mean):
+        _chk(lib().sa_hmm_add_assignment(self._h, kmer.encode(), float(event_mean)), "sa_hmm_add_assignment")
+
+    def write(self, path):
+        _chk(lib().sa_hmm_write(self._h, os.fsencode(path)), "sa_hmm_write")
+
+    def add_expectations_file(self, path):
+        """HMM.add_expectations_file: a read's .expectations file added to this object's accumulators"""
+        _chk(lib().sa_hmm_add_expectations_file(self._h, os.fsencode(path)), "sa_hmm_add_expectations_file")
+
+    def normalize(self):
+        _chk(lib().sa_hmm_normalize(self._h), "sa_hmm_normalize")
+
+    def load_into_model(self, model):
+        _chk(lib().sa_hmm_load_into_model(model._h, self._h), "sa_hmm_load_into_model")
+
+    def close(self):
+        if self._h:
+            lib().sa_hmm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class HdpState:

@@ -277,48 +277,32 @@ static void output_alignment(int64_t fmt, const char *f1, const char *f2, const 
     }
 }
 
-/* continuousPairHmm_writeToFile (impl/continuousHmm.c:352-408) / hdpHmm_writeToFile (:572-623) */
-static void write_expectations(const char *path, const strand_model_t *sm, const sa_strand_params_t *npp, int hdp,
+/* continuousPairHmm_writeToFile (impl/continuousHmm.c:352-408) / hdpHmm_writeToFile (:572-623): the library's Hmm object
+ * (sa_hmm_*), filled with what sa_expect_batch returned for the read.  `trans` already holds the transition pseudocount. */
+static void write_expectations(const char *path, const strand_model_t *sm, const sa_strand_params_t *npp, int hdp, double threshold,
                                const double *trans, double lik, const sa_job_t *job, const sa_assignment_t *as,
                                int64_t n_as) {
-    for (int i = 0; i < 9; i++)
-        if (isnan(trans[i])) { /* hmmContinuous_checkTransitions: an empty file is left behind */
-            fprintf(stderr, "GOT NaN TRANS\n");
-            FILE *f0 = fopen(path, "w");
-            if (f0) fclose(f0);
-            return;
-        }
-    FILE *fh = fopen(path, "w");
-    if (!fh) die("signalMachine: cannot open %s for writing", path);
+    sa_hmm_t *h = NULL;
+    int rc = sa_hmm_create(&h, sm->model, hdp ? SA_HMM_HDP : SA_HMM_GAUSSIAN, threshold, 0.0, 0.001 /* emissionsPseudocount, :785 */);
+    if (rc != SA_OK) die("signalMachine: cannot build the expectations object: %s", sa_strerror(rc));
     int64_t n_kmers = 1;
     for (int i = 0; i < sm->k; i++) n_kmers *= sm->n_alpha;
-    fprintf(fh, "%d\t%d\t%s\t%d\t\n", 3, sm->n_alpha, sm->alphabet, sm->k);
-    for (int i = 0; i < 9; i++) fprintf(fh, "%f\t", trans[i]);
-    fprintf(fh, "%f\n", lik);
     /* the event model is the state machine's table after this read's emissions_signal_scaleNoise
      * (impl/stateMachine.c:721-741: noise_mean *= scale_sd, noise_lambda *= var_sd, noise_sd = sqrt(mean^3 / lambda)) */
+    double *em = malloc(sizeof(double) * 5 * (size_t) n_kmers);
+    if (!em) die("signalMachine: out of memory%s", "");
     for (int64_t i = 0; i < n_kmers * 5; i += 5) {
-        double nm = sm->table[i + 2] * npp->scale_sd, nl = sm->table[i + 4] * npp->var_sd;
-        fprintf(fh, "%lf\t%lf\t%lf\t%lf\t%lf\t", sm->table[i], sm->table[i + 1], nm, sqrt(pow(nm, 3.0) / nl), nl);
+        const double nm = sm->table[i + 2] * npp->scale_sd, nl = sm->table[i + 4] * npp->var_sd;
+        em[i] = sm->table[i]; em[i + 1] = sm->table[i + 1]; em[i + 2] = nm; em[i + 3] = sqrt(pow(nm, 3.0) / nl); em[i + 4] = nl;
     }
-    fprintf(fh, "\n");
-    if (!hdp) {
-        for (int64_t i = 0; i < n_kmers * 2; i++) fprintf(fh, "%lf\t", 0.0);   /* eventExpectations: never updated */
-        fprintf(fh, "\n");
-        for (int64_t i = 0; i < n_kmers; i++) fprintf(fh, "%lf\t", 0.001);     /* posteriors = emissionsPseudocount */
-        fprintf(fh, "\n");
-        for (int64_t i = 0; i < n_kmers; i++) fprintf(fh, "%d\t", 0);          /* observed mask */
-        fprintf(fh, "\n");
-    } else {
-        for (int64_t i = 0; i < n_as; i++) fprintf(fh, "%lf\t", job->events[as[i].event * job->event_stride]);
-        fprintf(fh, "\n");
-        for (int64_t i = 0; i < n_as; i++) {
-            for (int n = 0; n < sm->k; n++) fputc(job->ref[as[i].ref_pos + n], fh);
-            fputc('\t', fh);
-        }
-        fprintf(fh, "\n");
-    }
-    fclose(fh);
+    sa_hmm_set_event_model(h, em);
+    free(em);
+    sa_hmm_add_expectations(h, trans, lik);
+    for (int64_t i = 0; hdp && i < n_as; i++)
+        sa_hmm_add_assignment(h, job->ref + as[i].ref_pos, job->events[as[i].event * job->event_stride]);
+    rc = sa_hmm_write(h, path);
+    sa_hmm_destroy(h);
+    if (rc != SA_OK) die("signalMachine: cannot open %s for writing", path);
 }
 
 static int load_strand_model(strand_model_t *sm, const char *model_path, const char *nhdp_path) {
@@ -866,7 +850,7 @@ static render_job_t *run_slice(run_t *Rp, read_t *reads, int64_t n_reads, int ba
                 if (path != NULL) {
                     fprintf(stderr, "signalAlign - writing expectations to file: %s\n", path);
                     write_expectations(path, sms[s], s == 0 ? &rd->np->template_params : &rd->np->complement_params, R.hdp,
-                                       trans + 9 * j, lik[j], &rd->jobs[s], as[j], n_as[j]);
+                                       R.p.threshold, trans + 9 * j, lik[j], &rd->jobs[s], as[j], n_as[j]);
                 }
                 sa_free(as[j]);
             }

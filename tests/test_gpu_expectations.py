@@ -189,3 +189,83 @@ def test_register_kernel_expectations_in_several_forward_storage_passes(oracle, 
     op = cases.oracle_params(oracle, p)
     t, l, _, _, _ = _oracle_expect(oracle, om, jobs[0], op)
     np.testing.assert_allclose(many_t[0], t, rtol=1e-9, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The EM loops of the reference's own tests with the M-step in the LIBRARY (sa_hmm_*: create, add, normalize, load into
+# the model) -- tests/stateMachineTests.c:1233-1330.  No oracle: the assertions are the reference's.
+# ---------------------------------------------------------------------------------------------------------------------
+def _zymo_em_inputs():
+    import zymo_wholeread as z
+    r = z.read_fixture()
+    alpha, k, t10, tab = synth.parse_model_table(cases.MODEL_R73)
+    ax, ay = z.remapped_anchors()
+    b = z.BANDING
+    p = sa.default_params(threshold=b["threshold"], expansion=b["expansion"], trace_back=b["trace_back"], min_diags=b["min_diags"],
+                          split=b["split"])
+    return z, r, alpha, k, t10, np.array(tab, dtype=np.float64), ax, ay, p
+
+
+@pytest.mark.parametrize("emission", [0, 1])
+def test_continuous_pair_hmm_em_on_the_zymo_read(emission):
+    # test_continuousPairHmm_em (:1233-1281): loadDescaledStateMachine3, getExpectationsUsingAnchors(..., 0, 0) ten times, each
+    # followed by continuousPairHmm_normalize and the two loads into the state machine; from the third iteration on
+    # `pLikelihood <= likelihood * 0.85` (likelihoods are negative: the new one may not be more than ~18 % worse).  emission 1 is
+    # the reference's (two distributions, descaled events), emission 0 the one signalMachine installs (default kernels).
+    z, r, alpha, k, t10, tab, ax, ay, p = _zymo_em_inputs()
+    tp = r["template_params"]
+    t5 = tab.reshape(-1, 5).copy()                                   # emissions_signal_scaleNoise (impl/stateMachine.c:721-741)
+    t5[:, 2] *= tp["scale_sd"]
+    t5[:, 4] *= tp["var_sd"]
+    t5[:, 3] = np.sqrt(np.power(t5[:, 2], 3.0) / t5[:, 4])
+    m = sa.Model.create(alpha, k, t10, t5.reshape(-1))
+    m.set_emission(emission)
+    job = dict(ref=r["ref"], events=r["template_events"], ax=ax, ay=ay, scale=tp["scale"], shift=tp["shift"], var=tp["var"],
+               ragged=(0, 0))
+    prev, history = -np.inf, []
+    for it in range(10):
+        h = sa.Hmm.create(m, sa.HMM_GAUSSIAN, 0.0, 0.001, 0.001)     # continuousPairHmm_makeExpectationsHmm(sM, 0.001, 0.001)
+        trans, lik, _ = sa.expect_batch(m, p, [job])
+        h.add_expectations(trans[0], lik[0])
+        assert np.all(h.transitions >= 0.001) and not h.observed.any()   # (the emission expectations are not updated: :914-944)
+        h.normalize()
+        h.load_into_model(m)
+        if it > 1:
+            assert prev <= h.likelihood * 0.85, (it, prev, h.likelihood)
+        prev = h.likelihood
+        history.append(prev)
+        h.close()
+    # ... and what EM promises, as far as this "likelihood" can show it: the figure is the reference's sum of the total
+    # probability over ALL diagonals of every traceback (hmm->likelihood += totalProbability per diagonal,
+    # impl/pairwiseAligner.c:1432), under transitions with a pseudocount -- it climbs steeply, then settles to within 1e-4
+    assert all(b >= a - 1e-4 * abs(a) for a, b in zip(history, history[1:])), history
+    assert history[-1] > history[0]
+    t = m.transitions10()
+    assert abs(t[0] + t[1] + t[2] - 1.0) < 1e-3 and abs(t[3] + t[4] - 1.0) < 1e-2 and abs(t[6] + t[8] - 1.0) < 1e-2
+
+
+def test_hdp_hmm_em_transitions_on_the_zymo_read():
+    # test_hdpHmm_emTransitions (:1283-1330): the bundled HDP, events descaled by nanopore_descaleNanoporeRead (the quirk of
+    # zymo_wholeread.hdp_test_events), hdpHmm_makeExpectationsHmm(sM, p->threshold, 0.0), hmmDiscrete_normalizeTransitions and
+    # continuousPairHmm_loadTransitionsIntoStateMachine ten times: `pLikelihood <= likelihood * 0.95` from the third iteration on
+    z, r, alpha, k, t10, tab, ax, ay, p = _zymo_em_inputs()
+    tp = r["template_params"]
+    m = sa.Model.load(cases.MODEL_R73, cases.NHDP)
+    job = dict(ref=r["ref"], events=z.hdp_test_events(r), ax=ax, ay=ay, scale=tp["scale"], shift=tp["shift"], var=tp["var"],
+               ragged=(0, 0))
+    prev = -np.inf
+    n_assign = []
+    for it in range(10):
+        h = sa.Hmm.create(m, sa.HMM_HDP, p.threshold, 0.0)
+        trans, lik, assigns = sa.expect_batch(m, p, [job])
+        h.add_expectations(trans[0], lik[0])
+        for pos, ev in assigns[0]:
+            h.add_assignment(job["ref"][int(pos):int(pos) + k], job["events"][int(ev), 0])
+        n_assign.append(h.view().n_assignments)
+        h.normalize()
+        h.load_into_model(m)
+        if it > 1:
+            assert prev <= h.likelihood * 0.95, (it, prev, h.likelihood)
+        prev = h.likelihood
+        h.close()
+    assert min(n_assign) > 500        # (to == match && p >= threshold: more than one assignment per second event)

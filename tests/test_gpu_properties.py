@@ -73,16 +73,18 @@ def test_em_on_transitions_does_not_lose_likelihood():
     t[[3, 4]] = [0.5, 0.5]
     t[[6, 8]] = [0.5, 0.5]
     history = []
+    pm = sa.Model.create(alpha, k, t, tab)
     for it in range(6):
-        pm = sa.Model.create(alpha, k, t, tab)
-        trans, lik, _ = sa.expect_batch(pm, p, jobs, pseudocount=0.001)
-        history.append(float(lik.sum()))
-        e = trans.sum(axis=0).reshape(3, 3)
-        e = e / e.sum(axis=1, keepdims=True)                 # hmmDiscrete_normalizeTransitions
-        # continuousPairHmm_loadTransitionsIntoStateMachine (impl/continuousHmm.c:320-338)
-        t[0], t[1], t[2] = e[0, 0], e[0, 1], e[0, 2]
-        t[3], t[4] = e[1, 0], e[1, 1]
-        t[6], t[8] = e[2, 0], e[2, 2]
-        pm.close()
+        # the library's expectations object and M-step (sa_hmm_*: hmmContinuous_getExpectationsHmm, continuousPairHmm_normalize,
+        # continuousPairHmm_loadTransitionsIntoStateMachine, impl/continuousHmm.c:282-351)
+        h = sa.Hmm.create(pm, sa.HMM_GAUSSIAN, 0.0, 0.001, 0.001)
+        trans, lik, _ = sa.expect_batch(pm, p, jobs)
+        for j in range(len(jobs)):
+            h.add_expectations(trans[j], lik[j])
+        history.append(h.likelihood)
+        h.normalize()
+        h.load_into_model(pm)
+        h.close()
+    pm.close()
     assert all(b >= a - 1e-6 * abs(a) for a, b in zip(history, history[1:])), history
     assert history[-1] > history[0]
