@@ -905,6 +905,183 @@ def measure(args, ctx, compact=False):
     return None
 
 
+def scaling_job(args, ctx):
+    """BASELINE configs[4] as a JOB (strong scaling): `--job-reads` (100 000) synthetic `--job-events` (10 000)-event R9.4 reads,
+    dealt to the ranks by signalalign_amd/shard.py (the one-process-per-read pool of src/signalalign/signalAlignment.py:694-737
+    is what this replaces), every rank aligning ITS share in slices of `--job-slice` reads through the pipelined boundary
+    (sa_batch_create of the next slices while earlier ones are on the GPU, as the timed loop of the headline does).  No collective
+    on the data path; the barrier and the max-over-ranks of the wall time are the only exchanges.  value = cell updates of ALL
+    ranks / the slowest rank's wall time.  Reads are generated for the first `job_sets` slices of a rank only and cycled (the
+    library keeps nothing of a slice between slices: every slice is checked, packed, uploaded and planned anew; 100 000 reads
+    would be 32 GB of host arrays and minutes of generation) -- the line says so.  Returns the record on rank 0."""
+    import signalalign_amd as sa
+    from signalalign_amd import synth, shard
+    from signalalign_amd._capi import jobs_bytes_in_block
+    dist, rank, world, device, backend = ctx["dist"], ctx["rank"], ctx["world"], ctx["device"], ctx["backend"]
+    total, ev, sl = int(args.job_reads), int(args.job_events), int(args.job_slice)
+    if ctx.get("ranks_per_device", 1) > 1:   # (rehearsal: several ranks share one card -- every rank's working set must fit its share)
+        sl = max(250, sl // int(ctx["ranks_per_device"]))
+    alpha, k, t10, tab = synth.parse_model_table(MODEL)
+    pm = sa.Model.load(MODEL)
+    params = sa.default_params(threshold=0.01, expansion=50, trace_back=100)
+    spec = dict(kind="gauss", model=MODEL, events=ev, kw={})
+    t_part = time.perf_counter()
+    mine = shard.shard_indices([ev] * total, rank, world)
+    t_part = time.perf_counter() - t_part
+    n_mine = len(mine)
+    sizes = shard.slice_sizes(n_mine, sl)
+    n_slices = len(sizes)
+    n_sets = max(1, min(int(args.job_sets), n_slices))
+    gen_workers = None if world == 1 else max(1, min(4, int(os.environ.get("SA_HOST_THREADS", "2"))))
+    memo = ctx.setdefault("reads_memo", {})
+    sets = []
+    t_gen = time.perf_counter()
+    for q in range(n_sets):
+        idx = [int(i) for i in mine[q * sl:(q + 1) * sl]]
+        key = ("scaling", ev, tuple(idx[:2]), idx[-1] if idx else -1, len(idx))   # (the scaling_slice leg's reads, when they are the same)
+        if memo.get("workload") != "scaling":
+            memo.clear()
+            memo["workload"] = "scaling"
+        if key not in memo:
+            memo[key] = synth.make_reads_parallel(spec, idx, workers=gen_workers)
+        sets.append(memo[key])
+    t_gen = time.perf_counter() - t_gen
+    host_threads = int(os.environ.get("SA_HOST_THREADS") or 0)
+    in_block = args.inputs == "host-block" or (args.inputs == "auto" and 0 < host_threads <= 3 and
+                                               max(jobs_bytes_in_block(js) for js in sets) <= (2 << 30))
+    try:
+        arrays = [sa.JobArray(js, host_block=in_block) for js in sets]
+    except sa.SaError:
+        in_block = False
+        arrays = [sa.JobArray(js) for js in sets]
+    xflags = sa.FLAG_INPUTS_IN_HOST_BLOCK if in_block else 0
+    partial = {}   # a last slice shorter than the others: the first reads of its set
+
+    def array_of(q):
+        if sizes[q] == len(sets[q % n_sets]):
+            return arrays[q % n_sets]
+        if sizes[q] not in partial:
+            partial[sizes[q]] = sa.JobArray(sets[q % n_sets][:sizes[q]], host_block=in_block)
+        return partial[sizes[q]]
+
+    def sync():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # pipeline depth from a slice's own storage, as the headline loop sizes it (this rank's share of the card in a rehearsal)
+    probe = sa.Batch(pm, params, arrays[0], ambig=None, device=device, flags=xflags)
+    st0 = probe.stats()
+    probe.run()
+    probe.close()
+    hbm_bytes = float(sa.device_memory(device)[1]) / max(1, ctx.get("ranks_per_device", 1))
+    if ctx.get("ranks_per_device", 1) > 1:
+        sa.pool_configure(device_limit_bytes=int(0.9 * hbm_bytes))   # (a slice's blocks stay parked for the next slice of this rank)
+    depth = max(1, min(args.in_flight, int(0.6 * hbm_bytes / max(1.25 * st0.f_bytes, 1.0)), int(0.8 * hbm_bytes / max(st0.device_bytes, 1.0))))
+    cells_done, events_done, pairs_done, reads_done = [0.0], [0.0], [0], [0]
+    first_buf = np.zeros(sl + 1, dtype=np.int64)
+
+    def run_slices(qs):
+        flying = []
+
+        def retire(item):
+            b, q = item
+            b.wait()
+            pairs_done[0] += int(b.results_view(first_buf)[1][sizes[q]])
+            b.close()
+        if depth == 1 and ctx.get("ranks_per_device", 1) > 1:
+            # a rehearsal with several ranks on one card (gloo): no rank has the device to itself -- one slice after the other,
+            # each planned into what is free at that moment
+            for q in qs:
+                cur = sa.Batch(pm, params, array_of(q), ambig=None, device=device, flags=xflags)
+                stc = cur.stats()
+                cur.run()
+                cells_done[0] += stc.cells_forward + stc.cells_backward
+                pairs_done[0] += int(cur.results_view(first_buf)[1][sizes[q]])
+                events_done[0] += float(sizes[q]) * ev
+                reads_done[0] += sizes[q]
+                cur.close()
+            return
+        if depth == 1:
+            def make(q):
+                return sa.Batch(pm, params, array_of(q), ambig=None, device=device, deferred=True, flags=sa.FLAG_DEVICE_TO_ITSELF | xflags)
+            nxt = make(qs[0]) if qs else None
+            for i, q in enumerate(qs):
+                cur = nxt
+                cur.start()
+                nxt = make(qs[i + 1]) if i + 1 < len(qs) else None
+                if nxt is not None:
+                    nxt.prepare()
+                cur.wait()
+                stc = cur.stats()
+                cells_done[0] += stc.cells_forward + stc.cells_backward
+                pairs_done[0] += int(cur.results_view(first_buf)[1][sizes[q]])
+                events_done[0] += float(sizes[q]) * ev
+                reads_done[0] += sizes[q]
+                cur.close()
+            return
+        for q in qs:
+            cur = sa.Batch(pm, params, array_of(q), ambig=None, device=device, flags=xflags)
+            stc = cur.stats()
+            cells_done[0] += stc.cells_forward + stc.cells_backward
+            events_done[0] += float(sizes[q]) * ev
+            reads_done[0] += sizes[q]
+            cur.start()
+            flying.append((cur, q))
+            if len(flying) >= depth:
+                retire(flying.pop(0))
+        for item in flying:
+            retire(item)
+
+    # before the job: the caching allocators see the pipeline's working set (a long-running aligner is in that state for good)
+    run_slices([0] * (depth + 2 if depth > 1 else 2))
+    sync()
+    cells_done[0] = events_done[0] = 0.0
+    pairs_done[0] = reads_done[0] = 0
+    t0 = time.perf_counter()
+    run_slices(list(range(n_slices)))
+    my_wall = time.perf_counter() - t0
+    sync()
+    dt = time.perf_counter() - t0
+    per_rank = [[float(n_mine), my_wall, cells_done[0]]]
+    cells_all, events_all, pairs_all = cells_done[0], events_done[0], float(pairs_done[0])
+    if dist is not None:
+        import torch
+        tdev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        rows = torch.zeros(world, 3, dtype=torch.float64, device=tdev)
+        rows[rank] = torch.tensor([float(n_mine), my_wall, cells_done[0]], dtype=torch.float64, device=tdev)
+        dist.all_reduce(rows, op=dist.ReduceOp.SUM)
+        per_rank = [[float(v) for v in row] for row in rows.cpu().tolist()]
+        tot = torch.tensor([cells_done[0], events_done[0], float(pairs_done[0]), float(reads_done[0])], dtype=torch.float64, device=tdev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        cells_all, events_all, pairs_all, reads_all = [float(v) for v in tot.cpu().tolist()]
+    else:
+        reads_all = float(reads_done[0])
+    if rank != 0:
+        return None
+    assert int(reads_all) == total, (reads_all, total)
+    return {
+        "workload": "BASELINE configs[4]: %d synthetic %d-event R9.4 reads (6-mer template Gaussian HMM, band 50, threshold 0.01), "
+                    "read-sharded over %d GPU%s, slices of %d reads" % (total, ev, world, "" if world == 1 else "s", sl),
+        "scaling": "strong", "n_gpus": world, "total_reads": total, "events_per_read": ev,
+        "value": cells_all / dt, "unit": "cell_updates/s", "wall_s": dt, "events_per_s": events_all / dt, "reads_per_s": reads_all / dt,
+        "pairs": pairs_all, "cell_updates": cells_all,
+        "slice_reads": sl, "slices_rank0": n_slices, "batches_in_flight": depth, "forward_storage_passes_per_slice": int(st0.n_chunks),
+        "read_sets_cycled": n_sets, "reads_generated_per_rank": sum(len(s_) for s_ in sets),
+        "inputs": "host-block" if in_block else "pageable", "host_threads_per_rank": os.environ.get("SA_HOST_THREADS"),
+        "per_rank": [{"rank": r_, "reads": int(v[0]), "wall_s": v[1], "value": v[2] / v[1]} for r_, v in enumerate(per_rank)],
+        "partition": "signalalign_amd/shard.py (longest processing time first over the reads' event counts), %.2f s" % t_part,
+        "outside_the_timed_job": "read generation (%.1f s), allocator priming (%d slices), the barrier" % (t_gen, depth + 2 if depth > 1 else 2),
+        "timed": "every rank's slices through sa_batch_create / start / wait / results in place / destroy, barrier on both sides, "
+                 "max over ranks",
+    }
+
+
 def main():
     # A streaming caller keeps three batches in flight, each with two compute streams, a copy stream and the upload stream: more
     # hardware queues than the runtime's default of four keep one batch's short kernels from queueing behind another's long
@@ -919,7 +1096,7 @@ def main():
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU (default: 2000 = BASELINE configs[1]; "
                                                              "scaling: 12500 = configs[4]'s 100k reads / 8 GPUs)")
     ap.add_argument("--events", type=int, default=None, help="events per read (default 5000; scaling: 10000)")
-    ap.add_argument("--workload", choices=["gaussian", "scaling", "cpg", "hdp", "hdp_cpg", "hdp_realistic", "realistic", "event_align",
+    ap.add_argument("--workload", choices=["gaussian", "scaling", "scaling_job", "cpg", "hdp", "hdp_cpg", "hdp_realistic", "realistic", "event_align",
                                            "mea", "expectations", "expectations_cpg"],
                     default="gaussian",
                     help="gaussian = BASELINE configs[1] (the headline); scaling = configs[4]'s per-GPU slice (12500 "
@@ -950,6 +1127,11 @@ def main():
                                                                 "K timed steps (config.long_run)")
     ap.add_argument("--cpu-reads-per-thread", type=int, default=30)
     ap.add_argument("--secondary-cpu-reads", type=int, default=6, help="reads per thread of the CPU baselines of the secondary legs")
+    ap.add_argument("--job-reads", type=int, default=100000, help="config.scaling_job (BASELINE configs[4]): reads of the whole job")
+    ap.add_argument("--job-events", type=int, default=10000)
+    ap.add_argument("--job-slice", type=int, default=2000, help="reads per batch of the scaling job")
+    ap.add_argument("--job-sets", type=int, default=2, help="distinct slice-sized read sets a rank generates and cycles")
+    ap.add_argument("--no-scaling-job", action="store_true", help="skip config.scaling_job")
     ap.add_argument("--secondary-budget-s", type=float, default=330.0,
                     help="a secondary leg is not started once the run has taken this long (the default line must stay well inside "
                          "the driver's time limit)")
@@ -1005,7 +1187,27 @@ def main():
         return res
     ctx = dict(dist=dist, rank=rank, world=world, device=device, backend=backend, ranks_per_device=ranks_per_device if world > 1 else 1,
                t_start=T_START)
+    if args.workload == "scaling_job":   # the job alone: its own line (strong scaling)
+        job = scaling_job(args, ctx)
+        if job is not None:
+            print(json.dumps({"metric": "dp_cell_updates_per_s", "value": job["value"], "unit": "cell_updates/s", "n_gpus": world,
+                              "steps": job["slices_rank0"], "warmup": 0, "ms_per_step": job["wall_s"] / max(job["slices_rank0"], 1) * 1e3,
+                              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                              "config": job}))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     out = measure(args, ctx)
+    if world > 1 and args.workload == "gaussian" and not args.kernels_only and not args.no_scaling_job:
+        # BASELINE configs[4] on the multi-GPU line: the 100 000-read job, strong scaling, beside the weak-scaling headline
+        sa.lib().sa_pool_release()
+        try:
+            job = scaling_job(args, ctx)
+        except Exception as ex:   # (every rank raises or none: the job's collectives are behind the slices)
+            job = {"failed": "%s: %s" % (type(ex).__name__, ex)}
+        if out is not None:
+            out["config"]["scaling_job"] = job
     if out is not None and world == 1 and args.workload == "gaussian" and not args.kernels_only and not args.no_secondary:
         # Every other BASELINE config and the two workloads beside them, compactly, on the same line: configs[2] (cpg) at its
         # 10 000 reads, configs[3] (hdp) at its 5000 reads and the reference's threshold 0.1 with the 0.01 figure beside it, one
@@ -1080,6 +1282,22 @@ def main():
         else:
             sec["expectations"] = {"skipped": "wall-time budget of the default run (%d s) reached" % args.secondary_budget_s}
         leg("scaling_slice", "scaling", 12500, 10000, 0.01, 4, 2)
+        # ... and the whole configs[4] job at this N (what `--gpus N` reports as config.scaling_job): 100 000 reads in slices
+        if args.no_scaling_job:
+            out["config"]["scaling_job"] = {"skipped": "--no-scaling-job"}
+        elif time.perf_counter() - t_start > args.secondary_budget_s:
+            out["config"]["scaling_job"] = {"skipped": "wall-time budget of the default run (%d s) reached" % args.secondary_budget_s}
+        else:
+            t_leg = time.perf_counter()
+            sa.lib().sa_pool_release()
+            try:
+                out["config"]["scaling_job"] = scaling_job(args, ctx)
+                out["config"]["scaling_job"]["leg_wall_s"] = time.perf_counter() - t_leg
+                sl_ = sec.get("scaling_slice") or {}
+                if sl_.get("value"):
+                    out["config"]["scaling_job"]["over_scaling_slice_value"] = out["config"]["scaling_job"]["value"] / sl_["value"]
+            except Exception as ex:
+                out["config"]["scaling_job"] = {"failed": "%s: %s" % (type(ex).__name__, ex)}
         out["config"]["wall_s_whole_run"] = time.perf_counter() - t_start
     if out is not None:
         print(json.dumps(out))

@@ -21,6 +21,16 @@ def shard_indices(costs, rank, world):
     return np.nonzero(owner == rank)[0]
 
 
+def slice_sizes(n_reads, slice_reads):
+    """A rank's share of a job cut into batches of `slice_reads` reads (the last one may be shorter)."""
+    n_reads, slice_reads = int(n_reads), int(slice_reads)
+    if n_reads <= 0:
+        return []
+    if slice_reads <= 0:
+        raise ValueError("slice_reads must be positive")
+    return [min(slice_reads, n_reads - q * slice_reads) for q in range((n_reads + slice_reads - 1) // slice_reads)]
+
+
 def merge_in_read_order(per_rank_indices, per_rank_results):
     """Inverse of shard_indices: results[i] for read i, whatever rank produced it."""
     n = sum(len(ix) for ix in per_rank_indices)

@@ -25,6 +25,19 @@ def test_shard_is_a_partition_and_balanced():
     assert res == [2 * i for i in range(1000)]
 
 
+def test_the_scaling_job_is_dealt_completely_and_evenly():
+    # BASELINE configs[4] as bench.py's config.scaling_job deals it: 100 000 reads of 10 000 events over 1, 2, 4, 8 ranks, each
+    # rank's share cut into slices of 2000 reads (bench.py --job-slice)
+    total, ev, sl = 100000, 10000, 2000
+    for world in (1, 2, 4, 8):
+        parts = [shard.shard_indices([ev] * total, r, world) for r in range(world)]
+        assert sum(len(p) for p in parts) == total and len(set(len(p) for p in parts)) == 1
+        assert np.array_equal(np.sort(np.concatenate(parts)), np.arange(total))
+        sizes = shard.slice_sizes(len(parts[0]), sl)
+        assert sum(sizes) == total // world and max(sizes) == sl and all(s_ > 0 for s_ in sizes)
+    assert shard.slice_sizes(12500, 2000) == [2000] * 6 + [500] and shard.slice_sizes(0, 5) == [] and shard.slice_sizes(3, 5) == [3]
+
+
 def test_two_rank_gloo_run():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
