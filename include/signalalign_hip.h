@@ -268,6 +268,13 @@ int sa_batch_pairs16_all(const sa_batch_t *b, const sa_pair16_t **out, int64_t *
  * job j's rows (`first` has n_jobs + 1 entries; may be NULL).  cap < total number of pairs: SA_EINVAL and *first is still
  * filled, so first[n_jobs] says how much room is needed. */
 int sa_batch_pairs_all(const sa_batch_t *b, sa_pair_t *out, int64_t cap, int64_t *first);
+/* A finished batch's working storage in HBM (everything sa_batch_stats_t.device_bytes counts) back to the library's allocator,
+ * the results kept: the packed pairs in pinned host memory, the per-job offsets and the statistics stay readable until
+ * sa_batch_destroy.  For a caller that holds batches for their results while further ones are created (signalMachine --twoD
+ * keeps the template strand's batch while the complement's runs).  Afterwards sa_batch_run / sa_batch_start: SA_ESTATE;
+ * sa_batch_mea still works (the pairs are uploaded again).  Before the batch has run, or between sa_batch_start and
+ * sa_batch_wait: SA_ESTATE. */
+int sa_batch_release_device(sa_batch_t *b);
 int sa_batch_stats(const sa_batch_t *b, sa_batch_stats_t *out);
 int sa_batch_job_cells(const sa_batch_t *b, int64_t job, double *cells_fwd, double *cells_bwd);
 void sa_batch_destroy(sa_batch_t *b);

@@ -82,7 +82,7 @@ PAIR_DTYPE = np.dtype([("prob_e7", "<i8"), ("x", "<i4"), ("y", "<i4"), ("path", 
 EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alphabet", "sa_model_table5",
            "sa_model_set_to_hdp_expected_values", "sa_model_set_emission", "sa_model_clone_with_table", "sa_kmer_id", "sa_default_ambig", "sa_load_ambig",
            "sa_batch_create", "sa_batch_create_deferred", "sa_batch_prepare", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_pairs16", "sa_batch_pairs16_all", "sa_batch_pairs_all", "sa_batch_stats",
-           "sa_batch_job_cells", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_expect_last_stats", "sa_plan_describe", "sa_plan_digest",
+           "sa_batch_job_cells", "sa_batch_release_device", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_expect_last_stats", "sa_plan_describe", "sa_plan_digest",
            "sa_plan_check_path_records", "sa_dplan_compare",
            "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_pool_configure", "sa_host_alloc", "sa_host_free", "sa_pair_roundtrip", "sa_fasta_subsequence", "sa_format_f6", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_device_memory", "sa_strerror", "sa_hdp_state_load", "sa_hdp_state_write", "sa_hdp_state_info", "sa_hdp_state_free", "sa_hdp_state_distr_sample", "sa_hdp_state_sample_weights", "sa_hdp_finalize_distributions",
            "sa_hmm_create", "sa_hmm_destroy", "sa_hmm_view", "sa_hmm_set_event_model", "sa_hmm_add_expectations",
@@ -433,6 +433,10 @@ class Batch:
 
     def run(self):
         _chk(lib().sa_batch_run(self._h), "sa_batch_run")
+
+    def release_device(self):
+        """sa_batch_release_device: the working storage in HBM back to the allocator, the results kept"""
+        _chk(lib().sa_batch_release_device(self._h), "sa_batch_release_device")
 
     def prepare(self):
         """sa_batch_prepare: a deferred batch's plan and launch lists now (while the batch before it runs)."""

@@ -83,6 +83,13 @@ int sa_hdp_state_load(sa_hdp_state_t **out, const char *path) {
     if (s->num_dps <= 0 || s->num_dps > ((int64_t) 1 << 31) || s->alphabet_size < 1 || s->alphabet_size > 60 ||
         (int64_t) strlen(s->alphabet) != s->alphabet_size || s->kmer_length < 1 || s->kmer_length > 12)
         goto bad;
+    {   /* every model constructor of impl/nanopore_hdp.c:413-1060 lays out one leaf DP per k-mer plus internal DPs that group
+         * k-mers (at most one per k-mer prefix / multiset and the base): a count far beyond that is a malformed header, refused
+         * before seven arrays of that size are allocated */
+        double leaves = 1.0;
+        for (int64_t i = 0; i < s->kmer_length; i++) leaves *= (double) s->alphabet_size;
+        if ((double) s->num_dps > 3.0 * leaves + 64.0) goto bad;
+    }
     if (s->has_data) {
         NEXT(); s->data = parse_f64s(ln, &s->n_data);
         NEXT(); s->data_dp = parse_int64s(ln, &n);
@@ -128,6 +135,7 @@ int sa_hdp_state_load(sa_hdp_state_t **out, const char *path) {
         } else if (sscanf(ln, "%lld %lld", &pa, &nc) != 2 || pa < 0 || pa >= s->num_dps || pa == id) {
             goto bad;
         }
+        if (nc < 0) goto bad;   /* (gamma + num_factor_children is a denominator of the sample weights) */
         s->dp_parent[id] = pa;
         s->dp_num_factor_children[id] = nc;
     }
@@ -225,6 +233,16 @@ int sa_hdp_state_load(sa_hdp_state_t **out, const char *path) {
         if (!s->f_n_children) { rc = SA_ENOMEM; goto bad; }
         for (int64_t i = 0; i < s->n_factors; i++)
             if (s->f_parent[i] >= 0) s->f_n_children[s->f_parent[i]]++;
+        /* num_factor_children of a DP counts the factors (middle factors, data points) whose PARENT factor sits in that DP
+         * (impl/hdp.c:346, :1368, :1413, :1682-1720): the two halves of the file must agree */
+        int64_t *cnt = calloc((size_t) s->num_dps, sizeof(int64_t));
+        if (!cnt) { rc = SA_ENOMEM; goto bad; }
+        for (int64_t i = 0; i < s->n_factors; i++)
+            if (s->f_parent[i] >= 0) cnt[s->f_ref[s->f_parent[i]]]++;
+        int same = 1;
+        for (int64_t id = 0; id < s->num_dps && same; id++) same = cnt[id] == s->dp_num_factor_children[id];
+        free(cnt);
+        if (!same) goto bad;
     }
     free(ln);
     fclose(f);

@@ -848,7 +848,27 @@ __global__ __launch_bounds__(64) void k_spec_match(DevPlan P, int seg0, int n_se
     if (mx > NEG_INF)
         for (int j = lane; j < np; j += 64) sum += exp(Fm[j] + em - mx) + exp(Fm[C + j] + ex - mx) + exp(Fm[2 * C + j] + ey - mx);
     sum = wave_sum(sum);
-    if (lane == 0) spec[seg] = (mx > NEG_INF && sum > 0.0) ? mx + log(sum) : NEG_INF;
+    if (lane == 0) {
+        double r = (mx > NEG_INF && sum > 0.0) ? mx + log(sum) : NEG_INF;
+        // NaN means "a segment of another kernel family" to the kernels that read this array: a NaN that comes out of the DATA (an
+        // event mean or a model entry that is not a number poisons the forward values) must not pass for that -- the traceback
+        // would return nothing without a word.  It is reported instead (sa_batch_run: SA_EINVAL).
+        if (!(sum == sum) || !(mx == mx)) { r = NEG_INF; P.overflow[2] = 1; }
+        spec[seg] = r;
+    }
+}
+
+// An event mean that is not a finite number: the reference's logAdd turns such a cell's NaN into NaN everywhere (every comparison
+// with it is false), the kernels' max/min drop it silently -- the read would come back with an alignment that steps around the
+// event, or with none.  One coalesced pass over the batch's event means per run (80 MB per 2000 x 5000-event reads: ~0.03 ms)
+// raises P.overflow[2] instead, whatever path brought the events here (packed by the host, gathered from the caller's block).
+__global__ __launch_bounds__(256) void k_check_events(const double *__restrict__ ev, long long n, int *flag) {
+    bool bad = false;
+    for (long long i = (long long) blockIdx.x * 256 + threadIdx.x; i < n; i += (long long) gridDim.x * 256) {
+        const unsigned hi = (unsigned) __double2hiint(ev[i]);
+        bad = bad || ((hi >> 20) & 0x7ffu) == 0x7ffu;
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) flag[2] = 1;
 }
 
 // spec (one-pass strip sweep, sa_strip.inc): per segment the speculative total its candidate bound was derived from, NaN for every
@@ -1218,6 +1238,8 @@ struct sa_batch {
     bool strip_one_pass;     // strip segments run the one-pass backward sweep (k_bwd_strip1; SA_STRIP_PASSES=2: the two-pass one)
     double *d_spec;          // ring / strip kernels: speculative totals, one per segment (NaN: a segment of another kernel family)
     double spec_slack;       // candidates: forward + backward >= spec - slack + log(threshold); grows when a pass has to be repeated
+    int spec_repeats;        // passes repeated because of it (the second repeat drops the bound altogether)
+    bool released;           // sa_batch_release_device: the working storage went back to the pool, the results stay
     unsigned long long *d_sortkey;   // k_gather_sorted's scratch: 8 + 4 bytes per candidate slot
     unsigned *d_sortidx;
     char *d_seam;            // their seam storage: per wave two arrays of seam_cap records of 16 bytes
@@ -1595,6 +1617,34 @@ static void cand_memo_note(const sa_model_t *m, double threshold, int device, in
     x->quiet = 0;
 }
 
+// The slack of the speculative candidate bound (sa_strip.inc: STRIP_SPEC_SLACK) a model had to grow to on a device is remembered
+// too: a stream of batches whose totals drift further than the default allows (longer tracebacks, densities broader than the
+// bundled HDP's) would otherwise run every batch's pass twice.  Keyed like the candidate capacity; +inf is remembered as well.
+struct SaSpecMemo {
+    struct Entry { uint64_t uid; int device; double slack; uint64_t used; };
+    std::mutex mu;
+    std::vector<Entry> e;
+    uint64_t clock = 0;
+};
+static SaSpecMemo g_spec_memo;
+static double spec_memo_slack(const sa_model_t *m, int device, double dflt) {
+    std::lock_guard<std::mutex> g(g_spec_memo.mu);
+    for (auto &x : g_spec_memo.e)
+        if (x.uid == m->uid && x.device == device) { x.used = ++g_spec_memo.clock; return x.slack > dflt ? x.slack : dflt; }
+    return dflt;
+}
+static void spec_memo_note(const sa_model_t *m, int device, double slack) {
+    std::lock_guard<std::mutex> g(g_spec_memo.mu);
+    for (auto &x : g_spec_memo.e)
+        if (x.uid == m->uid && x.device == device) { if (slack > x.slack) x.slack = slack; x.used = ++g_spec_memo.clock; return; }
+    if (g_spec_memo.e.size() >= 32) {
+        size_t lru = 0;
+        for (size_t i = 1; i < g_spec_memo.e.size(); i++) if (g_spec_memo.e[i].used < g_spec_memo.e[lru].used) lru = i;
+        g_spec_memo.e.erase(g_spec_memo.e.begin() + (long) lru);
+    }
+    g_spec_memo.e.push_back({m->uid, device, slack, ++g_spec_memo.clock});
+}
+
 static std::atomic<int> g_batches_started(0);
 static void dplan_release_fwd(sa_batch *b, struct DPlanPending *P);   // sa_dplan.inc (below)   // batches between sa_batch_start and sa_batch_wait (this process)
 
@@ -1688,7 +1738,7 @@ static int batch_create_impl(sa_batch_t **out, const sa_model_t *m, const sa_par
     b->pair_stream = nullptr;
     b->h_seg_off = nullptr;
     b->h_overflow = nullptr;
-    b->ran = false;
+    b->ran = false; b->released = false;
     b->quiet = false;
     b->runner = nullptr; b->runner_rc = SA_OK;
     b->d_regions = nullptr; b->d_rows = nullptr; b->d_pk = nullptr; b->d_poff = nullptr; b->d_pid = nullptr; b->d_px = nullptr; b->d_xc = nullptr;
@@ -1697,7 +1747,12 @@ static int batch_create_impl(sa_batch_t **out, const sa_model_t *m, const sa_par
     b->d_cands = nullptr; b->d_cand_count = nullptr; b->d_overflow = nullptr; b->d_totals = nullptr;
     b->d_seam = nullptr; b->d_ckxy = nullptr; b->seam_cap = 0; b->seam_cap_bwd = 0; b->seam_bwd_off = 0; b->strip_on = false;
     b->prepared = false; b->prepare_rc = SA_OK; b->lw_strip_max_n = b->lw_strip_max_seg = b->lw_strip_fwd_slots = b->lw_strip_bwd_slots = 0;
-    b->strip_one_pass = false; b->d_spec = nullptr; b->d_sortkey = nullptr; b->d_sortidx = nullptr; b->spec_slack = STRIP_SPEC_SLACK;
+    b->strip_one_pass = false; b->d_spec = nullptr; b->d_sortkey = nullptr; b->d_sortidx = nullptr;
+    // the exact totals of a traceback drift away from its speculative total diagonal by diagonal (1.6e-4 per diagonal with the flat
+    // HDP fixture: sa_strip.inc), so the slack is sized for the traceback's length -- the default 0.5 at the default 1100 diagonals --
+    // and starts from what earlier batches of this model on this device had to grow to
+    b->spec_slack = STRIP_SPEC_SLACK * std::max(1.0, (double) (p->min_diags_between_trace_back + p->trace_back_diagonals) / 1100.0);
+    b->spec_slack = spec_memo_slack(m, device, b->spec_slack);
     if (const char *ets = getenv("SA_TEST_SPEC_SLACK")) {   // test hook: a slack the totals' drift exceeds, so that the repeat below is exercised
         const double v_ = atof(ets);
         if (v_ > 0.0) b->spec_slack = v_;
@@ -1705,7 +1760,7 @@ static int batch_create_impl(sa_batch_t **out, const sa_model_t *m, const sa_par
     b->d_bscratch = nullptr; b->d_tab6 = nullptr; b->d_noise3 = nullptr; b->d_evn = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr;
     b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr; b->d_hdp_tab = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr;
     b->d_seg_off = nullptr; b->d_out = nullptr; b->d_ids = nullptr; b->d_gsum = nullptr; b->d_gmc = nullptr;
-    b->cand_alloc = 0; b->out_alloc = 0; b->cand_factor = 1;
+    b->cand_alloc = 0; b->out_alloc = 0; b->cand_factor = 1; b->spec_repeats = 0;
     b->h_pairs = nullptr; b->h_pairs_cap = 0; b->n_pairs_total = 0;
     b->d_pairs_up = nullptr; b->d_pairs_up_cap = 0;
     memset(&b->stats, 0, sizeof(b->stats));
@@ -2175,7 +2230,7 @@ static int batch_finish_body(sa_batch *b) {
                 // side buffer of the (two-pass) backward strip kernel: the two backward gap sums of every checkpoint cell, laid out like vbuf
                 TRY(dalloc((void **) &b->d_ckxy, 16ll * (pl->n_vbuf > 0 ? pl->n_vbuf : 1)));
                 // the one-pass sweep (default; SA_STRIP_PASSES=2: the two-pass sweep of round 2): speculative totals per segment, sort keys
-                // per candidate slot.  Its 64-bit sort key holds 26 bits of diagonals below a traceback's start.
+                // per candidate slot.  Its 64-bit sort key holds 24 bits of diagonals below a traceback's start (de << 40).
                 b->strip_one_pass = !(getenv("SA_STRIP_PASSES") && atoi(getenv("SA_STRIP_PASSES")) == 2);
             }
             if ((pl->n_ring_regions + pl->n_fast_regions > 0 && !host_finalize) || (b->expect && pl->n_ring_regions > 0)) {
@@ -2405,7 +2460,7 @@ static int submit_group(sa_batch *b, const DevPlan &P, int g, int which_stream, 
     }
     for (int cl = 15; cl >= 0; cl--)   // widest (longest-running) classes first
         if (G.nrs[cl]) launch_bwd_ring(P, b->d_ids + G.ids_rs[cl], G.nrs[cl], st, 64 * ((cl & 7) + 1), cl >= 8, b->expect);
-    if (G.nfs) launch_bwd_fast(P, b->d_ids + G.ids_fs, G.nfs, st, b->expect);
+    if (G.nfs) { const int rcl = launch_bwd_fast(P, b->d_ids + G.ids_fs, G.nfs, st, b->expect); if (rcl) return rcl; }
     HIPCHK(hipEventRecord(b->gev[4 * g + 1], st));
     if (G.ck1 > G.ck0)
         hipLaunchKernelGGL(k_fold, dim3((unsigned) ((G.ck1 - G.ck0 + 63) / 64)), dim3(64), 0, st, P, G.ck0, G.ck1);
@@ -2441,6 +2496,10 @@ static int enqueue_pass(sa_batch *b, bool finalize, AfterGroup after_group) {
         HIPCHK(hipMemsetAsync(b->d_spec, 0xff, 8 * (size_t) (pl->n_segs > 0 ? pl->n_segs : 1), s0));
     b->h_overflow[0] = 0;  // pinned host word the kernels raise directly
     b->h_overflow[1] = 0;  // ... and the one k_finalize raises when a speculative candidate bound turns out too high
+    b->h_overflow[2] = 0;  // ... and k_check_events' / k_spec_match's: an event mean or a forward value that is not a number
+    if (pl->n_ev > 0)
+        hipLaunchKernelGGL(k_check_events, dim3((unsigned) std::min<long long>((pl->n_ev + 255) / 256, 2048)), dim3(256), 0, s0,
+                           (const double *) b->d_ev, (long long) pl->n_ev, b->h_overflow);
     HIPCHK(hipEventRecord(b->ev[0], s0));
     for (size_t c = 0; c < b->chunks.size(); c++) {
         const sa_launch_chunk &C = b->chunks[c];
@@ -2586,6 +2645,7 @@ static int run_passes(sa_batch_t *b) {
         HIPCHK(sa_sync_stream(b->cstream[0], b->device));
         rc = collect_times(b);
         if (rc) return rc;
+        if (b->h_overflow[2]) return SA_EINVAL;   // (k_spec_match: a forward value that is not a number)
         if (!b->h_overflow[0]) return SA_OK;
         rc = grow_after_overflow(b);
         if (rc) return rc;
@@ -2596,6 +2656,7 @@ static int run_passes(sa_batch_t *b) {
 static int batch_run_body(sa_batch_t *b);
 int sa_batch_run(sa_batch_t *b) {
     if (!b) return SA_EINVAL;
+    if (b->released) return SA_ESTATE;   // (sa_batch_release_device: nothing left to run on)
     { const int rcf = batch_finish(b); if (rcf) return rcf; }   // (a deferred batch: the second half of its creation)
     b->quiet = false;
     const int rc = batch_run_body(b);
@@ -2721,13 +2782,21 @@ static int batch_run_body(sa_batch_t *b) {
             fprintf(stderr, "[spec] %lld segments with a speculative total; exact total - speculative total in [%.3e, %.3e]; slack %.3g\n",
                     n_spec, worst_lo, worst_hi, b->spec_slack);
         }
-        if (b->h_overflow[1] && b->d_spec && b->spec_slack < 1e6) {
+        if (b->h_overflow[2]) {
+            fprintf(stderr, "[signalalign_hip] an event mean (or a model entry: a traceback's forward values) is not a finite number: no result\n");
+            return SA_EINVAL;
+        }
+        if (b->h_overflow[1] && b->d_spec) {
             // a traceback's exact totals fell below its speculative total minus the slack (not seen with the default slack: the
             // totals of one traceback agree to ~1e-2, the flat HDP fixture's to 0.15; tests/test_gpu_parity.py forces it with
             // SA_TEST_SPEC_SLACK): its candidates may be incomplete -- the pass is repeated with a bound far lower (more candidates,
-            // same survivors)
-            b->spec_slack *= 4.0;
-            fprintf(stderr, "[signalalign_hip] a speculative candidate bound was too high; repeating the pass with slack %.0f\n", b->spec_slack);
+            // same survivors): x4, then x256 more, and if that is not enough with no bound at all (slack +inf: every posterior
+            // cell-path is a candidate and k_finalize's check cannot fire again) -- never accepted as it is
+            if (std::isinf(b->spec_slack)) return SA_ESTATE;   // (cannot happen: with an infinite slack the flag is never raised)
+            b->spec_repeats++;
+            b->spec_slack = b->spec_repeats == 1 ? b->spec_slack * 4.0 : (b->spec_repeats == 2 ? b->spec_slack * 256.0 : (double) INFINITY);
+            if (!getenv("SA_TEST_SPEC_SLACK")) spec_memo_note(pl->model, b->device, b->spec_slack);
+            fprintf(stderr, "[signalalign_hip] a speculative candidate bound was too high; repeating the pass with slack %g\n", b->spec_slack);
             continue;
         }
         if (b->h_overflow[0]) {
@@ -2792,7 +2861,7 @@ int sa_batch_device_view(sa_batch_t *b, const sa_pair16_t **pairs, std::vector<l
     }
     *device = b->device;
     HIPCHK(hipSetDevice(b->device));
-    if (b->job_dev_off.size() == nj) {
+    if (b->job_dev_off.size() == nj && !b->released) {
         *pairs = b->d_out;
         for (size_t j = 0; j < nj; j++) (*first)[j] = b->job_dev_off[j];
         return SA_OK;
@@ -2821,6 +2890,37 @@ int sa_batch_prepare(sa_batch_t *b) {
     }
     return b->prepare_rc;
 }
+// Returns a finished batch's working storage in HBM (forward planes, candidate and result slots, plan arrays, seams: everything
+// sa_batch_stats_t.device_bytes counts) to the caching allocator and keeps what the caller reads: the packed pairs in pinned host
+// memory, the per-job offsets, the statistics.  For a caller that holds batches for their RESULTS while it creates further ones
+// (signalMachine --twoD: the template batch while the complement batch runs; a render thread formatting the previous slice): the
+// next batch then plans into the whole card.  Afterwards sa_batch_run / sa_batch_start return SA_ESTATE; sa_batch_mea still works
+// (the pairs go up again, as after SA_FLAG_EXACT).
+int sa_batch_release_device(sa_batch_t *b) {
+    if (!b) return SA_EINVAL;
+    if (!b->ran || b->runner) return SA_ESTATE;   // (between sa_batch_start and sa_batch_wait: the run is still using it)
+    if (b->released) return SA_OK;
+    if (hipSetDevice(b->device) != hipSuccess) return SA_ENODEVICE;
+    for (int i = 0; i < 2; i++) {   // (a finished run has drained them; a failed one may not have)
+        if (b->cstream[i]) HIPCHK(sa_sync_stream(b->cstream[i], b->device));
+        if (b->xstream[i]) HIPCHK(sa_sync_stream(b->xstream[i], b->device));
+    }
+    if (b->pair_stream) HIPCHK(sa_sync_stream(b->pair_stream, b->device));
+    void **ptrs[] = {(void **) &b->d_regions, (void **) &b->d_rows, (void **) &b->d_pk, (void **) &b->d_poff, (void **) &b->d_pid, (void **) &b->d_px,
+                     (void **) &b->d_xc, (void **) &b->d_prec, (void **) &b->d_ev, (void **) &b->d_segs, (void **) &b->d_cks, (void **) &b->d_F,
+                     (void **) &b->d_E, (void **) &b->d_vbuf, (void **) &b->d_cands, (void **) &b->d_cand_count, (void **) &b->d_overflow,
+                     (void **) &b->d_totals, (void **) &b->d_bscratch, (void **) &b->d_tab6, (void **) &b->d_noise3, (void **) &b->d_evn,
+                     (void **) &b->d_hdp_slot, (void **) &b->d_hdp_y, (void **) &b->d_hdp_slope, (void **) &b->d_hdp_grid, (void **) &b->d_hdp_tab,
+                     (void **) &b->d_prob, (void **) &b->d_seg_pass, (void **) &b->d_seg_off, (void **) &b->d_out, (void **) &b->d_ids,
+                     (void **) &b->d_gsum, (void **) &b->d_gmc, (void **) &b->d_seam, (void **) &b->d_ckxy, (void **) &b->d_blk, (void **) &b->d_spec,
+                     (void **) &b->d_sortkey, (void **) &b->d_sortidx};
+    for (void **pp : ptrs)
+        if (*pp) { g_sa_pool.put(SaPool::DEVICE, *pp); *pp = nullptr; }
+    if (b->held_stage) { g_sa_pool.put(SaPool::PINNED, b->held_stage); b->held_stage = nullptr; }
+    b->released = true;
+    return SA_OK;
+}
+
 int sa_batch_start(sa_batch_t *b) {
     if (!b) return SA_EINVAL;
     if (b->runner) return SA_ESTATE;

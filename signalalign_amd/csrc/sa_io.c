@@ -443,16 +443,17 @@ int sa_fasta_subsequence(const char *fasta_path, const char *name, int64_t start
 #include <pthread.h>
 #include <sys/stat.h>
 #include <unistd.h>
-typedef struct { char *key; long long len, off, bases, width; long long size; long long mtime_ns; } fai_memo_t;
+typedef struct { char *key; long long len, off, bases, width; long long size; long long mtime_ns; long long fai_sig; } fai_memo_t;
 static fai_memo_t g_fai_memo[16];
 static int g_fai_next = 0;
 static pthread_mutex_t g_fai_mu = PTHREAD_MUTEX_INITIALIZER;
-static int fai_memo_get(const char *key, const struct stat *st, long long *len, long long *off, long long *bases, long long *width) {
+static int fai_memo_get(const char *key, const struct stat *st, long long fai_sig, long long *len, long long *off, long long *bases, long long *width) {
     int hit = 0;
     pthread_mutex_lock(&g_fai_mu);
     for (int i = 0; i < 16; i++)
         if (g_fai_memo[i].key && strcmp(g_fai_memo[i].key, key) == 0 && g_fai_memo[i].size == (long long) st->st_size &&
-            g_fai_memo[i].mtime_ns == (long long) st->st_mtim.tv_sec * 1000000000ll + st->st_mtim.tv_nsec) {
+            g_fai_memo[i].mtime_ns == (long long) st->st_mtim.tv_sec * 1000000000ll + st->st_mtim.tv_nsec &&
+            g_fai_memo[i].fai_sig == fai_sig) {
             *len = g_fai_memo[i].len; *off = g_fai_memo[i].off; *bases = g_fai_memo[i].bases; *width = g_fai_memo[i].width;
             hit = 1;
             break;
@@ -460,7 +461,7 @@ static int fai_memo_get(const char *key, const struct stat *st, long long *len, 
     pthread_mutex_unlock(&g_fai_mu);
     return hit;
 }
-static void fai_memo_put(const char *key, const struct stat *st, long long len, long long off, long long bases, long long width) {
+static void fai_memo_put(const char *key, const struct stat *st, long long fai_sig, long long len, long long off, long long bases, long long width) {
     pthread_mutex_lock(&g_fai_mu);
     fai_memo_t *e = &g_fai_memo[g_fai_next];
     g_fai_next = (g_fai_next + 1) % 16;
@@ -469,6 +470,7 @@ static void fai_memo_put(const char *key, const struct stat *st, long long len, 
     e->len = len; e->off = off; e->bases = bases; e->width = width;
     e->size = (long long) st->st_size;
     e->mtime_ns = (long long) st->st_mtim.tv_sec * 1000000000ll + st->st_mtim.tv_nsec;
+    e->fai_sig = fai_sig;
     pthread_mutex_unlock(&g_fai_mu);
 }
 static char *fasta_window(const char *fasta_path, long long len, long long off, long long bases, long long width, int64_t start,
@@ -486,11 +488,22 @@ static char *fasta_window(const char *fasta_path, long long len, long long off, 
         const long long extra = width > bases ? width - bases : 1;
         const size_t want = (size_t) (n + (n / bases + 2) * extra + 2);
         char *raw = malloc(want);
-        ssize_t have = raw ? pread(fd, raw, want, (off_t) pos) : -1;
+        if (!raw) { close(fd); free(seq); if (err) *err = -1; return NULL; }
+        /* (pread may return less than asked for -- a signal, a network file system: until `want` bytes or the end of the file) */
+        size_t have = 0;
+        int failed = 0;
+        while (have < want) {
+            const ssize_t r = pread(fd, raw + have, want - have, (off_t) (pos + (long long) have));
+            if (r < 0) { failed = 1; break; }
+            if (r == 0) break;
+            have += (size_t) r;
+        }
         close(fd);
-        for (ssize_t i = 0; i < have && got < n; i++)
+        for (size_t i = 0; i < have && got < n; i++)
             if (raw[i] != '\n' && raw[i] != '\r') seq[got++] = raw[i];
         free(raw);
+        /* fewer bases than the index promises (a read error, a FASTA shorter than its .fai says): an error, not a shorter window */
+        if (failed || got < n) { free(seq); if (err) *err = -1; return NULL; }
     }
     seq[got] = 0;
     return seq;
@@ -500,12 +513,27 @@ char *sa_fasta_fetch(const char *fasta_path, const char *name, int64_t start, in
     if (err) *err = 0;
     struct stat st_fa;
     char *memo_key = NULL;
+    /* the index's own size and modification time are part of what a remembered line is valid for (a regenerated .fai -- another
+     * line width -- must not be answered from memory); 0: no index next to the FASTA */
+    long long fai_sig = 0;
+    {
+        const size_t pl0 = strlen(fasta_path);
+        char *fai0 = malloc(pl0 + 5);
+        struct stat st_fi;
+        if (fai0) {
+            memcpy(fai0, fasta_path, pl0);
+            memcpy(fai0 + pl0, ".fai", 5);
+            if (stat(fai0, &st_fi) == 0)
+                fai_sig = ((long long) st_fi.st_mtim.tv_sec * 1000000000ll + st_fi.st_mtim.tv_nsec) ^ ((long long) st_fi.st_size << 20) ^ 1;
+            free(fai0);
+        }
+    }
     if (stat(fasta_path, &st_fa) == 0) {
         memo_key = malloc(strlen(fasta_path) + strlen(name) + 2);
         if (memo_key) {
             sprintf(memo_key, "%s\n%s", fasta_path, name);
             long long l_, o_, b_, w_;
-            if (fai_memo_get(memo_key, &st_fa, &l_, &o_, &b_, &w_)) {
+            if (fai_memo_get(memo_key, &st_fa, fai_sig, &l_, &o_, &b_, &w_)) {
                 free(memo_key);
                 return fasta_window(fasta_path, l_, o_, b_, w_, start, end_incl, err);
             }
@@ -581,7 +609,7 @@ char *sa_fasta_fetch(const char *fasta_path, const char *name, int64_t start, in
     fclose(fi);
     }
     if (len < 0) { free(memo_key); if (err) *err = -2; return NULL; }
-    if (memo_key) { fai_memo_put(memo_key, &st_fa, len, off, bases, width); free(memo_key); }
+    if (memo_key) { fai_memo_put(memo_key, &st_fa, fai_sig, len, off, bases, width); free(memo_key); }
     return fasta_window(fasta_path, len, off, bases, width, start, end_incl, err);
 }
 

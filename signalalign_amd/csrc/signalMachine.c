@@ -889,6 +889,9 @@ static render_job_t *run_slice(run_t *Rp, read_t *reads, int64_t n_reads, int ba
             rc = sa_batch_create(&b, R.two_dist ? reads[who[0]].model[s] : sms[s]->model, &R.p, bj, n_ok, R.ambig, device, 0);
             if (rc == SA_OK) rc = sa_batch_run(b);
             for (int64_t j = 0; j < n_ok && rc == SA_OK; j++) rc = sa_batch_n_pairs(b, j, &n_pairs[s][j]);
+            /* only the packed pairs (pinned host memory) are read from here on: the batch's HBM goes back now, so that the
+             * complement strand's batch -- and, with a render thread, the next slice's -- plans into the whole card */
+            if (rc == SA_OK) rc = sa_batch_release_device(b);
             if (rc == SA_OK) batches[s] = b;
             else sa_batch_destroy(b);
         } else { /* the same batch, kept alive for the path step: its pairs are still on the device */

@@ -712,3 +712,42 @@ def test_speculative_bound_that_is_too_high_repeats_the_pass(oracle, monkeypatch
         assert np.array_equal(got[j], want[j]), j
     for j in range(len(cjobs)):
         assert np.array_equal(cgot[j], cwant[j]), j
+
+
+def test_released_batches_keep_their_results_and_a_nan_event_is_reported(oracle, capfd):
+    """sa_batch_release_device (round 5): a finished batch's HBM goes back to the allocator while its packed pairs, offsets and
+    statistics stay readable; running it again is SA_ESTATE, the chained MEA step still works (pairs uploaded again).  And a read
+    whose event means hold a NaN no longer comes back as an empty alignment without a word: k_spec_match sees forward values that
+    are not numbers and sa_batch_run returns SA_EINVAL."""
+    pm, om = _models(oracle, cases.MODEL_6MER)
+    p = sa.default_params()
+    jobs = cases.synthetic_jobs(cases.MODEL_6MER, 3, 900, 400)
+    b = sa.Batch(pm, p, jobs)
+    with pytest.raises(sa.SaError):
+        b.release_device()                      # before it has run
+    b.run()
+    want = [b.pairs(j).copy() for j in range(3)]
+    mea_before = b.mea()
+    dev = b.stats().device_bytes
+    b.release_device()
+    b.release_device()                          # idempotent
+    assert b.stats().device_bytes == dev
+    for j in range(3):
+        assert np.array_equal(b.pairs(j), want[j]) and np.array_equal(b.pairs16(j), sa.Batch.pairs16(b, j))
+    with pytest.raises(sa.SaError) as ei:
+        b.run()
+    assert ei.value.code == -7
+    mea_after = b.mea()
+    for x, y in zip(mea_before, mea_after):
+        assert np.array_equal(x[0], y[0]) and x[1] == y[1] and x[2] == y[2]
+    b.close()
+    bad = dict(jobs[0])
+    ev = np.array(bad["events"], dtype=np.float64).copy()
+    ev.reshape(len(ev), -1)[len(ev) // 2, 0] = np.nan
+    bad["events"] = ev
+    capfd.readouterr()
+    b2 = sa.Batch(pm, p, [jobs[1], bad])
+    with pytest.raises(sa.SaError) as ei:
+        b2.run()
+    assert ei.value.code == -1 and "not a finite number" in capfd.readouterr().err
+    b2.close()
