@@ -576,6 +576,53 @@ int sa_hmm_load_into_model(sa_model_t *m, const sa_hmm_t *h);
 /* the model's transitions as the ten tokens of a .model file's second line (linear space; tokens 5, 7 and 9 are 0) */
 int sa_model_transitions10(const sa_model_t *m, double *out10);
 
+/* ---- HDP rebuild: model construction, data, the Gibbs sweeps ----------------------------------------
+ * What buildHdpUtil (impl/buildHdpUtil.c) and updateHdpFromAssignments (impl/signalMachine.c:384-397) do around the pieces above.
+ * The sweep itself is sequential, random-number-driven host code (signalalign_amd/csrc/sa_hdpgibbs.c); every kept sample's
+ * take_distr_sample and the finalisation run on the GPU.  PARITY UNPINNED by construction: the reference draws from rand() / ranlib
+ * and walks pointer-hashed sets; here one seeded generator and insertion-ordered lists -- its tests of this code are properties
+ * (tests/hdpTests.c:109-233, tests/nanoporeHdpTests.c:272-480), checked in tests/test_gpu_hdp_rebuild.py.
+ *   sa_hdp_state_new       a NanoporeHDP without data: new_hier_dir_proc / new_hier_dir_proc_2 (impl/hdp.c:879-995) + one of the tree
+ *                          layouts of impl/nanopore_hdp.c:489-1060 + finalize_hdp_structure.  `gamma` (depth values: 2 for the flat
+ *                          layout, 3 otherwise) fixes the concentration parameters; gamma == NULL takes a Gamma prior on them
+ *                          (gamma_alpha, gamma_beta per depth) and the sweeps sample them.  `groups`: per letter of `alphabet` (as
+ *                          given, unsorted) -- SA_HDP_LAYOUT_COMPOSITION: non-zero = purine; SA_HDP_LAYOUT_GROUP_MULTISET: group number
+ *   sa_hdp_nig_params_from_table  normal_inverse_gamma_params_from_minION (impl/nanopore_hdp.c:122-176): mu, nu, alpha, beta by maximum
+ *                          likelihood from a lookup table's level means and level sds
+ *   sa_hdp_state_pass_data / _pass_assignments / _pass_assignment_file   reset_hdp_data + pass_data_to_hdp (impl/hdp.c:1549-1660:
+ *                          observed DPs marked, one chain of factors per observed DP under one base factor); from (k-mer, event)
+ *                          assignments as hdpHmm_loadFromFile hands them on (impl/continuousHmm.c:722-780: sa_hmm_view's arrays);
+ *                          from an assignments / alignment table (update_nhdp_from_alignment_with_filter, impl/nanopore_hdp.c:206-297;
+ *                          strand_filter NULL: every row).  A k-mer outside the alphabet: SA_EALPHABET (the reference exits)
+ *   sa_hdp_state_gibbs     execute_gibbs_sampling (impl/hdp.c:2486-2549): num_samples distribution samples, one per `thinning`
+ *                          iterations behind `burn_in`; the collectors are ADDED to the state's (several calls continue one run)
+ *   sa_hdp_state_finalize  finalize_distributions (:2551-2584); afterwards sa_hdp_state_write gives a .nhdp the aligner loads
+ * SA_ESTATE: sampling without data or after finalisation, finalising without samples. */
+#define SA_HDP_LAYOUT_FLAT 0            /* flat_hdp_model: every k-mer under the base DP (singleLevel*)        */
+#define SA_HDP_LAYOUT_MULTISET 1        /* multiset_hdp_model: k-mers grouped by their multiset of letters     */
+#define SA_HDP_LAYOUT_MIDDLE_NTS 2      /* middle_2_nts_hdp_model: by their two middle letters                 */
+#define SA_HDP_LAYOUT_COMPOSITION 3     /* purine_composition_hdp_model: by their number of purines            */
+#define SA_HDP_LAYOUT_GROUP_MULTISET 4  /* group_multiset_hdp_model: by the multiset of their letters' groups  */
+int sa_hdp_state_new(sa_hdp_state_t **out, int layout, const char *alphabet, int64_t kmer_length, const int64_t *groups,
+                     const double *gamma, const double *gamma_alpha, const double *gamma_beta, double grid_start, double grid_stop,
+                     int64_t grid_length, double mu, double nu, double alpha, double beta);
+/* the same over any tree of Dirichlet processes (set_dir_proc_parent for every DP, parents[base] = -1, every leaf at depth - 1): a
+ * plain HierarchicalDirichletProcess, what the reference's own HDP tests build (tests/nanoporeHdpTests.c:272-345) */
+int sa_hdp_state_new_tree(sa_hdp_state_t **out, int64_t num_dps, int64_t depth, const int64_t *parents, const double *gamma,
+                          const double *gamma_alpha, const double *gamma_beta, double grid_start, double grid_stop, int64_t grid_length,
+                          double mu, double nu, double alpha, double beta);
+int sa_hdp_nig_params_from_table(const double *table5, int64_t n_kmers, double *mu_out, double *nu_out, double *alpha_out,
+                                 double *beta_out);
+int sa_hdp_state_pass_data(sa_hdp_state_t *s, const double *data, const int64_t *dp_ids, int64_t n);
+int sa_hdp_state_pass_assignments(sa_hdp_state_t *s, const char *kmers /* k characters each */, const double *events, int64_t n);
+int sa_hdp_state_pass_assignment_file(sa_hdp_state_t *s, const char *path, const char *strand_filter, int64_t *n_out);
+int sa_hdp_state_kmer_dp(const sa_hdp_state_t *s, const char *kmer);   /* kmer_id (impl/nanopore_hdp.c:405-410), -1 outside the alphabet */
+int sa_hdp_state_gibbs(sa_hdp_state_t *s, int64_t num_samples, int64_t burn_in, int64_t thinning, uint64_t seed, int device, int verbose);
+int sa_hdp_state_finalize(sa_hdp_state_t *s, int device);
+int64_t sa_hdp_state_samples_taken(const sa_hdp_state_t *s);
+double sa_hdp_digamma(double x);    /* test hooks: the two special functions of the maximum-likelihood alpha (x > 0) */
+double sa_hdp_trigamma(double x);
+
 int sa_device_count(void);
 /* HBM of `device`: bytes free (what the library's caching allocator holds counts as free) and in total; a caller that keeps
  * several batches in flight sizes its pipeline with this (sa_batch_stats_t.f_bytes is the bulk of a batch) */

@@ -85,6 +85,7 @@ EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alp
            "sa_batch_job_cells", "sa_batch_release_device", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_expect_last_stats", "sa_plan_describe", "sa_plan_digest",
            "sa_plan_check_path_records", "sa_dplan_compare",
            "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_pool_configure", "sa_host_alloc", "sa_host_free", "sa_pair_roundtrip", "sa_fasta_subsequence", "sa_format_f6", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_device_memory", "sa_strerror", "sa_hdp_state_load", "sa_hdp_state_write", "sa_hdp_state_info", "sa_hdp_state_free", "sa_hdp_state_distr_sample", "sa_hdp_state_sample_weights", "sa_hdp_finalize_distributions",
+           "sa_hdp_state_new", "sa_hdp_state_new_tree", "sa_hdp_nig_params_from_table", "sa_hdp_state_pass_data", "sa_hdp_state_pass_assignments", "sa_hdp_state_pass_assignment_file", "sa_hdp_state_kmer_dp", "sa_hdp_state_gibbs", "sa_hdp_state_finalize", "sa_hdp_state_samples_taken", "sa_hdp_digamma", "sa_hdp_trigamma",
            "sa_hmm_create", "sa_hmm_destroy", "sa_hmm_view", "sa_hmm_set_event_model", "sa_hmm_add_expectations",
            "sa_hmm_add_emission_expectation", "sa_hmm_add_assignment", "sa_hmm_add_expectations_file", "sa_hmm_write", "sa_hmm_load", "sa_hmm_normalize",
            "sa_hmm_load_into_model", "sa_model_transitions10",
@@ -228,6 +229,23 @@ def lib():
     L.sa_hdp_state_distr_sample.argtypes = [C.c_void_p, C.c_int, dp]
     L.sa_hdp_state_sample_weights.argtypes = [C.c_void_p, C.POINTER(ip), C.POINTER(ip), C.POINTER(dp), ip]
     L.sa_hdp_finalize_distributions.argtypes = [dp, C.c_int64, dp, C.c_int64, C.c_int64, C.c_int, dp, dp]
+    L.sa_hdp_state_new.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_int64, ip, dp, dp, dp, C.c_double, C.c_double, C.c_int64,
+                                   C.c_double, C.c_double, C.c_double, C.c_double]
+    L.sa_hdp_state_new_tree.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, ip, dp, dp, dp, C.c_double, C.c_double, C.c_int64,
+                                        C.c_double, C.c_double, C.c_double, C.c_double]
+    L.sa_hdp_nig_params_from_table.argtypes = [dp, C.c_int64, dp, dp, dp, dp]
+    L.sa_hdp_state_pass_data.argtypes = [C.c_void_p, dp, ip, C.c_int64]
+    L.sa_hdp_state_pass_assignments.argtypes = [C.c_void_p, C.c_char_p, dp, C.c_int64]
+    L.sa_hdp_state_pass_assignment_file.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, ip]
+    L.sa_hdp_state_kmer_dp.argtypes = [C.c_void_p, C.c_char_p]
+    L.sa_hdp_state_gibbs.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_int, C.c_int]
+    L.sa_hdp_state_finalize.argtypes = [C.c_void_p, C.c_int]
+    L.sa_hdp_state_samples_taken.argtypes = [C.c_void_p]
+    L.sa_hdp_state_samples_taken.restype = C.c_int64
+    L.sa_hdp_digamma.argtypes = [C.c_double]
+    L.sa_hdp_digamma.restype = C.c_double
+    L.sa_hdp_trigamma.argtypes = [C.c_double]
+    L.sa_hdp_trigamma.restype = C.c_double
     _LIB = L
     return L
 
@@ -890,11 +908,79 @@ class HdpState:
     """The whole state of a serialised NanoporeHDP (sa_hdp_state_*: the deterministic pieces of the HDP rebuild).  Arrays are
     copies (numpy) of the views sa_hdp_state_info hands out."""
 
-    def __init__(self, path):
-        self._h = C.c_void_p()
-        _chk(lib().sa_hdp_state_load(C.byref(self._h), os.fsencode(path)), "sa_hdp_state_load")
+    def __init__(self, path=None, _handle=None):
+        self._h = _handle if _handle is not None else C.c_void_p()
+        if _handle is None:
+            _chk(lib().sa_hdp_state_load(C.byref(self._h), os.fsencode(path)), "sa_hdp_state_load")
         self.info = HdpStateInfo()
+        self.refresh()
+
+    def refresh(self):
+        """the info views again (after a call that changed the state: data passed, a sampling run, finalisation)"""
         _chk(lib().sa_hdp_state_info(self._h, C.byref(self.info)), "sa_hdp_state_info")
+
+    @classmethod
+    def new(cls, layout, alphabet, kmer_length, grid, nig, gamma=None, gamma_alpha=None, gamma_beta=None, groups=None):
+        """sa_hdp_state_new: a NanoporeHDP without data.  layout: HDP_LAYOUT_*; grid = (start, stop, length); nig = (mu, nu, alpha,
+        beta); gamma: fixed concentration parameters by depth, or gamma_alpha / gamma_beta: a Gamma prior on them."""
+        h = C.c_void_p()
+        g = None if gamma is None else np.ascontiguousarray(gamma, dtype=np.float64)
+        ga = None if gamma_alpha is None else np.ascontiguousarray(gamma_alpha, dtype=np.float64)
+        gb = None if gamma_beta is None else np.ascontiguousarray(gamma_beta, dtype=np.float64)
+        gr = None if groups is None else np.ascontiguousarray(groups, dtype=np.int64)
+        _chk(lib().sa_hdp_state_new(C.byref(h), int(layout), alphabet.encode(), int(kmer_length), None if gr is None else _ip(gr),
+                                    None if g is None else _dp(g), None if ga is None else _dp(ga), None if gb is None else _dp(gb),
+                                    float(grid[0]), float(grid[1]), int(grid[2]), float(nig[0]), float(nig[1]), float(nig[2]), float(nig[3])),
+             "sa_hdp_state_new")
+        return cls(_handle=h)
+
+    @classmethod
+    def new_tree(cls, parents, depth, grid, nig, gamma=None, gamma_alpha=None, gamma_beta=None):
+        """sa_hdp_state_new_tree: a plain HierarchicalDirichletProcess over the tree `parents` (-1 for the base DP)"""
+        h = C.c_void_p()
+        pa = np.ascontiguousarray(parents, dtype=np.int64)
+        g = None if gamma is None else np.ascontiguousarray(gamma, dtype=np.float64)
+        ga = None if gamma_alpha is None else np.ascontiguousarray(gamma_alpha, dtype=np.float64)
+        gb = None if gamma_beta is None else np.ascontiguousarray(gamma_beta, dtype=np.float64)
+        _chk(lib().sa_hdp_state_new_tree(C.byref(h), len(pa), int(depth), _ip(pa), None if g is None else _dp(g),
+                                         None if ga is None else _dp(ga), None if gb is None else _dp(gb), float(grid[0]), float(grid[1]),
+                                         int(grid[2]), float(nig[0]), float(nig[1]), float(nig[2]), float(nig[3])), "sa_hdp_state_new_tree")
+        return cls(_handle=h)
+
+    def pass_data(self, data, dp_ids):
+        d = np.ascontiguousarray(data, dtype=np.float64)
+        i = np.ascontiguousarray(dp_ids, dtype=np.int64)
+        _chk(lib().sa_hdp_state_pass_data(self._h, _dp(d), _ip(i), len(d)), "sa_hdp_state_pass_data")
+        self.refresh()
+
+    def pass_assignments(self, kmers, events):
+        """(k-mers as a list of str or one concatenated str, event means): hdpHmm_loadFromFile's hand-over"""
+        km = kmers if isinstance(kmers, str) else "".join(kmers)
+        e = np.ascontiguousarray(events, dtype=np.float64)
+        _chk(lib().sa_hdp_state_pass_assignments(self._h, km.encode(), _dp(e), len(e)), "sa_hdp_state_pass_assignments")
+        self.refresh()
+
+    def pass_assignment_file(self, path, strand=None):
+        n = C.c_int64()
+        _chk(lib().sa_hdp_state_pass_assignment_file(self._h, os.fsencode(path), None if strand is None else strand.encode(), C.byref(n)),
+             "sa_hdp_state_pass_assignment_file")
+        self.refresh()
+        return n.value
+
+    def kmer_dp(self, kmer):
+        return lib().sa_hdp_state_kmer_dp(self._h, kmer.encode())
+
+    def gibbs(self, num_samples, burn_in, thinning, seed=1, device=0, verbose=False):
+        _chk(lib().sa_hdp_state_gibbs(self._h, int(num_samples), int(burn_in), int(thinning), int(seed), device, 1 if verbose else 0),
+             "sa_hdp_state_gibbs")
+        self.refresh()
+
+    def finalize(self, device=0):
+        _chk(lib().sa_hdp_state_finalize(self._h, device), "sa_hdp_state_finalize")
+        self.refresh()
+
+    def samples_taken(self):
+        return int(lib().sa_hdp_state_samples_taken(self._h))
 
     def close(self):
         if self._h:
@@ -943,6 +1029,17 @@ class HdpState:
         out = np.zeros((int(self.info.n_observed), int(self.info.grid_length)), dtype=np.float64)
         _chk(lib().sa_hdp_state_distr_sample(self._h, device, _dp(out)), "sa_hdp_state_distr_sample")
         return out
+
+
+HDP_LAYOUT_FLAT, HDP_LAYOUT_MULTISET, HDP_LAYOUT_MIDDLE_NTS, HDP_LAYOUT_COMPOSITION, HDP_LAYOUT_GROUP_MULTISET = 0, 1, 2, 3, 4
+
+
+def hdp_nig_params_from_table(table5):
+    """sa_hdp_nig_params_from_table: (mu, nu, alpha, beta) by maximum likelihood from a lookup table (5 doubles per k-mer)"""
+    t = np.ascontiguousarray(table5, dtype=np.float64).reshape(-1)
+    out = [C.c_double() for _ in range(4)]
+    _chk(lib().sa_hdp_nig_params_from_table(_dp(t), len(t) // 5, *[C.byref(o) for o in out]), "sa_hdp_nig_params_from_table")
+    return tuple(o.value for o in out)
 
 
 def hdp_finalize_distributions(grid, collectors, samples, device=0):

@@ -181,6 +181,131 @@ extern "C" int sa_hdp_state_distr_sample(const sa_hdp_state_t *s, int device, do
     return SA_OK;
 }
 
+
+// ---- the collectors of a sampling run (sa_hdpgibbs.c: sa_hdp_state_gibbs) ---------------------------------------------------
+// take_distr_sample (impl/hdp.c:2067-2092) once per kept sample of the Gibbs run: the collectors (observed DPs x grid points) stay
+// in HBM for the whole run, a sample brings its weights (CSR, from the host: sa_hdp_state_weights) and the base factors'
+// normal-inverse-gamma parameters, k_hdp_pdf evaluates the posterior predictives and the prior on the grid and k_hdp_mix_add adds
+// every observed DP's mixture to its collector.
+__global__ __launch_bounds__(256) void k_hdp_mix_add(const long long *__restrict__ row_start, const long long *__restrict__ col,
+                                                     const double *__restrict__ w, const double *__restrict__ P, int grid_length,
+                                                     double *__restrict__ out) {
+    const int i = (int) (blockIdx.x * blockDim.x + threadIdx.x);
+    const long long r = blockIdx.y;
+    if (i >= grid_length) return;
+    double acc = 0.0;
+    for (long long e = row_start[r]; e < row_start[r + 1]; e++) acc += w[e] * P[(size_t) col[e] * (size_t) grid_length + (size_t) i];
+    out[(size_t) r * (size_t) grid_length + (size_t) i] += acc;
+}
+
+struct sa_hdp_sampler {
+    int device;
+    int64_t G, nrow;
+    double *d_grid = nullptr, *d_sum = nullptr, *d_P = nullptr, *d_w = nullptr;
+    HdpCol *d_cols = nullptr;
+    long long *d_rs = nullptr, *d_col = nullptr;
+    int64_t cap_cols = 0, cap_nnz = 0;
+};
+
+extern "C" void sa_hdp_sampler_close(sa_hdp_sampler *h) {
+    if (!h) return;
+    (void) hipSetDevice(h->device);
+    void *ptrs[] = {h->d_grid, h->d_sum, h->d_P, h->d_w, h->d_cols, h->d_rs, h->d_col};
+    for (void *p : ptrs)
+        if (p) (void) hipFree(p);
+    delete h;
+}
+
+extern "C" int sa_hdp_sampler_open(sa_hdp_sampler **out, const sa_hdp_state_t *s, int device) {
+    if (!out || !s) return SA_EINVAL;
+    if (!s->has_data) return SA_ESTATE;
+    int rc = use_device(device);
+    if (rc) return rc;
+    sa_hdp_sampler *h = new (std::nothrow) sa_hdp_sampler();
+    if (!h) return SA_ENOMEM;
+    h->device = device; h->G = s->grid_length; h->nrow = s->n_observed;
+    const size_t plane = sizeof(double) * (size_t) (h->nrow > 0 ? h->nrow : 1) * (size_t) h->G;
+    if (hipMalloc((void **) &h->d_grid, sizeof(double) * (size_t) h->G) != hipSuccess || hipMalloc((void **) &h->d_sum, plane) != hipSuccess ||
+        hipMalloc((void **) &h->d_rs, sizeof(long long) * (size_t) (h->nrow + 2)) != hipSuccess ||
+        hipMemcpy(h->d_grid, s->grid, sizeof(double) * (size_t) h->G, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(h->d_sum, 0, plane) != hipSuccess) {
+        sa_hdp_sampler_close(h);
+        return SA_ENOMEM;
+    }
+    *out = h;
+    return SA_OK;
+}
+
+extern "C" int sa_hdp_sampler_add(sa_hdp_sampler *h, const sa_hdp_state_t *s) {
+    if (!h || !s || s->n_observed != h->nrow || s->grid_length != h->G) return SA_EINVAL;
+    if (hipSetDevice(h->device) != hipSuccess) return SA_ENODEVICE;
+    int64_t *row_start = nullptr, *col = nullptr, nnz = 0;
+    double *w = nullptr;
+    int rc = sa_hdp_state_weights(s, &row_start, &col, &w, &nnz);
+    if (rc) return rc;
+    struct Free3 { int64_t *a, *b; double *c; ~Free3() { free(a); free(b); free(c); } } free3{row_start, col, w};
+    const int64_t nb = s->n_base_factors, G = h->G, nrow = h->nrow;
+    std::vector<HdpCol> cols((size_t) (nb > 0 ? nb : 1));
+    int64_t c = 0;
+    for (int64_t f = 0; f < s->n_factors; f++) {
+        if (s->f_type[f] != 0) continue;
+        const double *pa = s->f_params + 5 * f;
+        HdpCol k;
+        const double nu_numer = pa[1] + 1.0;
+        k.mu = pa[0]; k.nu_ratio = pa[1] / nu_numer; k.beta_denom = pa[3]; k.two_alpha_numer = pa[2] + 1.0;
+        k.lg_half = lgamma(0.5 * k.two_alpha_numer); k.log_nu_numer = log(nu_numer); k.log_denom = pa[4]; k.pad = 0.0;
+        cols[(size_t) c++] = k;
+    }
+    if (nb + 1 > h->cap_cols) {   // (the number of base factors moves from sample to sample: grow in steps)
+        if (h->d_cols) (void) hipFree(h->d_cols);
+        if (h->d_P) (void) hipFree(h->d_P);
+        h->d_cols = nullptr; h->d_P = nullptr;
+        h->cap_cols = 2 * (nb + 1) + 16;
+        if (hipMalloc((void **) &h->d_cols, sizeof(HdpCol) * (size_t) h->cap_cols) != hipSuccess ||
+            hipMalloc((void **) &h->d_P, sizeof(double) * (size_t) h->cap_cols * (size_t) G) != hipSuccess) { h->cap_cols = 0; return SA_ENOMEM; }
+    }
+    if (nnz > h->cap_nnz) {
+        if (h->d_col) (void) hipFree(h->d_col);
+        if (h->d_w) (void) hipFree(h->d_w);
+        h->d_col = nullptr; h->d_w = nullptr;
+        h->cap_nnz = 2 * nnz + 1024;
+        if (hipMalloc((void **) &h->d_col, sizeof(long long) * (size_t) h->cap_nnz) != hipSuccess ||
+            hipMalloc((void **) &h->d_w, sizeof(double) * (size_t) h->cap_nnz) != hipSuccess) { h->cap_nnz = 0; return SA_ENOMEM; }
+    }
+    if (hipMemcpy(h->d_cols, cols.data(), sizeof(HdpCol) * (size_t) (nb > 0 ? nb : 1), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->d_rs, row_start, sizeof(long long) * (size_t) (nrow + 1), hipMemcpyHostToDevice) != hipSuccess ||
+        (nnz > 0 && (hipMemcpy(h->d_col, col, sizeof(long long) * (size_t) nnz, hipMemcpyHostToDevice) != hipSuccess ||
+                     hipMemcpy(h->d_w, w, sizeof(double) * (size_t) nnz, hipMemcpyHostToDevice) != hipSuccess)))
+        return SA_ENODEVICE;
+    const double two_alpha = 2.0 * s->alpha;
+    const double nu_factor = s->nu / (2.0 * (s->nu + 1.0) * s->beta);
+    const double constant_term = exp(lgamma(.5 * (two_alpha + 1.0)) - lgamma(.5 * two_alpha)) * sqrt(nu_factor / M_PI);
+    const double alpha_power = -0.5 * (two_alpha + 1.0);
+    const unsigned gx = (unsigned) ((G + 255) / 256);
+    for (int64_t c0 = 0; c0 <= nb; c0 += 65535) {
+        const int64_t n = nb + 1 - c0 < 65535 ? nb + 1 - c0 : 65535;
+        hipLaunchKernelGGL(k_hdp_pdf, dim3(gx, (unsigned) n), dim3(256), 0, 0, (const HdpCol *) h->d_cols + c0, (int) (nb - c0 > 0 ? nb - c0 : 0),
+                           (const double *) h->d_grid, (int) G, s->mu, nu_factor, constant_term, alpha_power, h->d_P + (size_t) c0 * (size_t) G);
+    }
+    for (int64_t r0 = 0; r0 < nrow; r0 += 65535) {
+        const int64_t n = nrow - r0 < 65535 ? nrow - r0 : 65535;
+        hipLaunchKernelGGL(k_hdp_mix_add, dim3(gx, (unsigned) n), dim3(256), 0, 0, (const long long *) h->d_rs + r0, (const long long *) h->d_col,
+                           (const double *) h->d_w, (const double *) h->d_P, (int) G, h->d_sum + (size_t) r0 * (size_t) G);
+    }
+    // (the next sample's uploads are blocking copies on the same stream: they order themselves behind these kernels)
+    return hipGetLastError() == hipSuccess ? SA_OK : SA_ENODEVICE;
+}
+
+extern "C" int sa_hdp_sampler_finish(sa_hdp_sampler *h, double *sum_out) {
+    if (!h || !sum_out) { sa_hdp_sampler_close(h); return SA_EINVAL; }
+    int rc = SA_OK;
+    if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+        (h->nrow > 0 && hipMemcpy(sum_out, h->d_sum, sizeof(double) * (size_t) h->nrow * (size_t) h->G, hipMemcpyDeviceToHost) != hipSuccess))
+        rc = SA_ENODEVICE;
+    sa_hdp_sampler_close(h);
+    return rc;
+}
+
 extern "C" int sa_hdp_finalize_distributions(const double *grid, int64_t grid_length, const double *sum, int64_t n_rows, int64_t samples,
                                              int device, double *y_out, double *slope_out) {
     if (!grid || !sum || !slope_out || grid_length < 2 || grid_length > (1 << 24) || n_rows < 0 || samples <= 0) return SA_EINVAL;

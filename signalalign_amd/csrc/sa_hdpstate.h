@@ -28,6 +28,7 @@ struct sa_hdp_state {
     int64_t *f_ref;                  /* the factor's DP (base, middle) or its data index (data point) */
     double *f_params;                /* 5 per factor: mu, nu, two_alpha, beta, log posterior term (base factors) */
     int64_t *f_n_children;
+    int64_t samples_taken;           /* distribution samples in `post` since the data were passed (not serialised: impl/hdp.c:2919-3050) */
 };
 /* CSR weights of one distribution sample (see sa_hdpstate.c); the three arrays are malloc'ed */
 int sa_hdp_state_weights(const struct sa_hdp_state *s, int64_t **row_start_out, int64_t **col_out, double **w_out, int64_t *nnz_out);
