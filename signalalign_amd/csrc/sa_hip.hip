@@ -51,6 +51,7 @@ struct DevModel {
     const int *hdp_slot;    // per k-mer: row of y/slope tables of the first observed ancestor, -1 if none
     const double *hdp_y, *hdp_slope, *hdp_grid;
     const double *hdp_tab;  // register kernels: {y[i], slope[i]} interleaved, one row per observed process
+    const double *hdp_coef; // k_emit_hdp: the four cubic coefficients of interval i of every row (twice the size of hdp_tab)
     double hdp_g0, hdp_gN, hdp_dx;
     unsigned hdp_tab_bytes;
     int grid_len;
@@ -1246,7 +1247,7 @@ struct sa_batch {
     unsigned seam_cap;
     unsigned seam_cap_bwd;   // records per seam array of the backward launches (a traceback segment is shorter than a region)
     long long seam_bwd_off;  // bytes: the forward launch's slots come first, then those of a pass's backward launches
-    double *d_tab6; double *d_noise3; double *d_evn; int *d_hdp_slot; double *d_hdp_y, *d_hdp_slope, *d_hdp_grid, *d_hdp_tab;
+    double *d_tab6; double *d_noise3; double *d_evn; int *d_hdp_slot; double *d_hdp_y, *d_hdp_slope, *d_hdp_grid, *d_hdp_tab, *d_hdp_coef;
     long long *d_prob; int *d_seg_pass; long long *d_seg_off; sa_pair16_t *d_out;
     int *d_ids;  // region / segment id lists per launch
     long long cand_alloc;
@@ -1335,6 +1336,7 @@ static DevPlan make_devplan(const sa_batch *b) {
     if (m->hdp) {
         const sa_hdp_t *h = m->hdp;
         P.m.hdp_tab = b->d_hdp_tab;
+        P.m.hdp_coef = b->d_hdp_coef;
         P.m.hdp_g0 = h->grid[0];
         P.m.hdp_gN = h->grid[h->grid_length - 1];
         P.m.hdp_dx = h->grid[1] - h->grid[0];  // grid_spline_interp: dx = x[1] - x[0]
@@ -1669,7 +1671,7 @@ void sa_batch_destroy(sa_batch_t *b) {
     const double td1 = now_ms_d();
     void *ptrs[] = {b->d_regions, b->d_rows, b->d_pk, b->d_poff, b->d_pid, b->d_px, b->d_xc, b->d_prec, b->d_ev, b->d_segs, b->d_cks, b->d_F, b->d_E,
                     b->d_vbuf, b->d_cands, b->d_cand_count, b->d_overflow, b->d_totals, b->d_bscratch, b->d_tab6, b->d_noise3, b->d_evn,
-                    b->d_hdp_slot, b->d_hdp_y, b->d_hdp_slope, b->d_hdp_grid, b->d_hdp_tab, b->d_prob, b->d_seg_pass, b->d_seg_off,
+                    b->d_hdp_slot, b->d_hdp_y, b->d_hdp_slope, b->d_hdp_grid, b->d_hdp_tab, b->d_hdp_coef, b->d_prob, b->d_seg_pass, b->d_seg_off,
                     b->d_out, b->d_ids, b->d_gsum, b->d_gmc, b->d_seam, b->d_ckxy, b->d_blk, b->d_spec, b->d_sortkey, b->d_sortidx};
     for (void *p : ptrs)
         if (p) g_sa_pool.put(SaPool::DEVICE, p);
@@ -1758,7 +1760,7 @@ static int batch_create_impl(sa_batch_t **out, const sa_model_t *m, const sa_par
         if (v_ > 0.0) b->spec_slack = v_;
     }
     b->d_bscratch = nullptr; b->d_tab6 = nullptr; b->d_noise3 = nullptr; b->d_evn = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr;
-    b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr; b->d_hdp_tab = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr;
+    b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr; b->d_hdp_tab = nullptr; b->d_hdp_coef = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr;
     b->d_seg_off = nullptr; b->d_out = nullptr; b->d_ids = nullptr; b->d_gsum = nullptr; b->d_gmc = nullptr;
     b->cand_alloc = 0; b->out_alloc = 0; b->cand_factor = 1; b->spec_repeats = 0;
     b->h_pairs = nullptr; b->h_pairs_cap = 0; b->n_pairs_total = 0;
@@ -2138,6 +2140,20 @@ static int batch_prepare_body(sa_batch *b) {
                 tab[2 * i + 1] = h->slope[i];
             }
             TRY(upload(&b->d_hdp_tab, tab.data(), (long long) tab.size()));
+            // the same spline as a cubic in the position inside interval i (k_emit_hdp, sa_fast.inc): c0 + c1 t + c2 t^2 + c3 t^3 with
+            // the combinations formed in long double; the last entry of a row (no interval to its right) stays zero
+            std::vector<double> coef((size_t) (h->n_slots * h->grid_length * 4), 0.0);
+            const long double dxl = (long double) h->grid[1] - (long double) h->grid[0];
+            for (long long s = 0; s < h->n_slots; s++)
+                for (long long i = 0; i + 1 < h->grid_length; i++) {
+                    const long long k = s * h->grid_length + i;
+                    const long double y0 = h->y[k], y1 = h->y[k + 1], s0 = h->slope[k], s1 = h->slope[k + 1], dy = y1 - y0;
+                    coef[4 * k] = (double) y0;
+                    coef[4 * k + 1] = (double) (s0 * dxl);
+                    coef[4 * k + 2] = (double) (3.0L * dy - (2.0L * s0 + s1) * dxl);
+                    coef[4 * k + 3] = (double) ((s0 + s1) * dxl - 2.0L * dy);
+                }
+            TRY(upload(&b->d_hdp_coef, coef.data(), (long long) coef.size()));
         }
     }
     {   // emission constants, on the device (same stream as the uploads they read)
@@ -2370,7 +2386,7 @@ int sa_dplan_compare(const sa_model_t *m, const sa_params_t *p, const sa_job_t *
     b->d_prec = nullptr; b->d_blk = nullptr; b->d_ev = nullptr; b->d_segs = nullptr; b->d_cks = nullptr; b->d_F = nullptr; b->d_E = nullptr; b->d_vbuf = nullptr;
     b->d_cands = nullptr; b->d_cand_count = nullptr; b->d_overflow = nullptr; b->d_totals = nullptr; b->d_bscratch = nullptr;
     b->d_tab6 = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr; b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr;
-    b->d_hdp_tab = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr; b->d_seg_off = nullptr; b->d_out = nullptr;
+    b->d_hdp_tab = nullptr; b->d_hdp_coef = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr; b->d_seg_off = nullptr; b->d_out = nullptr;
     b->d_ids = nullptr; b->d_gsum = nullptr; b->d_gmc = nullptr; b->d_seam = nullptr; b->d_ckxy = nullptr;
     b->d_spec = nullptr; b->d_sortkey = nullptr; b->d_sortidx = nullptr;
     int rcd;
@@ -2910,7 +2926,7 @@ int sa_batch_release_device(sa_batch_t *b) {
                      (void **) &b->d_xc, (void **) &b->d_prec, (void **) &b->d_ev, (void **) &b->d_segs, (void **) &b->d_cks, (void **) &b->d_F,
                      (void **) &b->d_E, (void **) &b->d_vbuf, (void **) &b->d_cands, (void **) &b->d_cand_count, (void **) &b->d_overflow,
                      (void **) &b->d_totals, (void **) &b->d_bscratch, (void **) &b->d_tab6, (void **) &b->d_noise3, (void **) &b->d_evn,
-                     (void **) &b->d_hdp_slot, (void **) &b->d_hdp_y, (void **) &b->d_hdp_slope, (void **) &b->d_hdp_grid, (void **) &b->d_hdp_tab,
+                     (void **) &b->d_hdp_slot, (void **) &b->d_hdp_y, (void **) &b->d_hdp_slope, (void **) &b->d_hdp_grid, (void **) &b->d_hdp_tab, (void **) &b->d_hdp_coef,
                      (void **) &b->d_prob, (void **) &b->d_seg_pass, (void **) &b->d_seg_off, (void **) &b->d_out, (void **) &b->d_ids,
                      (void **) &b->d_gsum, (void **) &b->d_gmc, (void **) &b->d_seam, (void **) &b->d_ckxy, (void **) &b->d_blk, (void **) &b->d_spec,
                      (void **) &b->d_sortkey, (void **) &b->d_sortidx};
