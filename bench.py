@@ -1132,6 +1132,8 @@ def main():
     ap.add_argument("--job-slice", type=int, default=2000, help="reads per batch of the scaling job")
     ap.add_argument("--job-sets", type=int, default=2, help="distinct slice-sized read sets a rank generates and cycles")
     ap.add_argument("--no-scaling-job", action="store_true", help="skip config.scaling_job")
+    ap.add_argument("--legs", default=None, help="comma-separated names of the config.secondary legs to run (default: all) -- for "
+                                                 "looking at one leg in the context of the default run")
     ap.add_argument("--secondary-budget-s", type=float, default=330.0,
                     help="a secondary leg is not started once the run has taken this long (the default line must stay well inside "
                          "the driver's time limit)")
@@ -1219,7 +1221,12 @@ def main():
         sec = out["config"]["secondary"] = {}
         t_start = ctx["t_start"]
 
+        only = None if not args.legs else set(args.legs.split(","))
+
         def leg(name, wl, reads, events, threshold, steps, warmup, cpu=True):
+            if only is not None and name not in only:
+                sec[name] = {"skipped": "--legs"}
+                return None
             if time.perf_counter() - t_start > args.secondary_budget_s:
                 sec[name] = {"skipped": "wall-time budget of the default run (%d s) reached" % args.secondary_budget_s}
                 return None
@@ -1239,6 +1246,10 @@ def main():
             sec[name] = {
                 "workload": r2["config"]["workload"], "value": r2["value"], "ms_per_step": r2["ms_per_step"], "steps": r2["steps"],
                 "median_ms_per_step_one_batch_at_a_time": r2.get("median_ms_per_step_one_batch_at_a_time"),
+                # (one batch at a time: the same figure from the median step -- a single stalled step, e.g. a hipMalloc of tens of
+                # GB that took seconds, moves `value` of a 4-step leg by an order of magnitude and this one not at all)
+                "value_from_median_step": (None if not r2.get("median_ms_per_step_one_batch_at_a_time") else
+                                           r2["value"] * r2["ms_per_step"] / r2["median_ms_per_step_one_batch_at_a_time"]),
                 "events_per_s": r2["config"]["events_per_s"],
                 "kernels_only_value": r2["config"]["kernels_only_resident_inputs"]["value"],
                 "kernel_ms": r2["config"]["kernel_ms"], "pairs_per_event": r2["config"]["pairs_per_event"],
@@ -1256,12 +1267,14 @@ def main():
         ks = max(4, min(args.steps, 10))
         leg("realistic", "realistic", 2000, 5000, 0.01, ks, max(5, args.in_flight + 3))
         leg("cpg", "cpg", 10000, 5000, 0.01, 5, 2)
-        if leg("hdp", "hdp", 5000, 5000, 0.1, ks, max(5, args.in_flight + 3)) is not None:
+        if leg("hdp", "hdp", 5000, 5000, 0.1, ks, max(5, args.in_flight + 3)) is not None or (only and "hdp_threshold_0.01" in only):
             r3 = leg("hdp_threshold_0.01", "hdp", 5000, 5000, 0.01, 3, 1, cpu=False)
             if r3 is not None:
                 sec["hdp_threshold_0.01"]["note"] = ("the bundled .nhdp is flat (every process: mean 59.8, sd 15.5 pA): 17.8 pairs "
                                                      "per event at 0.01, the step is their PCIe transfer")
-        if time.perf_counter() - t_start <= args.secondary_budget_s:
+        if only is not None and "expectations" not in only:
+            sec["expectations"] = {"skipped": "--legs"}
+        elif time.perf_counter() - t_start <= args.secondary_budget_s:
             t_leg = time.perf_counter()
             a3 = copy.copy(args)
             a3.workload, a3.reads, a3.events, a3.threshold, a3.steps, a3.warmup = "expectations", 2000, 5000, 0.01, ks, 2
@@ -1281,7 +1294,7 @@ def main():
                 sec["expectations"] = {"failed": "%s: %s" % (type(ex).__name__, ex)}
         else:
             sec["expectations"] = {"skipped": "wall-time budget of the default run (%d s) reached" % args.secondary_budget_s}
-        leg("scaling_slice", "scaling", 12500, 10000, 0.01, 4, 2)
+        leg("scaling_slice", "scaling", 12500, 10000, 0.01, 4, 3)
         # ... and the whole configs[4] job at this N (what `--gpus N` reports as config.scaling_job): 100 000 reads in slices
         if args.no_scaling_job:
             out["config"]["scaling_job"] = {"skipped": "--no-scaling-job"}
@@ -1296,6 +1309,9 @@ def main():
                 sl_ = sec.get("scaling_slice") or {}
                 if sl_.get("value"):
                     out["config"]["scaling_job"]["over_scaling_slice_value"] = out["config"]["scaling_job"]["value"] / sl_["value"]
+                if sl_.get("value_from_median_step"):
+                    out["config"]["scaling_job"]["over_scaling_slice_value_from_median_step"] = (
+                        out["config"]["scaling_job"]["value"] / sl_["value_from_median_step"])
             except Exception as ex:
                 out["config"]["scaling_job"] = {"failed": "%s: %s" % (type(ex).__name__, ex)}
         out["config"]["wall_s_whole_run"] = time.perf_counter() - t_start
