@@ -48,6 +48,11 @@ extern "C" {
                                      complete the creation too), the working buffers may not fit and that call returns
                                      SA_ENOMEM; the batch can then only be destroyed */
 
+#define SA_FLAG_VC_ROWS 32u        /* keep only the rows the variant-caller output prints (writePosteriorProbsVC, impl/signalMachine.c:161-232:
+                                     pairs whose reference k-mer holds the ambiguity letter 'X'); every other pair is counted and
+                                     summed on the device (sa_batch_all_pairs_summary: what the run's pair count and
+                                     scoreByPosteriorProbabilityIgnoringGaps need) and never crosses PCIe.  signalMachine -s 1 sets it.
+                                     Not for a batch that feeds sa_batch_mea (the path needs every pair). */
 #define SA_FLAG_INPUTS_IN_HOST_BLOCK 16u /* every job's `events`, `anchor_x` and `anchor_y` point into ONE block from sa_host_alloc
                                      (8-byte aligned inside it).  The library then does not read them on the host at all: the
                                      part of the block that holds them crosses PCIe with one DMA and a kernel checks the
@@ -257,6 +262,10 @@ int sa_batch_start(sa_batch_t *b);
 int sa_batch_wait(sa_batch_t *b);
 int sa_batch_n_pairs(const sa_batch_t *b, int64_t job, int64_t *n);
 int sa_batch_pairs(const sa_batch_t *b, int64_t job, sa_pair_t *out, int64_t cap);
+/* A job's number of pairs and the sum of their prob_e7 over ALL pairs above the threshold -- with SA_FLAG_VC_ROWS including the rows
+ * that were dropped on the device (without the flag: of the rows the batch holds).  100 * sum / (n * 1e7) is
+ * scoreByPosteriorProbabilityIgnoringGaps (impl/pairwiseAligner.c:407-412). */
+int sa_batch_all_pairs_summary(const sa_batch_t *b, int64_t job, int64_t *n_all, int64_t *sum_prob_e7);
 /* A job's pairs as the batch holds them: *out points at *n packed records (sa_pair16_t above) inside the batch's pinned result
  * block, valid until the batch is run again or destroyed.  Nothing is copied: this is where sa_batch_run / sa_batch_wait
  * leaves the results, and the form a caller that formats or forwards them reads (signalMachine's TSV writers, sa_batch_mea). */

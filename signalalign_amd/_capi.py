@@ -13,6 +13,7 @@ FLAG_EXACT = 1
 FLAG_FORCE_GENERIC = 2
 FLAG_DEVICE_TO_ITSELF = 8
 FLAG_INPUTS_IN_HOST_BLOCK = 16
+FLAG_VC_ROWS = 32
 
 
 class SaError(RuntimeError):
@@ -81,7 +82,7 @@ PAIR_DTYPE = np.dtype([("prob_e7", "<i8"), ("x", "<i4"), ("y", "<i4"), ("path", 
 
 EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alphabet", "sa_model_table5",
            "sa_model_set_to_hdp_expected_values", "sa_model_set_emission", "sa_model_clone_with_table", "sa_kmer_id", "sa_default_ambig", "sa_load_ambig",
-           "sa_batch_create", "sa_batch_create_deferred", "sa_batch_prepare", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_pairs", "sa_batch_pairs16", "sa_batch_pairs16_all", "sa_batch_pairs_all", "sa_batch_stats",
+           "sa_batch_create", "sa_batch_create_deferred", "sa_batch_prepare", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_all_pairs_summary", "sa_batch_pairs", "sa_batch_pairs16", "sa_batch_pairs16_all", "sa_batch_pairs_all", "sa_batch_stats",
            "sa_batch_job_cells", "sa_batch_release_device", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_expect_last_stats", "sa_plan_describe", "sa_plan_digest",
            "sa_plan_check_path_records", "sa_dplan_compare",
            "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_pool_configure", "sa_host_alloc", "sa_host_free", "sa_pair_roundtrip", "sa_fasta_subsequence", "sa_format_f6", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_device_memory", "sa_strerror", "sa_hdp_state_load", "sa_hdp_state_write", "sa_hdp_state_info", "sa_hdp_state_free", "sa_hdp_state_distr_sample", "sa_hdp_state_sample_weights", "sa_hdp_finalize_distributions",
@@ -186,6 +187,7 @@ def lib():
     L.sa_host_free.argtypes = [C.c_void_p]
     L.sa_host_free.restype = None
     L.sa_batch_n_pairs.argtypes = [C.c_void_p, C.c_int64, ip]
+    L.sa_batch_all_pairs_summary.argtypes = [C.c_void_p, C.c_int64, ip, ip]
     L.sa_batch_pairs.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
     L.sa_batch_pairs16.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), ip]
     L.sa_batch_pairs_all.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, ip]
@@ -511,6 +513,13 @@ class Batch:
             out = np.empty(total, dtype=PAIR_DTYPE)
         _chk(lib().sa_batch_pairs_all(self._h, out.ctypes.data, len(out), _ip(first)), "sa_batch_pairs_all")
         return out[:total], first
+
+    def all_pairs_summary(self, job):
+        """(number of pairs, sum of their prob_e7) over every pair above the threshold -- with FLAG_VC_ROWS including the rows the
+        device dropped"""
+        n, s = C.c_int64(0), C.c_int64(0)
+        _chk(lib().sa_batch_all_pairs_summary(self._h, job, C.byref(n), C.byref(s)), "sa_batch_all_pairs_summary")
+        return int(n.value), int(s.value)
 
     def n_pairs(self, job):
         n = C.c_int64()

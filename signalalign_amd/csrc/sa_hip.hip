@@ -875,14 +875,23 @@ __global__ __launch_bounds__(256) void k_check_events(const double *__restrict__
 // spec (one-pass strip sweep, sa_strip.inc): per segment the speculative total its candidate bound was derived from, NaN for every
 // other segment.  The bound is only valid while no exact total of the segment lies below spec - slack: checked here, raised in
 // P.overflow[1] (the pass is then repeated with the two-pass sweep).
+// vc_bits (SA_FLAG_VC_ROWS): one bit per reference position of every job (job j's from bit vc_off[j] on): set where the k-mer that
+// starts there holds the ambiguity letter 'X' -- the rows writePosteriorProbsVC prints (impl/signalMachine.c:161-232).  Pairs
+// elsewhere are counted and summed into seg_all (their number and the sum of their floor(p 1e7), what
+// scoreByPosteriorProbabilityIgnoringGaps needs) and dropped here, on the device.
 __global__ __launch_bounds__(64) void k_finalize(DevPlan P, int seg0, int n_segs, long long *prob_e7, int *seg_pass,
-                                                 const double *__restrict__ spec, double spec_slack) {
+                                                 const double *__restrict__ spec, double spec_slack,
+                                                 const unsigned long long *__restrict__ vc_bits, const long long *__restrict__ vc_off,
+                                                 long long *__restrict__ seg_all) {
     if ((int) blockIdx.x >= n_segs) return;
     int seg = seg0 + blockIdx.x;
     const sa_seg_t *S = &P.segs[seg];
     int n = P.cand_count[seg];
     int lane = threadIdx.x;
     int cnt = 0;
+    long long all_n = 0, all_sum = 0;
+    const sa_region_t *Rv = &P.regions[S->region];
+    const long long vc_base = vc_bits ? vc_off[Rv->job] : 0;
     if (spec) {
         const double sp = spec[seg];
         if (sp == sp && sp > NEG_INF) {
@@ -904,11 +913,20 @@ __global__ __launch_bounds__(64) void k_finalize(DevPlan P, int seg0, int n_segs
                 v = (long long) floor(p * SA_PROB_1);
                 pass = true;
             }
+            if (vc_bits && pass) {
+                all_n++; all_sum += v;
+                const long long bit = vc_base + (long long) c.x + Rv->x1;
+                if (!((vc_bits[bit >> 6] >> (bit & 63)) & 1ull)) { pass = false; v = -1; }
+            }
             prob_e7[S->cand_off + i] = v;
         }
         cnt += __popcll(__ballot(pass));
     }
     if (lane == 0) seg_pass[seg] = cnt;
+    if (vc_bits) {
+        for (int off = 32; off > 0; off >>= 1) { all_n += __shfl_xor(all_n, off, 64); all_sum += __shfl_xor(all_sum, off, 64); }
+        if (lane == 0) { seg_all[2ll * seg] = all_n; seg_all[2ll * seg + 1] = all_sum; }
+    }
 }
 
 // Expectation pass: the per-read sums on the device.  Every checkpoint group holds its seven transition sums scaled by its
@@ -1243,6 +1261,11 @@ struct sa_batch {
     bool released;           // sa_batch_release_device: the working storage went back to the pool, the results stay
     unsigned long long *d_sortkey;   // k_gather_sorted's scratch: 8 + 4 bytes per candidate slot
     unsigned *d_sortidx;
+    unsigned long long *d_vc_bits = nullptr;   // SA_FLAG_VC_ROWS: see k_finalize
+    long long *d_vc_off = nullptr, *d_seg_all = nullptr;
+    std::vector<unsigned long long> h_vc_bits;  // (the same on the host, for SA_FLAG_EXACT's host finalisation)
+    std::vector<long long> h_vc_off, job_all_n, job_all_sum;
+    bool plan_hdp = false;                      // the batch's model holds an HDP (g_pairs_memo's key)
     char *d_seam;            // their seam storage: per wave two arrays of seam_cap records of 16 bytes
     unsigned seam_cap;
     unsigned seam_cap_bwd;   // records per seam array of the backward launches (a traceback segment is shorter than a region)
@@ -1672,7 +1695,8 @@ void sa_batch_destroy(sa_batch_t *b) {
     void *ptrs[] = {b->d_regions, b->d_rows, b->d_pk, b->d_poff, b->d_pid, b->d_px, b->d_xc, b->d_prec, b->d_ev, b->d_segs, b->d_cks, b->d_F, b->d_E,
                     b->d_vbuf, b->d_cands, b->d_cand_count, b->d_overflow, b->d_totals, b->d_bscratch, b->d_tab6, b->d_noise3, b->d_evn,
                     b->d_hdp_slot, b->d_hdp_y, b->d_hdp_slope, b->d_hdp_grid, b->d_hdp_tab, b->d_hdp_coef, b->d_prob, b->d_seg_pass, b->d_seg_off,
-                    b->d_out, b->d_ids, b->d_gsum, b->d_gmc, b->d_seam, b->d_ckxy, b->d_blk, b->d_spec, b->d_sortkey, b->d_sortidx};
+                    b->d_out, b->d_ids, b->d_gsum, b->d_gmc, b->d_seam, b->d_ckxy, b->d_blk, b->d_spec, b->d_sortkey, b->d_sortidx,
+                    b->d_vc_bits, b->d_vc_off, b->d_seg_all};
     for (void *p : ptrs)
         if (p) g_sa_pool.put(SaPool::DEVICE, p);
     for (int i = 0; i < 8; i++)
@@ -1697,6 +1721,30 @@ void sa_batch_destroy(sa_batch_t *b) {
 
 #include "sa_dplan.inc"
 static void dplan_release_fwd(sa_batch *b, DPlanPending *P) { dplan_release(b, P, true); }
+
+// Pairs per event of the last finished batch with the same threshold and kind of model, process-wide: the estimate the NEXT batch's
+// pinned result block is sized from (a batch whose estimate is short copies its pairs after its kernels instead of beside them:
+// the bundled HDP at threshold 0.01 returns 17.8 pairs per event where the default estimate allows 1.5).
+struct SaPairsMemo {
+    std::mutex mu;
+    double thr[4] = {0, 0, 0, 0}, ratio[4] = {0, 0, 0, 0};
+    int hdp[4] = {0, 0, 0, 0}, next = 0;
+    void note(double threshold, bool is_hdp, double pairs, double events) {
+        if (!(events > 0)) return;
+        std::lock_guard<std::mutex> g(mu);
+        for (int i = 0; i < 4; i++)
+            if (thr[i] == threshold && hdp[i] == (int) is_hdp) { ratio[i] = pairs / events; return; }
+        thr[next] = threshold; hdp[next] = (int) is_hdp; ratio[next] = pairs / events;
+        next = (next + 1) & 3;
+    }
+    double estimate(double threshold, bool is_hdp) {
+        std::lock_guard<std::mutex> g(mu);
+        for (int i = 0; i < 4; i++)
+            if (thr[i] == threshold && hdp[i] == (int) is_hdp && ratio[i] > 0) return ratio[i] * 1.1 > 1.5 ? ratio[i] * 1.1 : 1.5;
+        return 1.5;
+    }
+};
+static SaPairsMemo g_pairs_memo;
 
 static int batch_create_impl(sa_batch_t **out, const sa_model_t *m, const sa_params_t *p, const sa_job_t *jobs, int64_t n_jobs,
                              const char *const *ambig, int device, unsigned flags, bool deferred) {
@@ -2008,6 +2056,7 @@ static int batch_prepare_body(sa_batch *b) {
     if (trace_c) fprintf(stderr, "[trace] create: planned (%s) at %.1f ms\n", b->dev_planned ? "device" : "host", now_ms_c() - tc0);
 
     b->expect = (flags & SA_FLAG_EXPECT_INTERNAL) != 0;
+    b->plan_hdp = m->hdp != nullptr;
     b->relax = !(flags & SA_FLAG_EXACT) && !b->expect && m->hdp == nullptr;
     b->ring_cap = 0;
     b->gen_threads = 64;
@@ -2155,6 +2204,28 @@ static int batch_prepare_body(sa_batch *b) {
                 }
             TRY(upload(&b->d_hdp_coef, coef.data(), (long long) coef.size()));
         }
+    }
+    if ((flags & SA_FLAG_VC_ROWS) && !b->expect) {   // which reference positions the variant-caller output reports on (k_finalize)
+        const int kk = m->k;
+        b->h_vc_off.assign((size_t) n_jobs + 1, 0);
+        for (int64_t j = 0; j < n_jobs; j++) b->h_vc_off[(size_t) j + 1] = b->h_vc_off[(size_t) j] + ((jobs[j].ref_len + 63) / 64 + 1) * 64;
+        b->h_vc_bits.assign((size_t) (b->h_vc_off[(size_t) n_jobs] / 64 + 1), 0ull);
+        for (int64_t j = 0; j < n_jobs; j++) {
+            const char *ref = jobs[j].ref;
+            const long long base = b->h_vc_off[(size_t) j];
+            long long last_x = -1;   // the last 'X' at or in front of position i + k - 1
+            for (long long i = 0; i < kk - 1 && i < jobs[j].ref_len; i++)
+                if (ref[i] == 'X') last_x = i;
+            for (long long i = 0; i + kk <= jobs[j].ref_len; i++) {
+                if (ref[i + kk - 1] == 'X') last_x = i + kk - 1;
+                if (last_x >= i) b->h_vc_bits[(size_t) ((base + i) >> 6)] |= 1ull << ((base + i) & 63);
+            }
+        }
+        TRY(upload(&b->d_vc_bits, b->h_vc_bits.data(), (long long) b->h_vc_bits.size()));
+        TRY(upload(&b->d_vc_off, b->h_vc_off.data(), (long long) b->h_vc_off.size()));
+        if (g_sa_pool.get(SaPool::DEVICE, (void **) &b->d_seg_all, sizeof(long long) * 2 * (size_t) (pl->n_segs > 0 ? pl->n_segs : 1), device) !=
+            hipSuccess)
+            return SA_ENOMEM;
     }
     {   // emission constants, on the device (same stream as the uploads they read)
         if (g_sa_pool.get(SaPool::DEVICE, (void **) &b->d_xc, sizeof(double) * 4 * (size_t) (pl->n_pid > 0 ? pl->n_pid : 1), device) !=
@@ -2351,7 +2422,7 @@ static int batch_finish_body(sa_batch *b) {
     // happened to overlap -- sometimes during the caller's warm-up, sometimes in the middle of its timed loop: a 100 ms
     // hipHostMalloc that also held up every other thread's HIP calls (12.5 against 16-19 ms per step, run to run).
     if (!(flags & SA_FLAG_EXACT) && !b->expect && b->h_pairs_cap == 0 && pl->params.threshold >= 0.005) {
-        const long long total = (long long) (1.5 * (double) pl->n_ev) + 4096;
+        const long long total = (long long) (g_pairs_memo.estimate(pl->params.threshold, m->hdp != nullptr) * (double) pl->n_ev) + 4096;
         const long long cap = total + total / 8 + 1024;
         if (g_sa_pool.get(SaPool::PINNED, (void **) &b->h_pairs, sizeof(sa_pair16_t) * (size_t) cap, device) == hipSuccess) b->h_pairs_cap = cap;
         else { (void) hipGetLastError(); b->h_pairs = nullptr; }   // (the run asks again)
@@ -2488,7 +2559,7 @@ static int submit_group(sa_batch *b, const DevPlan &P, int g, int which_stream, 
         // (groups without register / ring / one-pass strip segments: no look at the speculative totals)
         const double *spec = (b->d_spec && (any_ring || (b->strip_one_pass && G.nss > 0))) ? b->d_spec : nullptr;
         hipLaunchKernelGGL(k_finalize, dim3((unsigned) n), dim3(64), 0, st, P, (int) G.seg0, n, b->d_prob, b->d_seg_pass, spec,
-                           b->spec_slack);
+                           b->spec_slack, (const unsigned long long *) b->d_vc_bits, (const long long *) b->d_vc_off, b->d_seg_all);
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, b->d_seg_pass + G.seg0, soff, b->h_seg_off + G.seg0 + g, n);
         hipLaunchKernelGGL(k_gather, dim3((unsigned) n), dim3(64), 0, st, P, (int) G.seg0, n, b->d_prob, soff,
                            b->d_out + pl->segs[G.seg0].cand_off, spec, (b->strip_on && b->strip_one_pass && b->d_sortkey) ? 1 : 0);
@@ -2700,7 +2771,7 @@ static int batch_run_body(sa_batch_t *b) {
     // of a batch overlap its copies with the kernels; with the caching allocator the buffer is a reused block.  If the
     // estimate is short the run falls back to copying afterwards, as before.
     if (!(b->flags & SA_FLAG_EXACT) && b->h_pairs_cap == 0 && pl->params.threshold >= 0.005) {
-        int rce = reserve_pairs((long long) (1.5 * (double) pl->n_ev) + 4096);
+        int rce = reserve_pairs((long long) (g_pairs_memo.estimate(pl->params.threshold, b->plan_hdp) * (double) pl->n_ev) + 4096);
         if (rce) return rce;
     }
     if (b->flags & SA_FLAG_EXACT) {
@@ -2717,6 +2788,21 @@ static int batch_run_body(sa_batch_t *b) {
         std::vector<int64_t> np((size_t) (pl->n_jobs > 0 ? pl->n_jobs : 1), 0);
         int rc = sa_plan_finalize(pl, cands.data(), counts.data(), totals.data(), pp.data(), np.data());
         if (rc) return rc;
+        if (!b->h_vc_bits.empty()) {   // SA_FLAG_VC_ROWS on host-finalised pairs: the same test as k_finalize's
+            b->job_all_n.assign((size_t) pl->n_jobs, 0);
+            b->job_all_sum.assign((size_t) pl->n_jobs, 0);
+            for (long long j = 0; j < pl->n_jobs; j++) {
+                const long long base = b->h_vc_off[(size_t) j];
+                int64_t kept = 0;
+                for (int64_t q = 0; q < np[j]; q++) {
+                    b->job_all_n[(size_t) j]++;
+                    b->job_all_sum[(size_t) j] += pp[j][q].prob_e7;
+                    const long long bit = base + pp[j][q].x;
+                    if ((b->h_vc_bits[(size_t) (bit >> 6)] >> (bit & 63)) & 1ull) pp[j][kept++] = pp[j][q];
+                }
+                np[j] = kept;
+            }
+        }
         long long total = 0;
         for (long long j = 0; j < pl->n_jobs; j++) total += np[j];
         rc = reserve_pairs(total);
@@ -2858,6 +2944,18 @@ static int batch_run_body(sa_batch_t *b) {
         b->job_off[pl->n_jobs] = gbase[ng];
         b->n_pairs_total = gbase[ng];
     }
+    if (b->d_seg_all) {   // SA_FLAG_VC_ROWS: what the dropped rows would have added to a job's count and score
+        std::vector<long long> sa_((size_t) (2 * (n_segs > 0 ? n_segs : 1)), 0);
+        if (n_segs) HIPCHK(hipMemcpy(sa_.data(), b->d_seg_all, sizeof(long long) * 2 * (size_t) n_segs, hipMemcpyDeviceToHost));
+        b->job_all_n.assign((size_t) pl->n_jobs, 0);
+        b->job_all_sum.assign((size_t) pl->n_jobs, 0);
+        for (long long sg = 0; sg < n_segs; sg++) {
+            const long long j = pl->regions[pl->segs[sg].region].job;
+            b->job_all_n[(size_t) j] += sa_[(size_t) (2 * sg)];
+            b->job_all_sum[(size_t) j] += sa_[(size_t) (2 * sg + 1)];
+        }
+    }
+    g_pairs_memo.note(pl->params.threshold, b->plan_hdp, (double) b->n_pairs_total, (double) pl->n_ev);
     b->ran = true;
     return SA_OK;
 }
@@ -2929,7 +3027,8 @@ int sa_batch_release_device(sa_batch_t *b) {
                      (void **) &b->d_hdp_slot, (void **) &b->d_hdp_y, (void **) &b->d_hdp_slope, (void **) &b->d_hdp_grid, (void **) &b->d_hdp_tab, (void **) &b->d_hdp_coef,
                      (void **) &b->d_prob, (void **) &b->d_seg_pass, (void **) &b->d_seg_off, (void **) &b->d_out, (void **) &b->d_ids,
                      (void **) &b->d_gsum, (void **) &b->d_gmc, (void **) &b->d_seam, (void **) &b->d_ckxy, (void **) &b->d_blk, (void **) &b->d_spec,
-                     (void **) &b->d_sortkey, (void **) &b->d_sortidx};
+                     (void **) &b->d_sortkey, (void **) &b->d_sortidx, (void **) &b->d_vc_bits, (void **) &b->d_vc_off,
+                     (void **) &b->d_seg_all};
     for (void **pp : ptrs)
         if (*pp) { g_sa_pool.put(SaPool::DEVICE, *pp); *pp = nullptr; }
     if (b->held_stage) { g_sa_pool.put(SaPool::PINNED, b->held_stage); b->held_stage = nullptr; }
@@ -2960,6 +3059,20 @@ int sa_batch_n_pairs(const sa_batch_t *b, int64_t job, int64_t *n) {
     if (!b || !n || job < 0 || job >= b->c_n) return SA_EINVAL;
     if (!b->ran) return SA_ESTATE;
     *n = b->job_off[job + 1] - b->job_off[job];
+    return SA_OK;
+}
+int sa_batch_all_pairs_summary(const sa_batch_t *b, int64_t job, int64_t *n_all, int64_t *sum_prob_e7) {
+    if (!b || job < 0 || job >= b->c_n) return SA_EINVAL;
+    if (!b->ran) return SA_ESTATE;
+    if (b->job_all_n.size() == (size_t) b->c_n) {   // SA_FLAG_VC_ROWS: counted before the rows were dropped
+        if (n_all) *n_all = b->job_all_n[(size_t) job];
+        if (sum_prob_e7) *sum_prob_e7 = b->job_all_sum[(size_t) job];
+        return SA_OK;
+    }
+    long long s = 0;
+    for (long long i = b->job_off[job]; i < b->job_off[job + 1]; i++) s += (long long) ((b->h_pairs[i].b >> 32) & 0xffffffull);
+    if (n_all) *n_all = b->job_off[job + 1] - b->job_off[job];
+    if (sum_prob_e7) *sum_prob_e7 = s;
     return SA_OK;
 }
 int sa_batch_pairs(const sa_batch_t *b, int64_t job, sa_pair_t *out, int64_t cap) {

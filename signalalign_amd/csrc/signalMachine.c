@@ -672,6 +672,8 @@ typedef struct {
     int64_t **n_mea;
     sa_batch_t *const *batch;   /* [strand]: the batch is still alive and pairs[strand][job] is NULL -- a job's rows are expanded
                                  * from the batch's packed records (sa_batch_pairs16) by the thread that renders the job */
+    int64_t *const *all_n;      /* [strand][job], -s 1 only (SA_FLAG_VC_ROWS): number and prob_e7 sum of ALL pairs of the job -- the */
+    int64_t *const *all_sum;    /* rows the variant-caller output does not print were dropped on the device                        */
 } out_job_t;
 
 /* The rows of the full output that lie on the maximum-expected-accuracy path -- what mea_alignment_from_signal_align
@@ -738,8 +740,14 @@ static void output_one(int64_t j, void *ctx) {
     }
     for (int s = 0; s < n_strands; s++) {
         double tot = 0.0;
-        for (int64_t i = 0; i < c->n_pairs[s][j]; i++) tot += (double) pp[s][i].prob_e7;
-        c->score[j][s] = 100.0 * tot / ((double) c->n_pairs[s][j] * PROB_1); /* scoreByPosteriorProbabilityIgnoringGaps :407-412 */
+        int64_t n_all = c->n_pairs[s][j];
+        if (c->all_n && c->all_n[s]) {   /* (prob_e7 sums are integers below 2^53: the same double as the loop below gives) */
+            n_all = c->all_n[s][j];
+            tot = (double) c->all_sum[s][j];
+        } else {
+            for (int64_t i = 0; i < c->n_pairs[s][j]; i++) tot += (double) pp[s][i].prob_e7;
+        }
+        c->score[j][s] = 100.0 * tot / ((double) n_all * PROB_1); /* scoreByPosteriorProbabilityIgnoringGaps :407-412 */
     }
     if (rd->post_path != NULL) {
         out_ctx_t o;
@@ -804,6 +812,7 @@ typedef struct {
     sa_mea_pair_t **mea_s[2];
     int64_t *n_mea_s[2];
     sa_batch_t *batch[2];  /* alive until the slice is rendered (their packed records are what the rendering reads) */
+    int64_t *all_n_s[2], *all_sum_s[2];   /* -s 1: see out_job_t */
     int64_t n_failed;     /* out */
 } render_job_t;
 static void *render_slice(void *arg);
@@ -874,6 +883,10 @@ static render_job_t *run_slice(run_t *Rp, read_t *reads, int64_t n_reads, int ba
     int64_t **n_mea = n_mea_s;
     int validated = !batch_mode;   /* a single-read run has nobody to isolate a bad job from */
     sa_batch_t *batches[2] = {NULL, NULL};
+    int64_t *all_n[2] = {NULL, NULL}, *all_sum[2] = {NULL, NULL};
+    /* -s 1 prints only the rows whose reference k-mer holds an X: the others stay on the device (SA_FLAG_VC_ROWS), the run's pair
+     * count and score come from the totals the device kept */
+    const unsigned vc_flag = (R.out_fmt == 1 && !R.mea && !getenv("SA_CLI_EXPAND_EARLY") && !getenv("SA_CLI_VC_ON_HOST")) ? SA_FLAG_VC_ROWS : 0u;
     for (int s = 0; s < n_strands; s++) {
         pairs[s] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(sa_pair_t *));
         n_pairs[s] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(int64_t));
@@ -886,9 +899,15 @@ static render_job_t *run_slice(run_t *Rp, read_t *reads, int64_t n_reads, int ba
                                 n_pairs[s]);
         } else if (!R.mea) {   /* the batch stays alive for the rendering, which expands its packed records job by job */
             sa_batch_t *b = NULL;
-            rc = sa_batch_create(&b, R.two_dist ? reads[who[0]].model[s] : sms[s]->model, &R.p, bj, n_ok, R.ambig, device, 0);
+            rc = sa_batch_create(&b, R.two_dist ? reads[who[0]].model[s] : sms[s]->model, &R.p, bj, n_ok, R.ambig, device, vc_flag);
             if (rc == SA_OK) rc = sa_batch_run(b);
             for (int64_t j = 0; j < n_ok && rc == SA_OK; j++) rc = sa_batch_n_pairs(b, j, &n_pairs[s][j]);
+            if (vc_flag && rc == SA_OK) {
+                free(all_n[s]); free(all_sum[s]);
+                all_n[s] = calloc((size_t) n_ok, sizeof(int64_t));
+                all_sum[s] = calloc((size_t) n_ok, sizeof(int64_t));
+                for (int64_t j = 0; j < n_ok && rc == SA_OK; j++) rc = sa_batch_all_pairs_summary(b, j, &all_n[s][j], &all_sum[s][j]);
+            }
             /* only the packed pairs (pinned host memory) are read from here on: the batch's HBM goes back now, so that the
              * complement strand's batch -- and, with a render thread, the next slice's -- plans into the whole card */
             if (rc == SA_OK) rc = sa_batch_release_device(b);
@@ -943,7 +962,7 @@ static render_job_t *run_slice(run_t *Rp, read_t *reads, int64_t n_reads, int ba
     g_t_gpu += now_s() - ts1;
     render_job_t *job = calloc(1, sizeof(*job));
     job->Rp = Rp; job->reads = reads; job->n_reads = n_reads; job->n_ok = n_ok; job->who = who; job->bj = bj;
-    for (int s = 0; s < 2; s++) { job->pairs_s[s] = pairs[s]; job->n_pairs_s[s] = n_pairs[s]; job->mea_s[s] = mea[s]; job->n_mea_s[s] = n_mea[s]; job->batch[s] = batches[s]; }
+    for (int s = 0; s < 2; s++) { job->pairs_s[s] = pairs[s]; job->n_pairs_s[s] = n_pairs[s]; job->mea_s[s] = mea[s]; job->n_mea_s[s] = n_mea[s]; job->batch[s] = batches[s]; job->all_n_s[s] = all_n[s]; job->all_sum_s[s] = all_sum[s]; }
     return job;
 #undef R
 }
@@ -965,7 +984,7 @@ static void *render_slice(void *arg) {
     const double ts2 = now_s();
     double (*score)[2] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(*score));
     {
-        out_job_t oc = {&R, reads, who, pairs, n_pairs, score, mea, n_mea, job->batch};
+        out_job_t oc = {&R, reads, who, pairs, n_pairs, score, mea, n_mea, job->batch, job->all_n_s, job->all_sum_s};
         if (outputs_distinct(reads, who, n_ok)) parallel_for(n_ok, output_one, &oc);
         else for (int64_t j = 0; j < n_ok; j++) output_one(j, &oc);
     }
@@ -973,8 +992,8 @@ static void *render_slice(void *arg) {
     for (int64_t j = 0; j < n_ok; j++) {
         read_t *rd = &reads[who[j]];
         if (rd->failed) continue;
-        fprintf(stdout, "%s %" PRId64 "\t%" PRId64 "(%f)\t", rd->label, rd->n_guide, n_pairs[0][j], score[j][0]);
-        if (R.two_d) fprintf(stdout, "%" PRId64 "(%f)\n", n_pairs[1][j], score[j][1]);
+        fprintf(stdout, "%s %" PRId64 "\t%" PRId64 "(%f)\t", rd->label, rd->n_guide, job->all_n_s[0] ? job->all_n_s[0][j] : n_pairs[0][j], score[j][0]);
+        if (R.two_d) fprintf(stdout, "%" PRId64 "(%f)\n", job->all_n_s[1] ? job->all_n_s[1][j] : n_pairs[1][j], score[j][1]);
         else fprintf(stdout, "\n");
         fprintf(stderr, "signalAlign - SUCCESS: finished alignment of query %s, exiting\n", rd->label);
         for (int s = 0; s < n_strands; s++) {
@@ -985,7 +1004,7 @@ static void *render_slice(void *arg) {
     t_add(&g_t_render, now_s() - ts2);
     int64_t n_failed = 0;
     for (int64_t i = 0; i < n_reads; i++) n_failed += reads[i].failed ? 1 : 0;
-    for (int s = 0; s < n_strands; s++) { free(pairs[s]); free(n_pairs[s]); if (R.mea) { free(mea[s]); free(n_mea[s]); } }
+    for (int s = 0; s < n_strands; s++) { free(pairs[s]); free(n_pairs[s]); free(job->all_n_s[s]); free(job->all_sum_s[s]); if (R.mea) { free(mea[s]); free(n_mea[s]); } }
     free(score); free(bj); free(who);
     for (int64_t i = 0; i < n_reads; i++) release_read(&reads[i]);
     job->n_failed = n_failed;

@@ -149,6 +149,69 @@ def test_signalmachine_variant_caller_output(oracle, tmp_path):
         assert 0.01 <= float(r[3]) <= 1.0
 
 
+def test_variant_caller_rows_are_filtered_on_the_device(oracle, tmp_path):
+    """-s 1 keeps only the rows whose reference k-mer holds an X (writePosteriorProbsVC, impl/signalMachine.c:161-232).  The library
+    drops the others on the device (SA_FLAG_VC_ROWS) and keeps their count and probability sum for the summary line: the file and
+    the summary line are byte-identical to the run that fetches every pair and filters while it writes (SA_CLI_VC_ON_HOST=1), both
+    strands of a 2-D read, and the library call returns exactly the filtered subset of the unfiltered call -- device finalisation
+    and SA_FLAG_EXACT's host finalisation alike."""
+    npread_path = os.path.join(cases.GOLDEN, "npReads", "r9p4_oneD.npRead")
+    r = oracle.parse_npread(npread_path)
+    read = r["template_read"]
+    L = 1500
+    ref = list(read[:L])
+    cpg = [i for i in range(100, L - 100) if read[i:i + 2] == "CG"][:20]
+    for pos in cpg:
+        ref[pos] = "X"
+    ref = "".join(ref)
+    fasta = str(tmp_path / "ref.fa")
+    _write_fasta(fasta, "chrA", ref + "ACGTACGTAC")
+    cigar = str(tmp_path / "guide.cigar")
+    with open(cigar, "w") as f:
+        f.write("cigar: r 0 %d + chrA 0 %d + 1 M %d\n" % (L, L, L))
+    amb = str(tmp_path / "ce.positions")
+    with open(amb, "w") as f:
+        f.write("X\tCE\n")
+    base = [BIN, "-T", cases.MODEL_CPG, "-q", npread_path, "-f", fasta, "-n", "chrA", "-p", cigar, "-L", "r", "-s", "1", "-g", "100", "-a", amb]
+    outs = {}
+    for name, env in (("device", {}), ("host", {"SA_CLI_VC_ON_HOST": "1"})):
+        out = str(tmp_path / (name + ".tsv"))
+        pr = subprocess.run(base + ["-u", out], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        assert pr.returncode == 0, pr.stderr
+        outs[name] = (open(out).read(), pr.stdout)
+    assert outs["device"][0] and outs["device"] == outs["host"]
+    n_all = int(outs["device"][1].split("\t")[1].split("(")[0])
+    assert n_all > 10 * len(outs["device"][0].splitlines()) // 6        # the summary line still counts every pair
+    # the library call
+    import signalalign_amd as sa
+    from signalalign_amd import synth
+    pm = sa.Model.load(cases.MODEL_CPG)
+    kk = synth.parse_model_table(cases.MODEL_CPG)[1]
+    jobs = cases.synthetic_jobs(cases.MODEL_CPG, 6, 900, 4242)
+    rng = np.random.default_rng(3)
+    for j in jobs:                                    # X at a few cytosines of every read but the last (no X: every row goes)
+        s = list(j["ref"])
+        cs = [i for i in range(len(s) - 1) if s[i] == "C"]
+        if j is not jobs[-1]:
+            for i in rng.choice(cs, size=min(12, len(cs)), replace=False):
+                s[int(i)] = "X"
+        j["ref"] = "".join(s)
+    ambig = sa.default_ambig({"X": "CE"})
+    p = sa.default_params(threshold=0.01)
+    for flags in (0, sa.FLAG_EXACT):
+        full = sa.Batch(pm, p, jobs, ambig=ambig, flags=flags)
+        full.run()
+        vc = sa.Batch(pm, p, jobs, ambig=ambig, flags=flags | sa.FLAG_VC_ROWS)
+        vc.run()
+        for j, job in enumerate(jobs):
+            a, b = full.pairs(j), vc.pairs(j)
+            has_x = np.array([("X" in job["ref"][x:x + kk]) for x in a["x"]], dtype=bool)
+            assert np.array_equal(a[has_x], b), (flags, j)
+            assert vc.all_pairs_summary(j) == (len(a), int(a["prob_e7"].sum())) == full.all_pairs_summary(j)
+        assert len(vc.pairs(len(jobs) - 1)) == 0 and vc.n_pairs(0) > 0
+        full.close(); vc.close()
+
+
 def test_signalmachine_ambig_model_file(oracle, tmp_path):
     """-a <file> (create_ambig_bases2, impl/pairwiseAligner.c:68-92; impl/signalMachine.c:649-655): the file REPLACES the
     built-in ambiguity table.  With `X<TAB>AT` only A or T can be called at the X positions (which really hold a C: the
