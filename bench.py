@@ -492,6 +492,8 @@ def measure(args, ctx, compact=False):
         in_block = False
         arrays = [sa.JobArray(js) for js in sets]
     xflags = sa.FLAG_INPUTS_IN_HOST_BLOCK if in_block else 0
+    if getattr(args, "pairs8", False):   # 8-byte result records (x, y, probability): one path per cell only
+        xflags |= sa.FLAG_PAIRS8
     inputs_used = "host-block" if in_block else "pageable"
     n_events_total = sum(len(j["events"]) for j in jobs)
 
@@ -834,7 +836,8 @@ def measure(args, ctx, compact=False):
                         "results on the host + sa_batch_destroy; %s" % ("%d batches in flight (sa_batch_start / sa_batch_wait)" % depth
                                                                         if depth > 1 else "one batch on the device at a time, the next one checked, "
                                                                         "packed, uploaded and planned meanwhile (sa_batch_create_deferred)"),
-                "results": {"step_ends_at": "every job's pairs as packed 16-byte records (sa_pair16_t, include/signalalign_hip.h) in "
+                "result_record_bytes": 8 if getattr(args, "pairs8", False) else 16,
+                "results": {"step_ends_at": "every job's pairs as packed 16-byte records (sa_pair16_t, include/signalalign_hip.h; 8-byte sa_pair8_t with --pairs8) in "
                                             "the batch's pinned host block, read in place through sa_batch_pairs16_all",
                             "pairs_seen_in_timed_steps": pairs_timed,
                             "expand_to_sa_pair_t_ms": unpack_ms,
@@ -1132,6 +1135,8 @@ def main():
     ap.add_argument("--job-slice", type=int, default=2000, help="reads per batch of the scaling job")
     ap.add_argument("--job-sets", type=int, default=2, help="distinct slice-sized read sets a rank generates and cycles")
     ap.add_argument("--no-scaling-job", action="store_true", help="skip config.scaling_job")
+    ap.add_argument("--pairs8", action="store_true", help="SA_FLAG_PAIRS8: the batches hold 8-byte result records (x, y, probability) "
+                                                          "instead of 16-byte ones -- workloads with one path per cell")
     ap.add_argument("--legs", default=None, help="comma-separated names of the config.secondary legs to run (default: all) -- for "
                                                  "looking at one leg in the context of the default run")
     ap.add_argument("--secondary-budget-s", type=float, default=330.0,
@@ -1269,6 +1274,13 @@ def main():
         leg("cpg", "cpg", 10000, 5000, 0.01, 5, 2)
         if leg("hdp", "hdp", 5000, 5000, 0.1, ks, max(5, args.in_flight + 3)) is not None or (only and "hdp_threshold_0.01" in only):
             r3 = leg("hdp_threshold_0.01", "hdp", 5000, 5000, 0.01, 3, 1, cpu=False)
+            args_p8 = args.pairs8
+            args.pairs8 = True
+            r3b = leg("hdp_threshold_0.01_pairs8", "hdp", 5000, 5000, 0.01, 3, 1, cpu=False)
+            args.pairs8 = args_p8
+            if r3b is not None:
+                sec["hdp_threshold_0.01_pairs8"]["note"] = ("the same step with SA_FLAG_PAIRS8: 8-byte records (x, y, probability; the "
+                                                            "k-mer of a pair is the reference's at x), half the bytes over PCIe")
             if r3 is not None:
                 sec["hdp_threshold_0.01"]["note"] = ("the bundled .nhdp is flat (every process: mean 59.8, sd 15.5 pA): 17.8 pairs "
                                                      "per event at 0.01, the step is their PCIe transfer")

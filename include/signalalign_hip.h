@@ -53,6 +53,13 @@ extern "C" {
                                      summed on the device (sa_batch_all_pairs_summary: what the run's pair count and
                                      scoreByPosteriorProbabilityIgnoringGaps need) and never crosses PCIe.  signalMachine -s 1 sets it.
                                      Not for a batch that feeds sa_batch_mea (the path needs every pair). */
+#define SA_FLAG_PAIRS8 64u         /* the batch holds its pairs as 8-byte records (sa_pair8_t below) instead of 16-byte ones: half the
+                                     bytes over PCIe for results of hundreds of millions of pairs (broad HDP densities at a low
+                                     threshold).  Only for batches with ONE path per cell (no ambiguity letters: the pair's k-mer is
+                                     the reference's at x, the path index 0 -- neither is stored) and fewer than 2^20 reference
+                                     positions and events per job: SA_EUNSUPPORTED otherwise.  Read with sa_batch_pairs8 /
+                                     sa_batch_pairs8_all; the 16-byte accessors, sa_batch_pairs(_all) and sa_batch_mea return
+                                     SA_ESTATE on such a batch. */
 #define SA_FLAG_INPUTS_IN_HOST_BLOCK 16u /* every job's `events`, `anchor_x` and `anchor_y` point into ONE block from sa_host_alloc
                                      (8-byte aligned inside it).  The library then does not read them on the host at all: the
                                      part of the block that holds them crosses PCIe with one DMA and a kernel checks the
@@ -164,6 +171,18 @@ SA_PAIR16_ATTR SA_PAIR16_FN sa_pair_t sa_pair16_unpack(sa_pair16_t r) {
     return o;
 }
 
+/* SA_FLAG_PAIRS8: prob_e7 (24 bits: <= 1e7) << 40 | y (20 bits) << 20 | x (20 bits) */
+typedef uint64_t sa_pair8_t;
+#define SA_PAIR8_MAX_COORD (1ll << 20)
+SA_PAIR16_ATTR SA_PAIR16_FN sa_pair8_t sa_pair8_pack(int64_t prob_e7, int32_t x, int32_t y) {
+    return ((uint64_t) prob_e7 << 40) | (((uint64_t) (uint32_t) y & 0xfffffull) << 20) | ((uint64_t) (uint32_t) x & 0xfffffull);
+}
+SA_PAIR16_ATTR SA_PAIR16_FN void sa_pair8_unpack(sa_pair8_t r, int64_t *prob_e7, int32_t *x, int32_t *y) {
+    *x = (int32_t) (r & 0xfffffull);
+    *y = (int32_t) ((r >> 20) & 0xfffffull);
+    *prob_e7 = (int64_t) (r >> 40);
+}
+
 /* Test hook (host only): `in` through the packed 16-byte record and back into `out`. */
 int sa_pair_roundtrip(const sa_pair_t *in, sa_pair_t *out, int64_t n);
 
@@ -273,6 +292,9 @@ int sa_batch_pairs16(const sa_batch_t *b, int64_t job, const sa_pair16_t **out, 
 /* The whole batch at once: the records of all jobs are contiguous in job order; *out is the first record of job 0 and job j's
  * are (*out)[first[j] .. first[j + 1]) (`first`: n_jobs + 1 entries, may be NULL). */
 int sa_batch_pairs16_all(const sa_batch_t *b, const sa_pair16_t **out, int64_t *first);
+/* the same two for a batch created with SA_FLAG_PAIRS8 (8-byte records, in place, job after job) */
+int sa_batch_pairs8(const sa_batch_t *b, int64_t job, const sa_pair8_t **out, int64_t *n);
+int sa_batch_pairs8_all(const sa_batch_t *b, const sa_pair8_t **out, int64_t *first);
 /* Every job's pairs expanded into sa_pair_t, job after job, on the library's host threads: out[first[j] .. first[j + 1]) are
  * job j's rows (`first` has n_jobs + 1 entries; may be NULL).  cap < total number of pairs: SA_EINVAL and *first is still
  * filled, so first[n_jobs] says how much room is needed. */

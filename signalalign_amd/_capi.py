@@ -14,6 +14,7 @@ FLAG_FORCE_GENERIC = 2
 FLAG_DEVICE_TO_ITSELF = 8
 FLAG_INPUTS_IN_HOST_BLOCK = 16
 FLAG_VC_ROWS = 32
+FLAG_PAIRS8 = 64
 
 
 class SaError(RuntimeError):
@@ -82,7 +83,7 @@ PAIR_DTYPE = np.dtype([("prob_e7", "<i8"), ("x", "<i4"), ("y", "<i4"), ("path", 
 
 EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alphabet", "sa_model_table5",
            "sa_model_set_to_hdp_expected_values", "sa_model_set_emission", "sa_model_clone_with_table", "sa_kmer_id", "sa_default_ambig", "sa_load_ambig",
-           "sa_batch_create", "sa_batch_create_deferred", "sa_batch_prepare", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_all_pairs_summary", "sa_batch_pairs", "sa_batch_pairs16", "sa_batch_pairs16_all", "sa_batch_pairs_all", "sa_batch_stats",
+           "sa_batch_create", "sa_batch_create_deferred", "sa_batch_prepare", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_all_pairs_summary", "sa_batch_pairs", "sa_batch_pairs16", "sa_batch_pairs16_all", "sa_batch_pairs8", "sa_batch_pairs8_all", "sa_batch_pairs_all", "sa_batch_stats",
            "sa_batch_job_cells", "sa_batch_release_device", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_expect_last_stats", "sa_plan_describe", "sa_plan_digest",
            "sa_plan_check_path_records", "sa_dplan_compare",
            "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_pool_configure", "sa_host_alloc", "sa_host_free", "sa_pair_roundtrip", "sa_fasta_subsequence", "sa_format_f6", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_device_memory", "sa_strerror", "sa_hdp_state_load", "sa_hdp_state_write", "sa_hdp_state_info", "sa_hdp_state_free", "sa_hdp_state_distr_sample", "sa_hdp_state_sample_weights", "sa_hdp_finalize_distributions",
@@ -192,6 +193,8 @@ def lib():
     L.sa_batch_pairs16.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), ip]
     L.sa_batch_pairs_all.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, ip]
     L.sa_batch_pairs16_all.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), ip]
+    L.sa_batch_pairs8.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), ip]
+    L.sa_batch_pairs8_all.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), ip]
     L.sa_batch_stats.argtypes = [C.c_void_p, C.POINTER(BatchStats)]
     L.sa_batch_job_cells.argtypes = [C.c_void_p, C.c_int64, dp, dp]
     L.sa_batch_destroy.argtypes = [C.c_void_p]
@@ -448,6 +451,7 @@ class Batch:
             arr, self._keep = _make_jobs(jobs)
         amb = ambig if ambig is not None else default_ambig()
         self._amb, self._model = amb, model
+        self._flags = int(flags)
         fn, name = (lib().sa_batch_create_deferred, "sa_batch_create_deferred") if deferred else (lib().sa_batch_create, "sa_batch_create")
         _chk(fn(C.byref(self._h), model._h, C.byref(params), arr, self.n_jobs, amb, device, flags), name)
 
@@ -487,13 +491,31 @@ class Batch:
         buf = (C.c_uint64 * (2 * n.value)).from_address(ptr.value)
         return np.frombuffer(buf, dtype=np.uint64).reshape(-1, 2)
 
+    def pairs8(self, job):
+        """sa_batch_pairs8 (a FLAG_PAIRS8 batch): the job's records decoded into a structured array (x, y, prob_e7)"""
+        ptr, n = C.c_void_p(), C.c_int64()
+        _chk(lib().sa_batch_pairs8(self._h, job, C.byref(ptr), C.byref(n)), "sa_batch_pairs8")
+        out = np.zeros(n.value, dtype=[("x", np.int32), ("y", np.int32), ("prob_e7", np.int64)])
+        if n.value:
+            r = np.frombuffer((C.c_uint64 * n.value).from_address(ptr.value), dtype=np.uint64)
+            out["x"] = (r & np.uint64(0xfffff)).astype(np.int32)
+            out["y"] = ((r >> np.uint64(20)) & np.uint64(0xfffff)).astype(np.int32)
+            out["prob_e7"] = (r >> np.uint64(40)).astype(np.int64)
+        return out
+
     def results_view(self, first=None):
         """sa_batch_pairs16_all: what a finished batch holds, without copying anything -- (uint64 view [total, 2] of every job's
         packed records, first) with job j's records at view[first[j]:first[j + 1]].  `first`: an int64 array of n_jobs + 1
-        entries to reuse."""
+        entries to reuse.  (A FLAG_PAIRS8 batch: sa_batch_pairs8_all, a view [total, 1].)"""
         if first is None:
             first = np.zeros(self.n_jobs + 1, dtype=np.int64)
         ptr = C.c_void_p()
+        if self._flags & FLAG_PAIRS8:
+            _chk(lib().sa_batch_pairs8_all(self._h, C.byref(ptr), _ip(first)), "sa_batch_pairs8_all")
+            total = int(first[self.n_jobs])
+            if total == 0:
+                return np.zeros((0, 1), dtype=np.uint64), first
+            return np.frombuffer((C.c_uint64 * total).from_address(ptr.value), dtype=np.uint64).reshape(-1, 1), first
         _chk(lib().sa_batch_pairs16_all(self._h, C.byref(ptr), _ip(first)), "sa_batch_pairs16_all")
         total = int(first[self.n_jobs])
         if total == 0:

@@ -1007,8 +1007,14 @@ __device__ __forceinline__ bool seg_is_strip(const sa_region_t *R, int strip_on)
 //     diagonal, in the order the waves got there: a survivor's place is the number of survivors ahead of it in the list, minus
 //     those of its own diagonal among them, plus those of its own diagonal with a smaller (column, path) -- its neighbours in the
 //     list, a handful.
+// a result record at slot `pos` of a group's range: 16 bytes, or (SA_FLAG_PAIRS8: one path per cell, coordinates below 2^20) 8
+__device__ __forceinline__ void put_pair(sa_pair16_t *out, long long pos, int p8, long long pe, int x, int y, int path, int kmer) {
+    if (p8) reinterpret_cast<unsigned long long *>(out)[pos] = sa_pair8_pack(pe, x, y);
+    else out[pos] = sa_pair16_pack(pe, x, y, path, kmer);
+}
 __global__ __launch_bounds__(64) void k_gather(DevPlan P, int seg0, int n_segs, const long long *prob_e7,
-                                               const long long *seg_off, sa_pair16_t *out, const double *__restrict__ spec, int strip_on) {
+                                               const long long *seg_off, sa_pair16_t *out, const double *__restrict__ spec, int strip_on,
+                                               int p8) {
     if ((int) blockIdx.x >= n_segs) return;
     const int lseg = blockIdx.x;
     int seg = seg0 + lseg;
@@ -1055,8 +1061,7 @@ __global__ __launch_bounds__(64) void k_gather(DevPlan P, int seg0, int n_segs, 
                 k += less - same_before;
             }
             long long pos = seg_off[lseg] + (total - 1 - k);
-            out[pos] = sa_pair16_pack(pe[i], (int) (c.x + R->x1), (int) (c.y + R->y1), c.path,
-                                      pid[poff[c.x + 1] + c.path]);
+            put_pair(out, pos, p8, pe[i], (int) (c.x + R->x1), (int) (c.y + R->y1), c.path, pid[poff[c.x + 1] + c.path]);
         }
         done += __popcll(mask);
     }
@@ -1075,7 +1080,7 @@ __global__ __launch_bounds__(64) void k_gather(DevPlan P, int seg0, int n_segs, 
 #endif
 __global__ __launch_bounds__(64) void k_gather_sorted(DevPlan P, int seg0, int n_segs, const long long *prob_e7, const long long *seg_off,
                                                       sa_pair16_t *out, const double *__restrict__ spec,
-                                                      unsigned long long *keys_all, unsigned *idx_all) {
+                                                      unsigned long long *keys_all, unsigned *idx_all, int p8) {
     __shared__ int H[GATHER_H + 64];
     if ((int) blockIdx.x >= n_segs) return;
     const int lseg = blockIdx.x, seg = seg0 + lseg;
@@ -1154,8 +1159,8 @@ __global__ __launch_bounds__(64) void k_gather_sorted(DevPlan P, int seg0, int n
     for (long long k = lane; k < total; k += 64) {
         const unsigned i = idx[k];
         const sa_cand_t c = P.cands[S->cand_off + i];
-        out[seg_off[lseg] + (total - 1 - k)] = sa_pair16_pack(prob_e7[S->cand_off + i], (int) (c.x + R->x1), (int) (c.y + R->y1), c.path,
-                                                              pid[poff[c.x + 1] + c.path]);
+        put_pair(out, seg_off[lseg] + (total - 1 - k), p8, prob_e7[S->cand_off + i], (int) (c.x + R->x1), (int) (c.y + R->y1), c.path,
+                 pid[poff[c.x + 1] + c.path]);
     }
 }
 
@@ -1288,6 +1293,10 @@ struct sa_batch {
     int *h_overflow;               // pinned
     // results
     sa_pair16_t *h_pairs;    // pinned host copy of all pairs (packed, sa_internal.h), job after job
+    bool p8 = false;         // SA_FLAG_PAIRS8: the records are 8 bytes (sa_pair8_t), in h_pairs and in d_out alike
+    size_t rec() const { return p8 ? sizeof(sa_pair8_t) : sizeof(sa_pair16_t); }
+    sa_pair16_t *out_at(long long slot) const { return reinterpret_cast<sa_pair16_t *>(reinterpret_cast<char *>(d_out) + rec() * (size_t) slot); }
+    sa_pair16_t *host_at(long long slot) const { return reinterpret_cast<sa_pair16_t *>(reinterpret_cast<char *>(h_pairs) + rec() * (size_t) slot); }
     long long h_pairs_cap, n_pairs_total;
     std::vector<long long> job_off;
     std::vector<long long> job_dev_off;   // where a job's pairs start in d_out (device finalisation only)
@@ -2057,6 +2066,14 @@ static int batch_prepare_body(sa_batch *b) {
 
     b->expect = (flags & SA_FLAG_EXPECT_INTERNAL) != 0;
     b->plan_hdp = m->hdp != nullptr;
+    b->p8 = (flags & SA_FLAG_PAIRS8) != 0 && !b->expect;
+    if (b->p8) {   // 20 bits per coordinate, no path index, no k-mer: only what one path per cell and short matrices allow
+        if (flags & SA_FLAG_VC_ROWS) return SA_EINVAL;
+        for (int64_t j = 0; j < n_jobs; j++)
+            if (jobs[j].ref_len >= SA_PAIR8_MAX_COORD || jobs[j].n_events >= SA_PAIR8_MAX_COORD) return SA_EUNSUPPORTED;
+        for (long long r = 0; r < pl->n_regions; r++)
+            if (pl->regions[r].max_p > 1) return SA_EUNSUPPORTED;
+    }
     b->relax = !(flags & SA_FLAG_EXACT) && !b->expect && m->hdp == nullptr;
     b->ring_cap = 0;
     b->gen_threads = 64;
@@ -2361,6 +2378,29 @@ static int batch_finish_body(sa_batch *b) {
         b->gev.clear(); b->cev.clear();
         b->seam_cap = 0; b->seam_cap_bwd = 0; b->seam_bwd_off = 0; b->strip_one_pass = false;
     };
+    // A batch whose RESULTS take longer to cross PCIe than its kernels take to run (broad HDP densities at a low threshold: hundreds of
+    // millions of pairs) ends when its last copy ends, and its first copy cannot start before the forward sweep of its first pass has
+    // finished: such a batch sweeps in four passes instead of one, so that the first groups' pairs travel while the later passes
+    // compute (5000 HDP reads at threshold 0.01, 8-byte records: 87 -> 76 ms per step; the kernels themselves lose 5 ms to the
+    // smaller launches).  The estimate is the pairs-per-event of the last finished batch of this kind (g_pairs_memo).
+    if (!(flags & SA_FLAG_EXACT) && !b->expect && pl->n_chunks == 1 && pl->n_regions >= 64 && !getenv("SA_F_BUDGET_CELLPATHS")) {
+        const double est_bytes = g_pairs_memo.estimate(pl->params.threshold, b->plan_hdp) * (double) pl->n_ev * (double) b->rec();
+        if (est_bytes > 2.0e9) {
+            long long total = 0, largest = 1;
+            for (long long r = 0; r < pl->n_regions; r++) {
+                total += pl->regions[r].f_cellpaths;
+                largest = pl->regions[r].f_cellpaths > largest ? pl->regions[r].f_cellpaths : largest;
+            }
+            const long long quarter = (total + 3) / 4;
+            sa_plan_repack(pl, quarter > largest ? quarter : largest);
+            TRY(batch_build_lists(b));
+            if (pl->n_regions > 0 && hipMemcpy(b->d_regions, pl->regions, sizeof(sa_region_t) * (size_t) pl->n_regions, hipMemcpyHostToDevice) != hipSuccess) {
+                (void) hipGetLastError();
+                return SA_ENODEVICE;
+            }
+            if (trace_c) fprintf(stderr, "[trace] create: %.1f GB of pairs expected: forward storage in %d passes\n", est_bytes / 1e9, (int) pl->n_chunks);
+        }
+    }
     {
         int rcw = SA_OK;
         for (int attempt = 0; attempt < 6; attempt++) {
@@ -2424,7 +2464,7 @@ static int batch_finish_body(sa_batch *b) {
     if (!(flags & SA_FLAG_EXACT) && !b->expect && b->h_pairs_cap == 0 && pl->params.threshold >= 0.005) {
         const long long total = (long long) (g_pairs_memo.estimate(pl->params.threshold, m->hdp != nullptr) * (double) pl->n_ev) + 4096;
         const long long cap = total + total / 8 + 1024;
-        if (g_sa_pool.get(SaPool::PINNED, (void **) &b->h_pairs, sizeof(sa_pair16_t) * (size_t) cap, device) == hipSuccess) b->h_pairs_cap = cap;
+        if (g_sa_pool.get(SaPool::PINNED, (void **) &b->h_pairs, b->rec() * (size_t) cap, device) == hipSuccess) b->h_pairs_cap = cap;
         else { (void) hipGetLastError(); b->h_pairs = nullptr; }   // (the run asks again)
     }
     if (trace_c) fprintf(stderr, "[trace] create: done at %.1f ms\n", now_ms_c() - tc0);
@@ -2561,11 +2601,12 @@ static int submit_group(sa_batch *b, const DevPlan &P, int g, int which_stream, 
         hipLaunchKernelGGL(k_finalize, dim3((unsigned) n), dim3(64), 0, st, P, (int) G.seg0, n, b->d_prob, b->d_seg_pass, spec,
                            b->spec_slack, (const unsigned long long *) b->d_vc_bits, (const long long *) b->d_vc_off, b->d_seg_all);
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, b->d_seg_pass + G.seg0, soff, b->h_seg_off + G.seg0 + g, n);
+        sa_pair16_t *const gout = b->out_at(pl->segs[G.seg0].cand_off);
         hipLaunchKernelGGL(k_gather, dim3((unsigned) n), dim3(64), 0, st, P, (int) G.seg0, n, b->d_prob, soff,
-                           b->d_out + pl->segs[G.seg0].cand_off, spec, (b->strip_on && b->strip_one_pass && b->d_sortkey) ? 1 : 0);
+                           gout, spec, (b->strip_on && b->strip_one_pass && b->d_sortkey) ? 1 : 0, b->p8 ? 1 : 0);
         if (spec && G.nss > 0 && b->d_sortkey)
             hipLaunchKernelGGL(k_gather_sorted, dim3((unsigned) n), dim3(64), 0, st, P, (int) G.seg0, n, b->d_prob, soff,
-                               b->d_out + pl->segs[G.seg0].cand_off, spec, b->d_sortkey, b->d_sortidx);
+                               gout, spec, b->d_sortkey, b->d_sortidx, b->p8 ? 1 : 0);
         HIPCHK(hipEventRecord(b->gev[4 * g + 2], st));
     } else {
         HIPCHK(hipEventRecord(b->gev[4 * g + 2], st));
@@ -2762,7 +2803,7 @@ static int batch_run_body(sa_batch_t *b) {
             g_sa_pool.put(SaPool::PINNED, b->h_pairs);
             b->h_pairs = nullptr;
             long long cap = total + total / 8 + 1024;
-            HIPCHK(g_sa_pool.get(SaPool::PINNED, (void **) &b->h_pairs, sizeof(sa_pair16_t) * (size_t) cap, b->device));
+            HIPCHK(g_sa_pool.get(SaPool::PINNED, (void **) &b->h_pairs, b->rec() * (size_t) cap, b->device));
             b->h_pairs_cap = cap;
         }
         return SA_OK;
@@ -2810,8 +2851,10 @@ static int batch_run_body(sa_batch_t *b) {
         total = 0;
         for (long long j = 0; j < pl->n_jobs; j++) {
             b->job_off[j] = total;
-            for (int64_t q = 0; q < np[j]; q++)
-                b->h_pairs[total + q] = sa_pair16_pack(pp[j][q].prob_e7, pp[j][q].x, pp[j][q].y, pp[j][q].path, pp[j][q].kmer_id);
+            for (int64_t q = 0; q < np[j]; q++) {
+                if (b->p8) reinterpret_cast<sa_pair8_t *>(b->h_pairs)[total + q] = sa_pair8_pack(pp[j][q].prob_e7, pp[j][q].x, pp[j][q].y);
+                else b->h_pairs[total + q] = sa_pair16_pack(pp[j][q].prob_e7, pp[j][q].x, pp[j][q].y, pp[j][q].path, pp[j][q].kmer_id);
+            }
             total += np[j];
             free(pp[j]);
         }
@@ -2840,8 +2883,8 @@ static int batch_run_body(sa_batch_t *b) {
             gbase[g] = running;
             if (piped && running + tg <= b->h_pairs_cap) {
                 if (tg > 0)
-                    HIPCHK(hipMemcpyAsync(b->h_pairs + running, b->d_out + pl->segs[G.seg0].cand_off,
-                                          sizeof(sa_pair16_t) * (size_t) tg, hipMemcpyDeviceToHost, b->pair_stream));
+                    HIPCHK(hipMemcpyAsync(b->host_at(running), b->out_at(pl->segs[G.seg0].cand_off),
+                                          b->rec() * (size_t) tg, hipMemcpyDeviceToHost, b->pair_stream));
             } else {
                 piped = false;  // first run (or a larger result than last time): size the pinned buffer afterwards
             }
@@ -2913,8 +2956,8 @@ static int batch_run_body(sa_batch_t *b) {
                 const sa_launch_group &G = b->groups[g];
                 long long tg = gbase[g + 1] - gbase[g];
                 if (tg > 0)
-                    HIPCHK(hipMemcpyAsync(b->h_pairs + gbase[g], b->d_out + pl->segs[G.seg0].cand_off,
-                                          sizeof(sa_pair16_t) * (size_t) tg, hipMemcpyDeviceToHost, b->pair_stream));
+                    HIPCHK(hipMemcpyAsync(b->host_at(gbase[g]), b->out_at(pl->segs[G.seg0].cand_off),
+                                          b->rec() * (size_t) tg, hipMemcpyDeviceToHost, b->pair_stream));
             }
             HIPCHK(sa_sync_stream(b->pair_stream, b->device));
         }
@@ -2965,7 +3008,7 @@ static int batch_run_body(sa_batch_t *b) {
 int sa_batch_device_view(sa_batch_t *b, const sa_pair16_t **pairs, std::vector<long long> *first, std::vector<long long> *count,
                          std::vector<long long> *n_events, int *device) {
     if (!b || !pairs || !first || !count || !n_events || !device) return SA_EINVAL;
-    if (!b->ran) return SA_ESTATE;
+    if (!b->ran || b->p8) return SA_ESTATE;   // (8-byte records name neither path nor k-mer: nothing a downstream device step reads)
     const sa_plan_t *pl = b->plan;
     const size_t nj = (size_t) pl->n_jobs;
     first->assign(nj, 0); count->assign(nj, 0); n_events->assign(nj, 0);
@@ -3070,14 +3113,30 @@ int sa_batch_all_pairs_summary(const sa_batch_t *b, int64_t job, int64_t *n_all,
         return SA_OK;
     }
     long long s = 0;
-    for (long long i = b->job_off[job]; i < b->job_off[job + 1]; i++) s += (long long) ((b->h_pairs[i].b >> 32) & 0xffffffull);
+    for (long long i = b->job_off[job]; i < b->job_off[job + 1]; i++)
+        s += b->p8 ? (long long) (reinterpret_cast<const sa_pair8_t *>(b->h_pairs)[i] >> 40) : (long long) ((b->h_pairs[i].b >> 32) & 0xffffffull);
     if (n_all) *n_all = b->job_off[job + 1] - b->job_off[job];
     if (sum_prob_e7) *sum_prob_e7 = s;
     return SA_OK;
 }
+int sa_batch_pairs8(const sa_batch_t *b, int64_t job, const sa_pair8_t **out, int64_t *n) {
+    if (!b || !out || !n || job < 0 || job >= b->c_n) return SA_EINVAL;
+    if (!b->ran || !b->p8) return SA_ESTATE;
+    *out = reinterpret_cast<const sa_pair8_t *>(b->h_pairs) + b->job_off[job];
+    *n = b->job_off[job + 1] - b->job_off[job];
+    return SA_OK;
+}
+int sa_batch_pairs8_all(const sa_batch_t *b, const sa_pair8_t **out, int64_t *first) {
+    if (!b || !out) return SA_EINVAL;
+    if (!b->ran || !b->p8) return SA_ESTATE;
+    *out = reinterpret_cast<const sa_pair8_t *>(b->h_pairs);
+    if (first)
+        for (int64_t j = 0; j <= b->c_n; j++) first[j] = b->job_off[(size_t) j];
+    return SA_OK;
+}
 int sa_batch_pairs(const sa_batch_t *b, int64_t job, sa_pair_t *out, int64_t cap) {
     if (!b || job < 0 || job >= b->c_n) return SA_EINVAL;
-    if (!b->ran) return SA_ESTATE;
+    if (!b->ran || b->p8) return SA_ESTATE;
     long long n = b->job_off[job + 1] - b->job_off[job];
     if (n > cap) return SA_EINVAL;
     const sa_pair16_t *src = b->h_pairs + b->job_off[job];
@@ -3086,14 +3145,14 @@ int sa_batch_pairs(const sa_batch_t *b, int64_t job, sa_pair_t *out, int64_t cap
 }
 int sa_batch_pairs16(const sa_batch_t *b, int64_t job, const sa_pair16_t **out, int64_t *n) {
     if (!b || !out || !n || job < 0 || job >= b->c_n) return SA_EINVAL;
-    if (!b->ran) return SA_ESTATE;
+    if (!b->ran || b->p8) return SA_ESTATE;
     *n = b->job_off[job + 1] - b->job_off[job];
     *out = b->h_pairs + b->job_off[job];
     return SA_OK;
 }
 int sa_batch_pairs16_all(const sa_batch_t *b, const sa_pair16_t **out, int64_t *first) {
     if (!b || !out) return SA_EINVAL;
-    if (!b->ran) return SA_ESTATE;
+    if (!b->ran || b->p8) return SA_ESTATE;
     *out = b->h_pairs;
     if (first)
         for (long long j = 0; j <= (long long) b->c_n; j++) first[j] = b->job_off[(size_t) j];
@@ -3101,7 +3160,7 @@ int sa_batch_pairs16_all(const sa_batch_t *b, const sa_pair16_t **out, int64_t *
 }
 int sa_batch_pairs_all(const sa_batch_t *b, sa_pair_t *out, int64_t cap, int64_t *first) {
     if (!b || (!out && cap > 0)) return SA_EINVAL;
-    if (!b->ran) return SA_ESTATE;
+    if (!b->ran || b->p8) return SA_ESTATE;
     const long long nj = b->c_n, total = b->n_pairs_total;
     if (first)
         for (long long j = 0; j <= nj; j++) first[j] = b->job_off[(size_t) j];

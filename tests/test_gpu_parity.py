@@ -751,3 +751,37 @@ def test_released_batches_keep_their_results_and_a_nan_event_is_reported(oracle,
         b2.run()
     assert ei.value.code == -1 and "not a finite number" in capfd.readouterr().err
     b2.close()
+
+
+def test_eight_byte_result_records(oracle):
+    """SA_FLAG_PAIRS8: the same pairs as the 16-byte records in the same order, (x, y, prob_e7) only -- register, strip and
+    memory-resident kernels, device and host finalisation; refused where a cell may hold several paths or a coordinate does not fit
+    20 bits; the 16-byte accessors refuse such a batch."""
+    pm = sa.Model.load(cases.MODEL_6MER)
+    jobs = cases.synthetic_jobs(cases.MODEL_6MER, 5, 1400, 31) + cases.realistic_anchor_jobs(cases.MODEL_6MER, 3, 2500, 77)
+    p = sa.default_params(threshold=0.01)
+    for flags in (0, sa.FLAG_EXACT, sa.FLAG_FORCE_GENERIC):
+        a = sa.Batch(pm, p, jobs, flags=flags)
+        a.run()
+        b = sa.Batch(pm, p, jobs, flags=flags | sa.FLAG_PAIRS8)
+        b.run()
+        view, first = b.results_view()
+        assert view.shape == (int(first[-1]), 1)
+        for j in range(len(jobs)):
+            x, y = a.pairs(j), b.pairs8(j)
+            assert len(x) == len(y) == b.n_pairs(j) and len(x) > 100
+            assert np.array_equal(x["x"], y["x"]) and np.array_equal(x["y"], y["y"]) and np.array_equal(x["prob_e7"], y["prob_e7"])
+            assert a.all_pairs_summary(j) == b.all_pairs_summary(j)
+        with pytest.raises(sa.SaError):
+            b.pairs(0)
+        with pytest.raises(sa.SaError):
+            a.pairs8(0)
+        with pytest.raises(sa.SaError):
+            b.mea()
+        a.close(); b.close()
+    cm = sa.Model.load(cases.MODEL_CPG)
+    cj = cases.synthetic_jobs(cases.MODEL_CPG, 2, 600, 5)
+    s = list(cj[0]["ref"]); s[s.index("C", 50)] = "X"; cj[0]["ref"] = "".join(s)
+    with pytest.raises(sa.SaError) as ei:
+        sa.Batch(cm, p, cj, ambig=sa.default_ambig({"X": "CE"}), flags=sa.FLAG_PAIRS8).run()
+    assert ei.value.code == -8   # SA_EUNSUPPORTED
