@@ -959,6 +959,12 @@ class HdpState:
         ga = None if gamma_alpha is None else np.ascontiguousarray(gamma_alpha, dtype=np.float64)
         gb = None if gamma_beta is None else np.ascontiguousarray(gamma_beta, dtype=np.float64)
         gr = None if groups is None else np.ascontiguousarray(groups, dtype=np.int64)
+        depth = 2 if int(layout) == HDP_LAYOUT_FLAT else 3   # (the C entry point reads `depth` values of each vector it is given)
+        for v in (g, ga, gb):
+            if v is not None and len(v) != depth:
+                raise SaError(-1, "sa_hdp_state_new: %d concentration parameters for a layout of depth %d" % (len(v), depth))
+        if gr is not None and len(gr) != len(alphabet):
+            raise SaError(-1, "sa_hdp_state_new: one group per letter of the alphabet")
         _chk(lib().sa_hdp_state_new(C.byref(h), int(layout), alphabet.encode(), int(kmer_length), None if gr is None else _ip(gr),
                                     None if g is None else _dp(g), None if ga is None else _dp(ga), None if gb is None else _dp(gb),
                                     float(grid[0]), float(grid[1]), int(grid[2]), float(nig[0]), float(nig[1]), float(nig[2]), float(nig[3])),
@@ -973,6 +979,9 @@ class HdpState:
         g = None if gamma is None else np.ascontiguousarray(gamma, dtype=np.float64)
         ga = None if gamma_alpha is None else np.ascontiguousarray(gamma_alpha, dtype=np.float64)
         gb = None if gamma_beta is None else np.ascontiguousarray(gamma_beta, dtype=np.float64)
+        for v in (g, ga, gb):
+            if v is not None and len(v) != int(depth):
+                raise SaError(-1, "sa_hdp_state_new_tree: %d concentration parameters for depth %d" % (len(v), int(depth)))
         _chk(lib().sa_hdp_state_new_tree(C.byref(h), len(pa), int(depth), _ip(pa), None if g is None else _dp(g),
                                          None if ga is None else _dp(ga), None if gb is None else _dp(gb), float(grid[0]), float(grid[1]),
                                          int(grid[2]), float(nig[0]), float(nig[1]), float(nig[2]), float(nig[3])), "sa_hdp_state_new_tree")

@@ -139,7 +139,7 @@ def test_data_passing_and_serialisation_of_the_reference_test_hdp(tmp_path, orac
         s.pass_data([1.0, 2.0], [1, 3])
     s.pass_data(data[:100], dps[:100])
     assert s.info.n_data == 100 and s.info.n_factors == 1 + len(set(dps[:100].tolist())) + len({1, 2} & {1 if d in (3, 5) else 2 for d in dps[:100]}) + 100
-    if sa.device_count() == 0:
+    if sa.device_count() == 0 and not os.environ.get("SA_SAMPLER_STUB"):   # (probes/host_asan.sh stubs the GPU sampler out)
         with pytest.raises(sa.SaError) as ei:
             s.gibbs(10, 10, 10)
         assert ei.value.code == -3
