@@ -2391,8 +2391,7 @@ static int batch_finish_body(sa_batch *b) {
                 total += pl->regions[r].f_cellpaths;
                 largest = pl->regions[r].f_cellpaths > largest ? pl->regions[r].f_cellpaths : largest;
             }
-            const long long quarter = (total + 3) / 4;
-            sa_plan_repack(pl, quarter > largest ? quarter : largest);
+            sa_plan_repack(pl, (total + 3) / 4 + largest);   // (a pass closes before the region that would overflow it: four at most)
             TRY(batch_build_lists(b));
             if (pl->n_regions > 0 && hipMemcpy(b->d_regions, pl->regions, sizeof(sa_region_t) * (size_t) pl->n_regions, hipMemcpyHostToDevice) != hipSuccess) {
                 (void) hipGetLastError();

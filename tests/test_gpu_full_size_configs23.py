@@ -92,6 +92,24 @@ def test_baseline_config_3_full_size(oracle, threshold):
     b.run()
     assert _digest(b, n_reads)[0] == first
     b.close()
+    # a second batch of the same reads: its page-locked result block is sized from the first one's pairs per event, and at threshold
+    # 0.01 (7 GB of pairs) it sweeps in four forward passes so that its copies start early -- the same bytes either way
+    b2 = sa.Batch(pm, p, jobs)
+    b2.run()
+    assert b2.stats().n_chunks == (4 if threshold < 0.05 else 1)
+    assert _digest(b2, n_reads)[0] == first
+    b2.close()
+    if threshold < 0.05:   # ... and as 8-byte records
+        b8 = sa.Batch(pm, p, jobs, flags=sa.FLAG_PAIRS8)
+        b8.run()
+        view, first8 = b8.results_view()
+        full = sa.Batch(pm, p, jobs[:40])
+        full.run()
+        for j in range(40):
+            a, c = full.pairs(j), b8.pairs8(j)
+            assert np.array_equal(a["x"], c["x"]) and np.array_equal(a["y"], c["y"]) and np.array_equal(a["prob_e7"], c["prob_e7"])
+        assert view.shape == (int(first8[-1]), 1) and int(first8[-1]) > 4e8
+        b8.close(); full.close()
     pick = [0, 2500, 4999]
     small = sa.Batch(pm, p, [jobs[j] for j in pick])
     small.run()
