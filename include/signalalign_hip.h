@@ -409,6 +409,7 @@ int sa_format_f6(char *out, double v);
  *   sa_pool_configure(device_limit_bytes, pinned_limit_bytes)   a negative value leaves that bound as it is; 0 keeps nothing
  *       parked; blocks above a lowered bound are freed at once.  Wins over the environment.
  *   sa_pool_release()                                           returns everything that is parked right now.
+ *   sa_pool_release_device()                                    ... the device blocks only (page-locked blocks stay parked)
  * sa_host_alloc / sa_host_free: page-locked host memory for a caller's own input arrays (SA_FLAG_INPUTS_IN_HOST_BLOCK); a
  * block belongs to the caller until sa_host_free, which must not be called before every batch created from it has run or has
  * been destroyed.
@@ -417,6 +418,7 @@ int sa_pool_configure(int64_t device_limit_bytes, int64_t pinned_limit_bytes);
 void *sa_host_alloc(size_t bytes);   /* NULL: no memory (or no device) */
 void sa_host_free(void *block);      /* NULL or a pointer sa_host_alloc did not return: ignored */
 void sa_pool_release(void);
+void sa_pool_release_device(void);
 
 /* ---- maximum-expected-accuracy path over a read's posteriors ----------------------------------
  * Replaces maximum_expected_accuracy_alignment + get_indexes_from_best_path (src/signalalign/mea_algorithm.py:25-197,

@@ -86,7 +86,7 @@ EXPORTS = ["sa_model_create", "sa_model_load", "sa_model_destroy", "sa_model_alp
            "sa_batch_create", "sa_batch_create_deferred", "sa_batch_prepare", "sa_batch_run", "sa_batch_n_pairs", "sa_batch_all_pairs_summary", "sa_batch_pairs", "sa_batch_pairs16", "sa_batch_pairs16_all", "sa_batch_pairs8", "sa_batch_pairs8_all", "sa_batch_pairs_all", "sa_batch_stats",
            "sa_batch_job_cells", "sa_batch_release_device", "sa_batch_destroy", "sa_align_batch", "sa_expect_batch", "sa_expect_last_stats", "sa_plan_describe", "sa_plan_digest",
            "sa_plan_check_path_records", "sa_dplan_compare",
-           "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_pool_configure", "sa_host_alloc", "sa_host_free", "sa_pair_roundtrip", "sa_fasta_subsequence", "sa_format_f6", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_device_memory", "sa_strerror", "sa_hdp_state_load", "sa_hdp_state_write", "sa_hdp_state_info", "sa_hdp_state_free", "sa_hdp_state_distr_sample", "sa_hdp_state_sample_weights", "sa_hdp_finalize_distributions",
+           "sa_guide_to_anchors", "sa_remap_anchors", "sa_estimate_params", "sa_scalings_mom", "sa_event_align_batch", "sa_event_align_release", "sa_pool_release", "sa_pool_release_device", "sa_pool_configure", "sa_host_alloc", "sa_host_free", "sa_pair_roundtrip", "sa_fasta_subsequence", "sa_format_f6", "sa_batch_start", "sa_batch_wait", "sa_mea_batch", "sa_mea_release", "sa_mea_params", "sa_batch_mea", "sa_mea_printed_posterior", "sa_mea_printed_posterior_device", "sa_device_count", "sa_device_memory", "sa_strerror", "sa_hdp_state_load", "sa_hdp_state_write", "sa_hdp_state_info", "sa_hdp_state_free", "sa_hdp_state_distr_sample", "sa_hdp_state_sample_weights", "sa_hdp_finalize_distributions",
            "sa_hdp_state_new", "sa_hdp_state_new_tree", "sa_hdp_nig_params_from_table", "sa_hdp_state_pass_data", "sa_hdp_state_pass_assignments", "sa_hdp_state_pass_assignment_file", "sa_hdp_state_kmer_dp", "sa_hdp_state_gibbs", "sa_hdp_state_finalize", "sa_hdp_state_samples_taken", "sa_hdp_digamma", "sa_hdp_trigamma",
            "sa_hmm_create", "sa_hmm_destroy", "sa_hmm_view", "sa_hmm_set_event_model", "sa_hmm_add_expectations",
            "sa_hmm_add_emission_expectation", "sa_hmm_add_assignment", "sa_hmm_add_expectations_file", "sa_hmm_write", "sa_hmm_load", "sa_hmm_normalize",

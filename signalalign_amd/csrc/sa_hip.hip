@@ -1587,6 +1587,9 @@ static bool sa_host_block_of(const char *p, const char **base, size_t *bytes) {
     return true;
 }
 
+extern "C" void sa_pool_release_device(void) {
+    g_sa_pool.release(SaPool::DEVICE);
+}
 extern "C" void sa_pool_release(void) {
     g_sa_pool.release(SaPool::DEVICE);
     g_sa_pool.release(SaPool::PINNED);
