@@ -83,6 +83,25 @@ def test_random_shapes(oracle, model_path, ambiguous, seed, require_strips=True)
         for j in range(len(jobs)):
             assert np.array_equal(blk.pairs(j), ref_b.pairs(j)), (j, expansion, split)
         blk.close()
+        # round 5, the two result-side flags under the same shapes: with ambiguity letters only the rows whose reference k-mer holds
+        # an X leave the device (SA_FLAG_VC_ROWS), the others are counted and summed; without, the 8-byte records hold the same pairs
+        if ambiguous:
+            vc = sa.Batch(pm, p, jobs, ambig=amb_p, flags=sa.FLAG_VC_ROWS)
+            vc.run()
+            for j, job in enumerate(jobs):
+                a = ref_b.pairs(j)
+                keep = np.array([("X" in job["ref"][x:x + k]) for x in a["x"]], dtype=bool)
+                assert np.array_equal(a[keep], vc.pairs(j)), (j, expansion, split)
+                assert vc.all_pairs_summary(j) == (len(a), int(a["prob_e7"].sum()))
+            vc.close()
+        else:
+            p8 = sa.Batch(pm, p, jobs, flags=sa.FLAG_PAIRS8)
+            p8.run()
+            for j in range(len(jobs)):
+                a, c = ref_b.pairs(j), p8.pairs8(j)
+                assert len(a) == len(c) and np.array_equal(a["x"], c["x"]) and np.array_equal(a["y"], c["y"]) \
+                    and np.array_equal(a["prob_e7"], c["prob_e7"]), (j, expansion, split)
+            p8.close()
         ref_b.close()
     # thinned and absent anchors leave wide one-path bands: those regions run on the strip kernels (sa_strip.inc), small
     # split rectangles and ragged ends included
