@@ -2222,6 +2222,14 @@ static int batch_prepare_body(sa_batch *b) {
                     coef[4 * k + 2] = (double) (3.0L * dy - (2.0L * s0 + s1) * dxl);
                     coef[4 * k + 3] = (double) ((s0 + s1) * dxl - 2.0L * dy);
                 }
+#ifdef EMIT_F32TAB   // (probe build: the four coefficients of an interval as floats, 16 B per interval, in the front half of the table)
+            {
+                float *cf = reinterpret_cast<float *>(coef.data());
+                std::vector<float> tmp((size_t) (h->n_slots * h->grid_length * 4));
+                for (size_t q = 0; q < tmp.size(); q++) tmp[q] = (float) coef[q];
+                memcpy(cf, tmp.data(), tmp.size() * sizeof(float));
+            }
+#endif
             TRY(upload(&b->d_hdp_coef, coef.data(), (long long) coef.size()));
         }
     }
