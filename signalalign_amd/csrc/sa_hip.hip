@@ -2224,10 +2224,9 @@ static int batch_prepare_body(sa_batch *b) {
                 }
 #ifdef EMIT_F32TAB   // (probe build: the four coefficients of an interval as floats, 16 B per interval, in the front half of the table)
             {
-                float *cf = reinterpret_cast<float *>(coef.data());
                 std::vector<float> tmp((size_t) (h->n_slots * h->grid_length * 4));
                 for (size_t q = 0; q < tmp.size(); q++) tmp[q] = (float) coef[q];
-                memcpy(cf, tmp.data(), tmp.size() * sizeof(float));
+                memcpy(coef.data(), tmp.data(), tmp.size() * sizeof(float));
             }
 #endif
             TRY(upload(&b->d_hdp_coef, coef.data(), (long long) coef.size()));
