@@ -1279,7 +1279,7 @@ def main():
             r3 = leg("hdp_threshold_0.01", "hdp", 5000, 5000, 0.01, 3, 1, cpu=False)
             args_p8 = args.pairs8
             args.pairs8 = True
-            r3b = leg("hdp_threshold_0.01_pairs8", "hdp", 5000, 5000, 0.01, 3, 1, cpu=False)
+            r3b = leg("hdp_threshold_0.01_pairs8", "hdp", 5000, 5000, 0.01, 3, 1, cpu=True)
             args.pairs8 = args_p8
             if r3b is not None:
                 sec["hdp_threshold_0.01_pairs8"]["note"] = ("the same step with SA_FLAG_PAIRS8: 8-byte records (x, y, probability; the "
