@@ -152,9 +152,9 @@ def test_signalmachine_variant_caller_output(oracle, tmp_path):
 def test_variant_caller_rows_are_filtered_on_the_device(oracle, tmp_path):
     """-s 1 keeps only the rows whose reference k-mer holds an X (writePosteriorProbsVC, impl/signalMachine.c:161-232).  The library
     drops the others on the device (SA_FLAG_VC_ROWS) and keeps their count and probability sum for the summary line: the file and
-    the summary line are byte-identical to the run that fetches every pair and filters while it writes (SA_CLI_VC_ON_HOST=1), both
-    strands of a 2-D read, and the library call returns exactly the filtered subset of the unfiltered call -- device finalisation
-    and SA_FLAG_EXACT's host finalisation alike."""
+    the summary line are byte-identical to the run that fetches every pair and filters while it writes (SA_CLI_VC_ON_HOST=1) -- a 1-D
+    read and both strands of the bundled 2-D read --, and the library call returns exactly the filtered subset of the unfiltered call -- device finalisation and SA_FLAG_EXACT's host
+    finalisation alike."""
     npread_path = os.path.join(cases.GOLDEN, "npReads", "r9p4_oneD.npRead")
     r = oracle.parse_npread(npread_path)
     read = r["template_read"]
@@ -182,6 +182,34 @@ def test_variant_caller_rows_are_filtered_on_the_device(oracle, tmp_path):
     assert outs["device"][0] and outs["device"] == outs["host"]
     n_all = int(outs["device"][1].split("\t")[1].split("(")[0])
     assert n_all > 10 * len(outs["device"][0].splitlines()) // 6        # the summary line still counts every pair
+    # both strands of the bundled 2-D read (--twoD: two batches, the template's released before the complement's runs), the
+    # reference's own contig with an X at fifteen cytosines of the aligned window
+    import json
+    cig = json.load(open(os.path.join(cases.GOLDEN, "cigars", "zymoC_lastz_anchors.json")))["calls"][0]["cigars"][0].split()
+    cigar2 = str(tmp_path / "guide2d.cigar")
+    with open(cigar2, "w") as f:
+        f.write(" ".join(["cigar:", "read2d"] + cig[2:5] + ["ZYMO"] + cig[6:]) + "\n")
+    zymo = "".join(l.strip() for l in open(os.path.join(cases.GOLDEN, "sequences", "zymo_sequence.fasta")) if not l.startswith(">"))
+    t0, t1 = sorted((int(cig[6]), int(cig[7])))
+    z = list(zymo)
+    cs = [i for i in range(t0 + 20, t1 - 20) if z[i] == "C"]
+    for i in cs[::max(1, len(cs) // 15)][:15]:
+        z[i] = "X"
+    fasta2 = str(tmp_path / "zymo_x.fa")
+    _write_fasta(fasta2, "ZYMO", "".join(z))
+    model_c = os.path.join(cases.GOLDEN, "models", "testModelR73_acegot_complement.model")
+    npread2 = os.path.join(cases.GOLDEN, "npReads", "ZymoC_ch_1_file1.npRead")
+    outs2 = {}
+    for name, env in (("device", {}), ("host", {"SA_CLI_VC_ON_HOST": "1"})):
+        out = str(tmp_path / (name + "_2d.tsv"))
+        pr = subprocess.run([BIN, "-T", cases.MODEL_R73, "-C", model_c, "-q", npread2, "-f", fasta2, "-n", "ZYMO", "-p", cigar2, "-u", out,
+                             "-L", "read2d", "--twoD", "-s", "1", "-g", "100"], capture_output=True, text=True, timeout=300,
+                            env=dict(os.environ, **env))
+        assert pr.returncode == 0, pr.stderr
+        outs2[name] = (open(out).read(), pr.stdout)
+    assert outs2["device"] == outs2["host"]
+    strands = {l.split("\t")[4] for l in outs2["device"][0].splitlines()}
+    assert strands == {"t", "c"}, strands
     # the library call
     import signalalign_amd as sa
     from signalalign_amd import synth
