@@ -322,3 +322,29 @@ def test_rebuilt_densities_match_the_ones_the_reference_sampler_stored():
     l1 = np.sum(0.5 * (d[:, 1:] + d[:, :-1]) * np.diff(grid), axis=1)
     assert np.median(l1) < 0.003 and l1.max() < 0.015, (float(np.median(l1)), float(l1.max()))
     assert l1[list(obs).index(i.base_dp)] < 0.001
+
+
+def test_a_transparent_middle_level_changes_nothing():
+    """A check of the middle-level plumbing (middle factors are sampled through joint log-likelihoods, data-point factors through
+    likelihoods: different code) that needs no reference: put a middle process between every leaf and the base process and give that
+    level a concentration parameter of 1e8 -- every table a leaf opens then opens a table of its own in the middle process, which sits at
+    the base process exactly as the leaf's table did without it.  The leaves' densities must agree with the two-level model's up to
+    Monte-Carlo noise (two seeds of the two-level model differ by as much)."""
+    data = np.array(gzip.open(os.path.join(HDP_DATA, "test_hdp_data.txt.gz"), "rt").read().split(), dtype=np.float64)[:1600]
+    leaf = np.arange(1600) % 4
+    grid, nig = (-12.0, 12.0, 121), (0.0, 0.2, 2.0, 4.0)
+
+    def run(parents, depth, gamma, dp_of_leaf, seed):
+        s = sa.HdpState.new_tree(parents, depth, grid, nig, gamma=gamma)
+        s.pass_data(data, np.array([dp_of_leaf[q] for q in leaf], dtype=np.int64))
+        s.gibbs(1500, 30 * len(data), 2 * len(data), seed=seed)
+        s.finalize()
+        post, rows = s.array("post"), s.array("row_of_dp")
+        return np.array([post[rows[dp_of_leaf[q]]] for q in range(4)]), s.array("grid")
+    two, g = run([-1, 0, 0, 0, 0], 2, [3.0, 2.0], {0: 1, 1: 2, 2: 3, 3: 4}, 1)
+    two_b, _ = run([-1, 0, 0, 0, 0], 2, [3.0, 2.0], {0: 1, 1: 2, 2: 3, 3: 4}, 2)
+    three, _ = run([-1, 0, 0, 0, 0, 1, 2, 3, 4], 3, [3.0, 1e8, 2.0], {0: 5, 1: 6, 2: 7, 3: 8}, 3)
+    l1 = lambda a, b: np.sum(0.5 * (np.abs(a - b)[:, 1:] + np.abs(a - b)[:, :-1]) * np.diff(g), axis=1)
+    noise, diff = l1(two, two_b), l1(two, three)
+    print("transparent middle level: L1 two-level seed 1 vs seed 2 %s; two-level vs three-level %s" % (np.round(noise, 4), np.round(diff, 4)))
+    assert noise.max() < 0.005 and diff.max() < 0.006, (noise, diff)   # (measured: 0.0008-0.0011 and 0.0014-0.0017)
