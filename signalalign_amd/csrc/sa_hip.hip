@@ -54,6 +54,7 @@ struct DevModel {
     const double *hdp_coef; // k_emit_hdp: the four cubic coefficients of interval i of every row (twice the size of hdp_tab)
     double hdp_g0, hdp_gN, hdp_dx;
     unsigned hdp_tab_bytes;
+    unsigned hdp_hot;       // byte offset in hdp_tab of the row most k-mers resolve to (0xffffffff: no such row)
     int grid_len;
 };
 
@@ -1271,6 +1272,7 @@ struct sa_batch {
     std::vector<unsigned long long> h_vc_bits;  // (the same on the host, for SA_FLAG_EXACT's host finalisation)
     std::vector<long long> h_vc_off, job_all_n, job_all_sum;
     bool plan_hdp = false;                      // the batch's model holds an HDP (g_pairs_memo's key)
+    unsigned hdp_hot = 0xffffffffu;             // DevModel.hdp_hot
     char *d_seam;            // their seam storage: per wave two arrays of seam_cap records of 16 bytes
     unsigned seam_cap;
     unsigned seam_cap_bwd;   // records per seam array of the backward launches (a traceback segment is shorter than a region)
@@ -1373,6 +1375,7 @@ static DevPlan make_devplan(const sa_batch *b) {
         P.m.hdp_gN = h->grid[h->grid_length - 1];
         P.m.hdp_dx = h->grid[1] - h->grid[0];  // grid_spline_interp: dx = x[1] - x[0]
         P.m.hdp_tab_bytes = (unsigned) (h->n_slots * h->grid_length * 16);
+        P.m.hdp_hot = b->hdp_hot;
     }
     P.threshold = pl->params.threshold;
     P.log_thr = log(pl->params.threshold);
@@ -2198,6 +2201,15 @@ static int batch_prepare_body(sa_batch *b) {
             for (long long i = 0; i < m->n_kmers; i++) {
                 long long r = h->resolved[i];
                 slot[i] = (r >= 0 && h->slot[r] >= 0) ? (int) h->slot[r] : -1;
+            }
+            {   // the row most k-mers resolve to (k_emit_hdp stages it in LDS): worth it from a quarter of the k-mers on
+                std::vector<long long> cnt((size_t) (h->n_slots > 0 ? h->n_slots : 1), 0);
+                for (long long i = 0; i < m->n_kmers; i++)
+                    if (slot[(size_t) i] >= 0) cnt[(size_t) slot[(size_t) i]]++;
+                long long best = 0;
+                for (long long s_ = 1; s_ < h->n_slots; s_++)
+                    if (cnt[(size_t) s_] > cnt[(size_t) best]) best = s_;
+                b->hdp_hot = (h->n_slots > 0 && 4 * cnt[(size_t) best] >= m->n_kmers) ? (unsigned) (best * h->grid_length * 16) : 0xffffffffu;
             }
             TRY(upload(&b->d_hdp_slot, slot.data(), (long long) slot.size()));
             TRY(upload(&b->d_hdp_y, h->y, h->n_slots * h->grid_length));
