@@ -8,6 +8,7 @@
 #include <string.h>
 #include <time.h>
 #include <unistd.h>
+#include <sys/syscall.h>
 static double now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 static int node_cpus(int node, cpu_set_t *set) {
     char path[128], buf[4096];
@@ -65,5 +66,22 @@ int main() {
         hipHostFree(h);
     }
     sched_setaffinity(0, sizeof(old), &old);
+    // ... and with the MEMORY bound to a node (set_mempolicy MPOL_BIND), whatever CPU the thread runs on
+    for (int node = 0; node < 2; node++) {
+        unsigned long mask = 1ul << node;
+        if (syscall(SYS_set_mempolicy, 2 /* MPOL_BIND */, &mask, 64ul) != 0) { printf("set_mempolicy(node %d) failed\n", node); continue; }
+        void *h = nullptr;
+        if (hipHostMalloc(&h, bytes, hipHostMallocDefault) != hipSuccess) { printf("memory on node %d: hipHostMalloc failed\n", node); continue; }
+        syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
+        double best = 0;
+        for (int r = 0; r < 5; r++) {
+            double a = now();
+            hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost);
+            double g = bytes / (now() - a) / 1e9;
+            if (g > best) best = g;
+        }
+        printf("memory bound to node %d: device-to-host best of 5: %.1f GB/s\n", node, best);
+        hipHostFree(h);
+    }
     return 0;
 }
