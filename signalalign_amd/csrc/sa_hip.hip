@@ -2210,6 +2210,7 @@ static int batch_prepare_body(sa_batch *b) {
                 for (long long s_ = 1; s_ < h->n_slots; s_++)
                     if (cnt[(size_t) s_] > cnt[(size_t) best]) best = s_;
                 b->hdp_hot = (h->n_slots > 0 && 4 * cnt[(size_t) best] >= m->n_kmers) ? (unsigned) (best * h->grid_length * 16) : 0xffffffffu;
+                if (getenv("SA_HDP_HOT") && atoi(getenv("SA_HDP_HOT")) == 0) b->hdp_hot = 0xffffffffu;   // test hook: the flavours without a hot row
             }
             TRY(upload(&b->d_hdp_slot, slot.data(), (long long) slot.size()));
             TRY(upload(&b->d_hdp_y, h->y, h->n_slots * h->grid_length));

@@ -785,3 +785,30 @@ def test_eight_byte_result_records(oracle):
     with pytest.raises(sa.SaError) as ei:
         sa.Batch(cm, p, cj, ambig=sa.default_ambig({"X": "CE"}), flags=sa.FLAG_PAIRS8).run()
     assert ei.value.code == -8   # SA_EUNSUPPORTED
+
+
+def test_hdp_emission_kernels_without_a_hot_row(oracle):
+    """k_emit_hdp / k_emit_hdp_ring stage the row most k-mers resolve to in LDS when a model has one (the bundled model: the base
+    process's, 99 % of the k-mers); a model without such a row takes the loops that read every cell's coefficients from memory.
+    SA_HDP_HOT=0 forces those on the bundled model: the same pairs, byte for byte, register, strip and ring regions."""
+    pm, om = _models(oracle, cases.MODEL_R73, cases.NHDP)
+    pm.set_to_hdp_expected_values()
+    p = sa.default_params(threshold=0.05)
+    jobs = cases.hdp_jobs(3, 900, 11, table5=pm.table5())
+    sparse = dict(jobs[1])
+    keep = np.zeros(len(sparse["ax"]), dtype=bool)
+    keep[::37] = True
+    sparse["ax"], sparse["ay"] = sparse["ax"][keep], sparse["ay"][keep]
+    amb = dict(jobs[2])
+    amb["ref"] = amb["ref"].replace("CG", "XG")
+    jobs = jobs + [sparse, amb]
+    ambig = sa.default_ambig({"X": "CE"})
+    got, st = _run(pm, p, jobs, ambig=ambig)
+    assert st.n_fast_regions >= 1 and st.n_ring_regions >= 1
+    os.environ["SA_HDP_HOT"] = "0"
+    try:
+        got2, _ = _run(pm, p, jobs, ambig=ambig)
+    finally:
+        del os.environ["SA_HDP_HOT"]
+    for a, b in zip(got, got2):
+        assert len(a) > 50 and np.array_equal(a, b)
