@@ -377,27 +377,27 @@ def measure(args, ctx, compact=False):
     from signalalign_amd import synth
     dist, rank, world, device, backend = ctx["dist"], ctx["rank"], ctx["world"], ctx["device"], ctx["backend"]
     gold = os.path.join(ROOT, "tests", "golden", "models")
-    model_path, nhdp, ambig, read_kw, wl_name = MODEL, None, None, {}, "BASELINE configs[1]: R9.4 6-mer template Gaussian HMM"
+    model_path, nhdp, ambig, read_kw, wl_name = MODEL, None, None, {}, "BASELINE configs[1]: R9.4 6-mer Gaussian HMM"
     if args.workload == "cpg":
         model_path = os.path.join(gold, "testModelR9.4_450bps.cpg.6mer.template.model")
         ambig, read_kw = sa.default_ambig({"X": "CE"}), {"cpg_ambiguous": True}
         if args.cpg_every > 1:   # sparse variant positions: only every n-th CpG cytosine is ambiguous
             read_kw["cpg_every"] = int(args.cpg_every)
-        wl_name = "BASELINE configs[2]: R9.4 6-mer CpG model (ACEGT), every CpG cytosine ambiguous (C/E)"
+        wl_name = "BASELINE configs[2]: R9.4 6-mer CpG model (ACEGT), every CpG cytosine C/E"
         if args.cpg_every > 1:
             wl_name = ("R9.4 6-mer CpG model (ACEGT), every %d-th CpG cytosine ambiguous (C/E): sparse variant positions "
                        "(not a BASELINE config)" % args.cpg_every)
     elif args.workload == "scaling":
-        wl_name = "BASELINE configs[4], one GPU's slice (100k reads / 8): R9.4 6-mer template Gaussian HMM"
+        wl_name = "BASELINE configs[4], one GPU's slice of 8 (R9.4 6-mer Gaussian HMM)"
     elif args.workload in ("hdp", "hdp_cpg", "hdp_realistic"):
         model_path = os.path.join(gold, "testModelR73_acegot_template.model")
         nhdp = os.path.join(gold, "templateSingleLevelFixed.nhdp")
-        wl_name = "BASELINE configs[3]: HDP emissions (templateSingleLevelFixed.nhdp, R7.3 ACEGOT 6-mer model)"
+        wl_name = "BASELINE configs[3]: HDP emissions (templateSingleLevelFixed.nhdp, R7.3 ACEGOT)"
         if args.workload == "hdp_cpg":     # the reference's methylation-calling workflow: --sm3Hdp with variant positions
             ambig = sa.default_ambig({"X": "CE"})
-            wl_name += ", every CpG cytosine ambiguous (C/E): several paths per cell"
+            wl_name += ", every CpG cytosine C/E"
         if args.workload == "hdp_realistic":
-            wl_name += ", anchors of a real guide alignment (a sixth of the bases)"
+            wl_name += ", anchors of a guide alignment"
     alpha, k, t10, tab = synth.parse_model_table(model_path)
     pm = sa.Model.load(model_path, nhdp)
     if nhdp:
@@ -606,6 +606,21 @@ def measure(args, ctx, compact=False):
     first_buf = np.zeros(len(jobs) + 1, dtype=np.int64)
 
     carry = {}   # one batch at a time: the batch whose first half was made during the previous call's last step
+    step_log = []   # pipelined loop: (step ms, create ms, wait ms) of every step
+    wait_ms = [0.0]
+
+    def step_stats(log):
+        """p10 / p50 / p90 / max of the steps of a run of the pipelined loop and, for the slowest three, which stage stretched"""
+        if len(log) < 5:
+            return None
+        tot = sorted(x[0] for x in log)
+        q = lambda f: tot[min(len(tot) - 1, int(f * len(tot)))]
+        med_c = sorted(x[1] for x in log)[len(log) // 2]
+        med_w = sorted(x[2] for x in log)[len(log) // 2]
+        slow = sorted(log, key=lambda x: -x[0])[:3]
+        return {"p10": round(q(0.1), 3), "p50": round(q(0.5), 3), "p90": round(q(0.9), 3), "max": round(tot[-1], 3),
+                "median_create_ms": round(med_c, 3), "median_wait_ms": round(med_w, 3),
+                "slowest": [{"ms": round(x[0], 2), "create_ms": round(x[1], 2), "wait_ms": round(x[2], 2)} for x in slow]}
 
     def stream(n_steps, first, leave_next=False):
         flying = []
@@ -649,7 +664,9 @@ def measure(args, ctx, compact=False):
         defer = bool(os.environ.get("SA_BENCH_DEFER"))   # (experiment hook)
 
         def retire(old):
+            t_w = time.perf_counter()
             old.wait()
+            wait_ms[0] = (time.perf_counter() - t_w) * 1e3
             if defer:
                 stc = old.stats()
                 cells_done[0] += stc.cells_forward + stc.cells_backward
@@ -672,8 +689,12 @@ def measure(args, ctx, compact=False):
             t_b = time.perf_counter()
             cur.start()
             flying.append(cur)
+            wait_ms[0] = 0.0
             if len(flying) >= depth:
                 retire(flying.pop(0))
+            # per step: whole step, sa_batch_create (host fan-out: checks, packing, upload, device planner), the wait for the oldest
+            # batch in flight; the rest is start + results in place + destroy
+            step_log.append(((time.perf_counter() - t_a) * 1e3, (t_b - t_a) * 1e3, wait_ms[0]))
             if dbg:
                 thr = open("/sys/fs/cgroup/cpu.stat").read().split() if os.path.exists("/sys/fs/cgroup/cpu.stat") else []
                 nthr = thr[thr.index("nr_throttled") + 1] if "nr_throttled" in thr else "?"
@@ -682,6 +703,7 @@ def measure(args, ctx, compact=False):
         for old in flying:
             retire(old)
 
+    steps_timed = None
     if args.kernels_only:
         dt, cells_done[0] = dt_resident * args.steps, cells * args.steps
     else:
@@ -696,10 +718,12 @@ def measure(args, ctx, compact=False):
         cells_done[0] = 0.0
         pairs_seen[0] = 0
         del done_at[:]
+        del step_log[:]
         t0 = time.perf_counter()
         stream(args.steps, priming + args.warmup, leave_next=args.warmup > 0)
         sync()
         dt = time.perf_counter() - t0
+        steps_timed = step_stats(step_log)
         if carry.get("nxt") is not None:
             carry.pop("nxt").close()
     cells_streamed = cells_done[0]
@@ -716,11 +740,13 @@ def measure(args, ctx, compact=False):
             and args.long_steps > args.steps):
         # K = 20 steps are 0.2 s: a longer sample of the same loop beside it (NOT `value`: the contract times exactly K steps)
         cells_done[0] = 0.0
+        del step_log[:]
         tl0 = time.perf_counter()
         stream(args.long_steps, priming + args.warmup + args.steps)
         dtl = time.perf_counter() - tl0
         long_run = {"steps": args.long_steps, "seconds": dtl, "ms_per_step": dtl / args.long_steps * 1e3,
-                    "value": cells_done[0] / dtl, "note": "same pipelined loop as the timed steps, run once more for longer"}
+                    "value": cells_done[0] / dtl, "step_ms": step_stats(step_log),
+                    "note": "same pipelined loop as the timed steps, run once more for longer"}
     if dist is not None:
         import torch
         tdev = "cuda" if backend == "nccl" else "cpu"
@@ -818,8 +844,7 @@ def measure(args, ctx, compact=False):
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%s, %d synthetic %d-event reads per GPU, band=50, threshold %g, traceBackDiagonals 100"
-                            % (wl_name, args.reads, args.events, args.threshold),
+                "workload": "%s, %d x %d-event synthetic reads per GPU, band 50, threshold %g" % (wl_name, args.reads, args.events, args.threshold),
                 "reads_per_gpu": args.reads, "events_per_read": args.events, "event_stride": args.event_stride,
                 "inputs": inputs_used if args.inputs != "auto" else inputs_used + " (auto: host-block when SA_HOST_THREADS <= 3)",
                 "host_threads": os.environ.get("SA_HOST_THREADS"),
@@ -843,7 +868,7 @@ def measure(args, ctx, compact=False):
                             "expand_to_sa_pair_t_ms": unpack_ms,
                             "note": "sa_batch_pairs_all (24-byte sa_pair_t rows, host threads) is NOT inside the timed step; "
                                     "its cost per batch is expand_to_sa_pair_t_ms"},
-                "read_sets_cycled": n_sets, "batches_in_flight": depth, "long_run": long_run,
+                "read_sets_cycled": n_sets, "batches_in_flight": depth, "long_run": long_run, "step_ms": steps_timed,
                 "allocator_priming_batches_before_warmup": (depth + 2 if depth > 1 else 0) if not args.kernels_only else 0,
                 "first_batch_create_s": t_create,
                 "serial_cycle_ms": cycle,
@@ -939,8 +964,11 @@ def scaling_job(args, ctx):
     memo = ctx.setdefault("reads_memo", {})
     sets = []
     t_gen = time.perf_counter()
+    starts = [0]
+    for z in sizes:
+        starts.append(starts[-1] + z)
     for q in range(n_sets):
-        idx = [int(i) for i in mine[q * sl:(q + 1) * sl]]
+        idx = [int(i) for i in mine[starts[q]:starts[q + 1]]]
         key = ("scaling", ev, tuple(idx[:2]), idx[-1] if idx else -1, len(idx))   # (the scaling_slice leg's reads, when they are the same)
         if memo.get("workload") != "scaling":
             memo.clear()
@@ -1040,49 +1068,159 @@ def scaling_job(args, ctx):
 
     # before the job: the caching allocators see the pipeline's working set (a long-running aligner is in that state for good)
     run_slices([0] * (depth + 2 if depth > 1 else 2))
-    sync()
-    cells_done[0] = events_done[0] = 0.0
-    pairs_done[0] = reads_done[0] = 0
-    t0 = time.perf_counter()
-    run_slices(list(range(n_slices)))
-    my_wall = time.perf_counter() - t0
-    sync()
-    dt = time.perf_counter() - t0
-    per_rank = [[float(n_mine), my_wall, cells_done[0]]]
-    cells_all, events_all, pairs_all = cells_done[0], events_done[0], float(pairs_done[0])
+    # The job, R times inside one launch (one 1-second measurement is host jitter as much as anything): every
+    # repetition is bracketed by the barrier on both sides; its wall is the MAX over ranks; a rank's idle time at the closing
+    # barrier is that wall minus its own.  value = the job's cell updates / the MEDIAN repetition's wall; min and max beside it.
+    reps = max(1, int(args.job_reps))
+    rep_rows = []   # per repetition: [wall (max over ranks), per-rank own walls]
+    cells_all = events_all = pairs_all = reads_all = 0.0
+    for rep in range(reps):
+        sync()
+        cells_done[0] = events_done[0] = 0.0
+        pairs_done[0] = reads_done[0] = 0
+        t0 = time.perf_counter()
+        run_slices(list(range(n_slices)))
+        my_wall = time.perf_counter() - t0
+        sync()
+        dt = time.perf_counter() - t0
+        own = [my_wall]
+        cells_all, events_all, pairs_all, reads_all = cells_done[0], events_done[0], float(pairs_done[0]), float(reads_done[0])
+        if dist is not None:
+            import torch
+            tdev = "cuda" if backend == "nccl" else "cpu"
+            t = torch.tensor([dt], dtype=torch.float64, device=tdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            rows = torch.zeros(world, dtype=torch.float64, device=tdev)
+            rows[rank] = my_wall
+            dist.all_reduce(rows, op=dist.ReduceOp.SUM)
+            own = [float(v) for v in rows.cpu().tolist()]
+            tot = torch.tensor([cells_done[0], events_done[0], float(pairs_done[0]), float(reads_done[0])], dtype=torch.float64, device=tdev)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            cells_all, events_all, pairs_all, reads_all = [float(v) for v in tot.cpu().tolist()]
+        rep_rows.append([dt, own])
+    n_mine_all = [float(n_mine)]
     if dist is not None:
         import torch
         tdev = "cuda" if backend == "nccl" else "cpu"
-        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        rows = torch.zeros(world, 3, dtype=torch.float64, device=tdev)
-        rows[rank] = torch.tensor([float(n_mine), my_wall, cells_done[0]], dtype=torch.float64, device=tdev)
+        rows = torch.zeros(world, dtype=torch.float64, device=tdev)
+        rows[rank] = float(n_mine)
         dist.all_reduce(rows, op=dist.ReduceOp.SUM)
-        per_rank = [[float(v) for v in row] for row in rows.cpu().tolist()]
-        tot = torch.tensor([cells_done[0], events_done[0], float(pairs_done[0]), float(reads_done[0])], dtype=torch.float64, device=tdev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        cells_all, events_all, pairs_all, reads_all = [float(v) for v in tot.cpu().tolist()]
-    else:
-        reads_all = float(reads_done[0])
+        n_mine_all = [float(v) for v in rows.cpu().tolist()]
     if rank != 0:
         return None
     assert int(reads_all) == total, (reads_all, total)
+    walls = sorted(r_[0] for r_ in rep_rows)
+    med = walls[len(walls) // 2]
+    med_row = min(rep_rows, key=lambda r_: abs(r_[0] - med))
     return {
-        "workload": "BASELINE configs[4]: %d synthetic %d-event R9.4 reads (6-mer template Gaussian HMM, band 50, threshold 0.01), "
-                    "read-sharded over %d GPU%s, slices of %d reads" % (total, ev, world, "" if world == 1 else "s", sl),
+        "workload": "BASELINE configs[4]: %d x %d-event reads over %d GPU%s, batches of <= %d" % (total, ev, world, "" if world == 1 else "s", sl),
         "scaling": "strong", "n_gpus": world, "total_reads": total, "events_per_read": ev,
-        "value": cells_all / dt, "unit": "cell_updates/s", "wall_s": dt, "events_per_s": events_all / dt, "reads_per_s": reads_all / dt,
-        "pairs": pairs_all, "cell_updates": cells_all,
-        "slice_reads": sl, "slices_rank0": n_slices, "batches_in_flight": depth, "forward_storage_passes_per_slice": int(st0.n_chunks),
+        "value": cells_all / med, "unit": "cell_updates/s", "wall_s": med, "repetitions": reps,
+        "wall_s_min": walls[0], "wall_s_max": walls[-1], "wall_spread": (walls[-1] - walls[0]) / med,
+        "wall_s_all": [r_[0] for r_ in rep_rows],
+        "events_per_s": events_all / med, "reads_per_s": reads_all / med, "pairs": pairs_all, "cell_updates": cells_all,
+        "slice_reads": sizes[0], "slice_sizes_rank0": sorted(set(sizes), reverse=True), "slices_rank0": n_slices,
+        "batches_in_flight": depth, "forward_storage_passes_per_slice": int(st0.n_chunks),
         "read_sets_cycled": n_sets, "reads_generated_per_rank": sum(len(s_) for s_ in sets),
         "inputs": "host-block" if in_block else "pageable", "host_threads_per_rank": os.environ.get("SA_HOST_THREADS"),
-        "per_rank": [{"rank": r_, "reads": int(v[0]), "wall_s": v[1], "value": v[2] / v[1]} for r_, v in enumerate(per_rank)],
-        "partition": "signalalign_amd/shard.py (longest processing time first over the reads' event counts), %.2f s" % t_part,
-        "outside_the_timed_job": "read generation (%.1f s), allocator priming (%d slices), the barrier" % (t_gen, depth + 2 if depth > 1 else 2),
-        "timed": "every rank's slices through sa_batch_create / start / wait / results in place / destroy, barrier on both sides, "
-                 "max over ranks",
+        # of the median repetition: a rank's own wall and what it waited at the closing barrier
+        "per_rank": [{"rank": r_, "reads": int(n_mine_all[r_]), "wall_s": w_, "idle_at_barrier_s": med_row[0] - w_}
+                     for r_, w_ in enumerate(med_row[1])],
+        "partition_s": t_part, "generation_s": t_gen,
+        "timed": "R repetitions of the whole job; each: barrier, every rank's batches through create / start / wait / results in "
+                 "place / destroy, barrier; wall = max over ranks; value from the median repetition",
     }
+
+
+LEG_COLUMNS = ["value", "ms_per_step", "roofline_frac", "frac_by_counters", "cpu_value", "kernels_only_value", "stage_ms",
+               "dominant_kernel"]
+
+
+def _r(x, nd=4):
+    """numbers to nd significant digits (the line must stay inside the driver's 8 KB stdout tail)"""
+    if isinstance(x, float):
+        return float("%.*g" % (nd, x)) if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _r(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+def compact_line(out, full_path):
+    """The ONE line of the contract, short: every BASELINE config with its fractions and CPU figure in `config.legs` (columns:
+    LEG_COLUMNS) right in front of `roofline`, prose cut.  The complete record (every note, per-stage time and sample description)
+    goes to `full_path` when that can be written (profiles/bench_r06_*.json are copies of it)."""
+    c = dict(out.get("config") or {})
+    if full_path:
+        try:
+            os.makedirs(os.path.dirname(full_path), exist_ok=True)
+            with open(full_path, "w") as f:
+                json.dump(out, f)
+        except OSError:
+            full_path = None
+    head = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                     "vs_baseline", "dtype", "data")}
+    cfg = {"workload": str(c.get("workload", ""))[:140]}
+    for k in ("reads_per_gpu", "events_per_read", "batches_in_flight", "events_per_s", "pairs_per_event", "result_record_bytes",
+              "forward_storage_passes", "kernel_ms", "step_ms", "host_threads", "wall_s_whole_run"):
+        if c.get(k) is not None:
+            cfg[k] = c[k]
+    if c.get("inputs"):
+        cfg["inputs"] = str(c["inputs"]).split(" ")[0]
+    if c.get("kernels_only_resident_inputs"):
+        cfg["kernels_only_value"] = c["kernels_only_resident_inputs"]["value"]
+    if c.get("regions_on_register_kernels"):
+        cfg["regions_register_ring_strip"] = [c.get("regions_on_register_kernels"), c.get("regions_on_ring_kernels"),
+                                              c.get("regions_on_strip_kernels")]
+    if c.get("ring_kernels_lane_use") and "busy_lane_fraction" in c["ring_kernels_lane_use"]:
+        cfg["ring_busy_lane_fraction"] = c["ring_kernels_lane_use"]["busy_lane_fraction"]
+    if c.get("long_run"):
+        cfg["long_run"] = {k: c["long_run"].get(k) for k in ("steps", "value", "ms_per_step", "step_ms")}
+    job = c.get("scaling_job")
+    if isinstance(job, dict):
+        if "value" in job:
+            cfg["scaling_job"] = {k: job.get(k) for k in ("value", "n_gpus", "total_reads", "events_per_read", "repetitions", "wall_s",
+                                                          "wall_s_min", "wall_s_max", "wall_spread", "slice_sizes_rank0", "slices_rank0",
+                                                          "batches_in_flight", "over_scaling_slice_value", "per_rank")}
+            cfg["scaling_job"]["scaling"] = "strong"
+        else:
+            cfg["scaling_job"] = job
+    sec = c.get("secondary")
+    if isinstance(sec, dict):
+        legs = {}
+        for name, r in sec.items():
+            if not isinstance(r, dict) or "value" not in r:
+                legs[name] = ("skipped: " + str(r.get("skipped"))[:40]) if isinstance(r, dict) and r.get("skipped") else str(r)[:80]
+                continue
+            legs[name] = [r.get("value"), r.get("ms_per_step"), r.get("roofline_frac"), r.get("roofline_frac_by_counters"),
+                          (r.get("cpu_baseline") or {}).get("value"), r.get("kernels_only_value"), r.get("stage_ms"),
+                          r.get("dominant_kernel")]
+        cfg["legs_columns"] = LEG_COLUMNS
+        cfg["legs"] = legs   # (last key of config: right in front of `roofline`)
+    if full_path:
+        cfg["full_record"] = os.path.relpath(full_path, ROOT)
+    head["config"] = _r(cfg)
+    rf = out.get("roofline") or {}
+    head["roofline"] = _r({k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_by_counters",
+                                                  "traffic_over_algorithmic", "stage_ms", "launches_per_step", "avg_launch_ms",
+                                                  "algorithmic_bytes_per_step", "bound_of_the_formula") if k in rf}, 5)
+    meta = rf.get("counters_collected_at")
+    if isinstance(meta, dict):
+        head["roofline"]["counters_collected_at"] = {k: meta.get(k) for k in ("head", "tag", "collected") if k in meta}
+    elif rf.get("source"):
+        head["roofline"]["source"] = str(rf["source"])[:120]
+    if out.get("issue_roofline"):
+        ir = out["issue_roofline"]
+        head["issue_roofline"] = _r({k: ir.get(k) for k in ("kernel", "frac", "valu_per_step", "instructions_per_step", "wave_wait_frac")})
+    cb = out.get("cpu_baseline")
+    if cb:
+        head["cpu_baseline"] = _r({k: cb.get(k) for k in ("value", "unit", "cores", "kind", "one_thread_value",
+                                                           "single_socket_linear_extrapolation", "socket_model",
+                                                           "physical_cores_per_socket", "cgroup_cpu_quota") if k in cb})
+        head["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+    return json.dumps(head)
 
 
 def main():
@@ -1134,7 +1272,10 @@ def main():
     ap.add_argument("--job-events", type=int, default=10000)
     ap.add_argument("--job-slice", type=int, default=2000, help="reads per batch of the scaling job")
     ap.add_argument("--job-sets", type=int, default=2, help="distinct slice-sized read sets a rank generates and cycles")
+    ap.add_argument("--full-record", default=os.path.join(ROOT, "gpurun_out", "bench_full_record.json"),
+                    help="where the complete record goes (the printed line is its short form); '' = nowhere")
     ap.add_argument("--no-scaling-job", action="store_true", help="skip config.scaling_job")
+    ap.add_argument("--job-reps", type=int, default=5, help="repetitions of the scaling job inside one launch (median, min, max reported)")
     ap.add_argument("--pairs8", action="store_true", help="SA_FLAG_PAIRS8: the batches hold 8-byte result records (x, y, probability) "
                                                           "instead of 16-byte ones -- workloads with one path per cell")
     ap.add_argument("--legs", default=None, help="comma-separated names of the config.secondary legs to run (default: all) -- for "
@@ -1276,7 +1417,7 @@ def main():
         leg("realistic", "realistic", 2000, 5000, 0.01, ks, max(5, args.in_flight + 3))
         leg("cpg", "cpg", 10000, 5000, 0.01, 5, 2)
         if leg("hdp", "hdp", 5000, 5000, 0.1, ks, max(5, args.in_flight + 3)) is not None or (only and any(x_.startswith("hdp_threshold_0.01") for x_ in only)):
-            r3 = leg("hdp_threshold_0.01", "hdp", 5000, 5000, 0.01, 3, 1, cpu=False)
+            r3 = leg("hdp_threshold_0.01", "hdp", 5000, 5000, 0.01, 3, 1, cpu=True)
             args_p8 = args.pairs8
             args.pairs8 = True
             r3b = leg("hdp_threshold_0.01_pairs8", "hdp", 5000, 5000, 0.01, 3, 1, cpu=True)
@@ -1331,7 +1472,7 @@ def main():
                 out["config"]["scaling_job"] = {"failed": "%s: %s" % (type(ex).__name__, ex)}
         out["config"]["wall_s_whole_run"] = time.perf_counter() - t_start
     if out is not None:
-        print(json.dumps(out))
+        print(compact_line(out, args.full_record))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -52,7 +52,9 @@ extern "C" {
                                      pairs whose reference k-mer holds the ambiguity letter 'X'); every other pair is counted and
                                      summed on the device (sa_batch_all_pairs_summary: what the run's pair count and
                                      scoreByPosteriorProbabilityIgnoringGaps need) and never crosses PCIe.  signalMachine -s 1 sets it.
-                                     Not for a batch that feeds sa_batch_mea (the path needs every pair). */
+                                     Not for a batch that feeds sa_batch_mea (the path needs every pair: sa_batch_mea returns SA_ESTATE
+                                     for such a batch) and not together with SA_FLAG_PAIRS8 (SA_EINVAL: an 8-byte record does not
+                                     name the k-mer the filter looks at). */
 #define SA_FLAG_PAIRS8 64u         /* the batch holds its pairs as 8-byte records (sa_pair8_t below) instead of 16-byte ones: half the
                                      bytes over PCIe for results of hundreds of millions of pairs (broad HDP densities at a low
                                      threshold).  Only for batches with ONE path per cell (no ambiguity letters: the pair's k-mer is

@@ -37,10 +37,12 @@ static void usage(void) {   /* the reference's option letters; the wording is th
         "                      6/7  middle nts      fixed / Gamma prior   ACEGOT\n"
         "                      8/9  group multiset  fixed / Gamma prior   ACEGOT\n"
         "                      10   flat, prior, ACEGT      11  multiset, prior, ACEGT\n"
-        "                      12   flat, prior, ACEGIT     13  multiset, prior, ACEGIT\n"
-        "                      14   flat, fixed, alphabet from -b\n"
+        "                      12   multiset, prior, ACEGIT 13  flat, prior, ACEGIT\n"
+        "                      14   flat, fixed, ACGT\n"
+        "                      15-20 flat, fixed: ACFGT, ACGTbp, ACEGTbdehip, ACGTabcdefghijklm, ACGTabcdefghijklmnopq, ACGTabc\n"
+        "                      other flat, fixed, alphabet from -b\n"
         "  -a <k>            k-mer length\n"
-        "  -b <letters>      alphabet of type 14\n"
+        "  -b <letters>      alphabet of a type above 20\n"
         "  -T, -C <file>     template / complement lookup table (signalAlign model format)\n"
         "  -l <file>         assignments (kmer, strand, mean, probability) or a full alignment table\n"
         "  -v, -w <file>     template / complement output\n"
@@ -112,8 +114,15 @@ static sa_hdp_state_t *from_scratch(const opts_t *o, const char *model_file) {
         case 12: layout = SA_HDP_LAYOUT_MULTISET; prior = 1; alphabet = "ACEGIT"; break;   /* multisetPriorEcoli */
         case 13: prior = 1; alphabet = "ACEGIT"; break;                     /* singleLevelPriorEcoli       */
         case 14: alphabet = "ACGT"; break;                                  /* singleLevelFixedCanonical   */
-        default:                                                            /* every other type: a flat model over -b <alphabet> */
-            if (!o->alphabet) die("loadNanoporeHdpFromScratch: this NanoporeHdpType needs an alphabet (-b)");
+        /* the flat, fixed-gamma models whose alphabets the reference hard-codes (inc/stateMachine.h:25-30, impl/nanopore_hdp.c:1160-1240) */
+        case 15: alphabet = "ACFGT"; break;                                 /* singleLevelFixedM6A        METHYL_ADENOSINE_RNA */
+        case 16: alphabet = "ACGTbp"; break;                                /* singleLevelFixedrRNA       M7G_PSI_RRNA         */
+        case 17: alphabet = "ACEGTbdehip"; break;                           /* singleLevelAll16SrRNA      ALL_16SRRNA          */
+        case 18: alphabet = "ACGTabcdefghijklm"; break;                     /* singleLevelYeast           ALL_YEAST            */
+        case 19: alphabet = "ACGTabcdefghijklmnopq"; break;                 /* singleLevelYeastAltC       ALL_YEAST_ALTC       */
+        case 20: alphabet = "ACGTabc"; break;                               /* singleLevelYeastSmall5mer  ALL_YEAST_SMALL_5MER */
+        default:                                                            /* an unspecified type: a flat model over -b <alphabet> (:1403-1412) */
+            if (!o->alphabet) die("loadNanoporeHdpFromScratch: an unspecified NanoporeHdpType needs an alphabet (-b)");
             alphabet = o->alphabet;
             break;
     }

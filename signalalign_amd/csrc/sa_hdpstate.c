@@ -88,7 +88,11 @@ int sa_hdp_state_load(sa_hdp_state_t **out, const char *path) {
          * before seven arrays of that size are allocated */
         double leaves = 1.0;
         for (int64_t i = 0; i < s->kmer_length; i++) leaves *= (double) s->alphabet_size;
-        if ((double) s->num_dps > 3.0 * leaves + 64.0) goto bad;
+        /* (sa_hdp_state_new_tree writes a plain DP tree under the placeholder header "A", k = 1 -- any number of processes:
+         * bounded by what a file of that many lines could hold at all, checked against the arrays below) */
+        const int placeholder = s->alphabet_size == 1 && s->kmer_length == 1;
+        if (!placeholder && (double) s->num_dps > 3.0 * leaves + 64.0) goto bad;
+        if (placeholder && s->num_dps > ((int64_t) 1 << 24)) goto bad;
     }
     if (s->has_data) {
         NEXT(); s->data = parse_f64s(ln, &s->n_data);

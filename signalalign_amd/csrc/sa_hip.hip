@@ -181,13 +181,6 @@ __device__ __forceinline__ bool legal_step(const DevModel &m, int from, int to) 
 // sweeps reduce twice per checkpoint, i.e. twice per ten diagonals: an eighth of k_bwd_fast's instructions.
 // A lane without a source (or outside the row mask) keeps `old` = its own value: max(v, v).
 __device__ __forceinline__ double wave_max(double v) {
-#ifdef SA_WAVE_REDUCE_SHFL   // (A/B build: the former butterfly)
-    for (int off = 32; off > 0; off >>= 1) {
-        double o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
-#endif
     int lo_, hi_;
     double o_;
     // (butterflies: every lane has a source, the move needs no old value -- no copy in front of it)
@@ -217,10 +210,6 @@ __device__ __forceinline__ double wave_max(double v) {
 // ends with its row's sum; a lane outside a broadcast's row mask adds 0.0).  The order of the additions differs from a serial
 // sum's, as the __shfl_xor butterfly's did.
 __device__ __forceinline__ double wave_sum(double v) {
-#ifdef SA_WAVE_REDUCE_SHFL
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-#endif
     int lo_, hi_;
 #define SA_WSUM_BFLY(CTRL)                                                                       \
     lo_ = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, false);                    \
@@ -767,9 +756,7 @@ __device__ __forceinline__ double la_exact_bf(const double *tab, double x, doubl
 // checkpoints), and are transposed through LDS so that every lane then walks its own checkpoint.  Two tiles of 64 x (FOLD_TW + 1)
 // doubles: 9 KB per wave at FOLD_TW 8, seventeen waves per CU (FOLD_TW 4 / 8 / 16 / 32: 0.88 / 0.57 / 0.60 / 1.14 ms on the headline batch, 2.04 / 1.31 / 1.58 / 2.99 on the realistic one) (the 64-term tile of rounds 1-3 took 33 KB: four waves per CU, one
 // chain each -- k_fold 0.84 ms of the headline batch's 9.9 and 2.4 of the realistic batch's 29).
-#ifndef FOLD_TW
 #define FOLD_TW 8
-#endif
 #define FOLD_LD (FOLD_TW + 1)
 __global__ __launch_bounds__(64) void k_fold(DevPlan P, long long ck0, long long ck1) {
     __shared__ double tileA[64 * FOLD_LD], tileB[64 * FOLD_LD];
@@ -1076,9 +1063,7 @@ __global__ __launch_bounds__(64) void k_gather(DevPlan P, int seg0, int n_segs, 
 // writes them.  A survivor's key: diagonals below the start << 40 | column << 12 | path (28 and 12 bits: the planners' limits are
 // 2^28 columns and 255 paths per cell on these kernels); its candidate slot travels beside the key.  keys / idx: 12 bytes of
 // scratch per candidate slot.  The result does not depend on the order the candidates arrived in.
-#ifndef GATHER_H
 #define GATHER_H 1024   // (4 KB of LDS per wave: 8192 entries held a wave to four per CU and cost the realistic batch 0.97 ms)
-#endif
 __global__ __launch_bounds__(64) void k_gather_sorted(DevPlan P, int seg0, int n_segs, const long long *prob_e7, const long long *seg_off,
                                                       sa_pair16_t *out, const double *__restrict__ spec,
                                                       unsigned long long *keys_all, unsigned *idx_all, int p8) {
@@ -1271,7 +1256,7 @@ struct sa_batch {
     long long *d_vc_off = nullptr, *d_seg_all = nullptr;
     std::vector<unsigned long long> h_vc_bits;  // (the same on the host, for SA_FLAG_EXACT's host finalisation)
     std::vector<long long> h_vc_off, job_all_n, job_all_sum;
-    bool plan_hdp = false;                      // the batch's model holds an HDP (g_pairs_memo's key)
+    bool plan_hdp = false;                      // the batch's model holds an HDP
     unsigned hdp_hot = 0xffffffffu;             // DevModel.hdp_hot
     char *d_seam;            // their seam storage: per wave two arrays of seam_cap records of 16 bytes
     unsigned seam_cap;
@@ -1737,25 +1722,30 @@ void sa_batch_destroy(sa_batch_t *b) {
 #include "sa_dplan.inc"
 static void dplan_release_fwd(sa_batch *b, DPlanPending *P) { dplan_release(b, P, true); }
 
-// Pairs per event of the last finished batch with the same threshold and kind of model, process-wide: the estimate the NEXT batch's
-// pinned result block is sized from (a batch whose estimate is short copies its pairs after its kernels instead of beside them:
-// the bundled HDP at threshold 0.01 returns 17.8 pairs per event where the default estimate allows 1.5).
+// Pairs per event of the last finished batch of the same MODEL (its uid: a broad HDP at threshold 0.01 returns 17.8 pairs per event, a
+// narrow model beside it 0.9), device and threshold, process-wide: the estimate the NEXT such batch's pinned result block is sized
+// from (a batch whose estimate is short copies its pairs after its kernels instead of beside them).  Clamped to [1.5, 64] pairs per
+// event; a pinned block that cannot be had at the estimated size is not an error (the run copies after its kernels, as without one).
 struct SaPairsMemo {
     std::mutex mu;
-    double thr[4] = {0, 0, 0, 0}, ratio[4] = {0, 0, 0, 0};
-    int hdp[4] = {0, 0, 0, 0}, next = 0;
-    void note(double threshold, bool is_hdp, double pairs, double events) {
+    struct E { uint64_t uid; int device; double thr, ratio; };
+    E e[8] = {};
+    int next = 0;
+    void note(uint64_t uid, int device, double threshold, double pairs, double events) {
         if (!(events > 0)) return;
         std::lock_guard<std::mutex> g(mu);
-        for (int i = 0; i < 4; i++)
-            if (thr[i] == threshold && hdp[i] == (int) is_hdp) { ratio[i] = pairs / events; return; }
-        thr[next] = threshold; hdp[next] = (int) is_hdp; ratio[next] = pairs / events;
-        next = (next + 1) & 3;
+        for (int i = 0; i < 8; i++)
+            if (e[i].uid == uid && e[i].device == device && e[i].thr == threshold && e[i].ratio > 0) { e[i].ratio = pairs / events > 1e-9 ? pairs / events : 1e-9; return; }
+        e[next] = E{uid, device, threshold, pairs / events > 1e-9 ? pairs / events : 1e-9};
+        next = (next + 1) & 7;
     }
-    double estimate(double threshold, bool is_hdp) {
+    double estimate(uint64_t uid, int device, double threshold) {
         std::lock_guard<std::mutex> g(mu);
-        for (int i = 0; i < 4; i++)
-            if (thr[i] == threshold && hdp[i] == (int) is_hdp && ratio[i] > 0) return ratio[i] * 1.1 > 1.5 ? ratio[i] * 1.1 : 1.5;
+        for (int i = 0; i < 8; i++)
+            if (e[i].uid == uid && e[i].device == device && e[i].thr == threshold && e[i].ratio > 0) {
+                const double r = e[i].ratio * 1.1;
+                return r < 1.5 ? 1.5 : (r > 64.0 ? 64.0 : r);
+            }
         return 1.5;
     }
 };
@@ -2235,13 +2225,6 @@ static int batch_prepare_body(sa_batch *b) {
                     coef[4 * k + 2] = (double) (3.0L * dy - (2.0L * s0 + s1) * dxl);
                     coef[4 * k + 3] = (double) ((s0 + s1) * dxl - 2.0L * dy);
                 }
-#ifdef EMIT_F32TAB   // (probe build: the four coefficients of an interval as floats, 16 B per interval, in the front half of the table)
-            {
-                std::vector<float> tmp((size_t) (h->n_slots * h->grid_length * 4));
-                for (size_t q = 0; q < tmp.size(); q++) tmp[q] = (float) coef[q];
-                memcpy(coef.data(), tmp.data(), tmp.size() * sizeof(float));
-            }
-#endif
             TRY(upload(&b->d_hdp_coef, coef.data(), (long long) coef.size()));
         }
     }
@@ -2407,7 +2390,7 @@ static int batch_finish_body(sa_batch *b) {
     // compute (5000 HDP reads at threshold 0.01, 8-byte records: 87 -> 76 ms per step; the kernels themselves lose 5 ms to the
     // smaller launches).  The estimate is the pairs-per-event of the last finished batch of this kind (g_pairs_memo).
     if (!(flags & SA_FLAG_EXACT) && !b->expect && pl->n_chunks == 1 && pl->n_regions >= 64 && !getenv("SA_F_BUDGET_CELLPATHS")) {
-        const double est_bytes = g_pairs_memo.estimate(pl->params.threshold, b->plan_hdp) * (double) pl->n_ev * (double) b->rec();
+        const double est_bytes = g_pairs_memo.estimate(pl->model->uid, b->device, pl->params.threshold) * (double) pl->n_ev * (double) b->rec();
         if (est_bytes > 2.0e9) {
             long long total = 0, largest = 1;
             for (long long r = 0; r < pl->n_regions; r++) {
@@ -2484,7 +2467,7 @@ static int batch_finish_body(sa_batch *b) {
     // happened to overlap -- sometimes during the caller's warm-up, sometimes in the middle of its timed loop: a 100 ms
     // hipHostMalloc that also held up every other thread's HIP calls (12.5 against 16-19 ms per step, run to run).
     if (!(flags & SA_FLAG_EXACT) && !b->expect && b->h_pairs_cap == 0 && pl->params.threshold >= 0.005) {
-        const long long total = (long long) (g_pairs_memo.estimate(pl->params.threshold, m->hdp != nullptr) * (double) pl->n_ev) + 4096;
+        const long long total = (long long) (g_pairs_memo.estimate(m->uid, device, pl->params.threshold) * (double) pl->n_ev) + 4096;
         const long long cap = total + total / 8 + 1024;
         if (g_sa_pool.get(SaPool::PINNED, (void **) &b->h_pairs, b->rec() * (size_t) cap, device) == hipSuccess) b->h_pairs_cap = cap;
         else { (void) hipGetLastError(); b->h_pairs = nullptr; }   // (the run asks again)
@@ -2838,8 +2821,12 @@ static int batch_run_body(sa_batch_t *b) {
     // of a batch overlap its copies with the kernels; with the caching allocator the buffer is a reused block.  If the
     // estimate is short the run falls back to copying afterwards, as before.
     if (!(b->flags & SA_FLAG_EXACT) && b->h_pairs_cap == 0 && pl->params.threshold >= 0.005) {
-        int rce = reserve_pairs((long long) (g_pairs_memo.estimate(pl->params.threshold, b->plan_hdp) * (double) pl->n_ev) + 4096);
-        if (rce) return rce;
+        // (an estimate: when the pinned block cannot be had at that size the run copies after its kernels, exactly as with no estimate)
+        if (reserve_pairs((long long) (g_pairs_memo.estimate(pl->model->uid, b->device, pl->params.threshold) * (double) pl->n_ev) + 4096) != SA_OK) {
+            (void) hipGetLastError();
+            b->h_pairs = nullptr;
+            b->h_pairs_cap = 0;
+        }
     }
     if (b->flags & SA_FLAG_EXACT) {
         int rcp0 = run_passes(b);
@@ -3024,7 +3011,7 @@ static int batch_run_body(sa_batch_t *b) {
             b->job_all_sum[(size_t) j] += sa_[(size_t) (2 * sg + 1)];
         }
     }
-    g_pairs_memo.note(pl->params.threshold, b->plan_hdp, (double) b->n_pairs_total, (double) pl->n_ev);
+    g_pairs_memo.note(pl->model->uid, b->device, pl->params.threshold, (double) b->n_pairs_total, (double) pl->n_ev);
     b->ran = true;
     return SA_OK;
 }
@@ -3034,7 +3021,9 @@ static int batch_run_body(sa_batch_t *b) {
 int sa_batch_device_view(sa_batch_t *b, const sa_pair16_t **pairs, std::vector<long long> *first, std::vector<long long> *count,
                          std::vector<long long> *n_events, int *device) {
     if (!b || !pairs || !first || !count || !n_events || !device) return SA_EINVAL;
-    if (!b->ran || b->p8) return SA_ESTATE;   // (8-byte records name neither path nor k-mer: nothing a downstream device step reads)
+    // (8-byte records name neither path nor k-mer, and a batch filtered for the variant-caller output holds only the rows of X positions:
+    // nothing a downstream device step -- the MEA path over ALL posteriors -- may read)
+    if (!b->ran || b->p8 || (b->flags & SA_FLAG_VC_ROWS)) return SA_ESTATE;
     const sa_plan_t *pl = b->plan;
     const size_t nj = (size_t) pl->n_jobs;
     first->assign(nj, 0); count->assign(nj, 0); n_events->assign(nj, 0);
@@ -3107,7 +3096,7 @@ int sa_batch_release_device(sa_batch_t *b) {
 
 int sa_batch_start(sa_batch_t *b) {
     if (!b) return SA_EINVAL;
-    if (b->runner) return SA_ESTATE;
+    if (b->runner || b->released) return SA_ESTATE;   // (sa_batch_release_device: nothing left to run on)
     b->runner_rc = SA_OK;
     g_batches_started.fetch_add(1);
     b->runner = new (std::nothrow) std::thread([b]() { b->runner_rc = sa_batch_run(b); });

@@ -22,13 +22,17 @@ def shard_indices(costs, rank, world):
 
 
 def slice_sizes(n_reads, slice_reads):
-    """A rank's share of a job cut into batches of `slice_reads` reads (the last one may be shorter)."""
+    """A rank's share of a job cut into batches of AT MOST `slice_reads` reads, all of the same size to within one read
+    (12 500 reads in slices of 2000: seven slices of 1786 / 1785, not six of 2000 and one of 500 -- a short last batch runs at the
+    rate of a small launch and a rank's wall time is the sum over its batches)."""
     n_reads, slice_reads = int(n_reads), int(slice_reads)
     if n_reads <= 0:
         return []
     if slice_reads <= 0:
         raise ValueError("slice_reads must be positive")
-    return [min(slice_reads, n_reads - q * slice_reads) for q in range((n_reads + slice_reads - 1) // slice_reads)]
+    k = (n_reads + slice_reads - 1) // slice_reads
+    base, extra = divmod(n_reads, k)
+    return [base + 1] * extra + [base] * (k - extra)
 
 
 def merge_in_read_order(per_rank_indices, per_rank_results):

@@ -237,7 +237,14 @@ def test_variant_caller_rows_are_filtered_on_the_device(oracle, tmp_path):
             assert np.array_equal(a[has_x], b), (flags, j)
             assert vc.all_pairs_summary(j) == (len(a), int(a["prob_e7"].sum())) == full.all_pairs_summary(j)
         assert len(vc.pairs(len(jobs) - 1)) == 0 and vc.n_pairs(0) > 0
+        if flags == 0:   # a filtered batch holds the X rows only: the MEA path over all posteriors is refused, not computed on them
+            with pytest.raises(sa.SaError) as ei:
+                vc.mea()
+            assert ei.value.code == -7
         full.close(); vc.close()
+    with pytest.raises(sa.SaError) as ei:       # 8-byte records do not name the k-mer the filter looks at
+        sa.Batch(pm, p, jobs, ambig=ambig, flags=sa.FLAG_VC_ROWS | sa.FLAG_PAIRS8)
+    assert ei.value.code == -1
 
 
 def test_signalmachine_ambig_model_file(oracle, tmp_path):

@@ -348,3 +348,31 @@ def test_a_transparent_middle_level_changes_nothing():
     noise, diff = l1(two, two_b), l1(two, three)
     print("transparent middle level: L1 two-level seed 1 vs seed 2 %s; two-level vs three-level %s" % (np.round(noise, 4), np.round(diff, 4)))
     assert noise.max() < 0.005 and diff.max() < 0.006, (noise, diff)   # (measured: 0.0008-0.0011 and 0.0014-0.0017)
+
+
+def test_build_hdp_util_hard_coded_alphabets(tmp_path):
+    """NanoporeHdpType 15-20: flat, fixed-gamma models whose alphabets the reference hard-codes (impl/nanopore_hdp.c:1160-1240,
+    inc/stateMachine.h:25-30) -- trainModels.py composes `-p <type>` for them without -b; -b counts for unspecified types only."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "signalalign_amd", "bin", "buildHdpUtil")
+    asg = str(tmp_path / "assignments.tsv")
+    rows = gzip.open(os.path.join(HDP_DATA, "d6160b0b-a35e-43b5-947f-adaa1abade28.sm.assignments.tsv.gz"), "rt").read().splitlines()[:1500]
+    open(asg, "w").write("\n".join(rows) + "\n")
+
+    def run(ptype, extra=()):
+        out = str(tmp_path / ("t%s.nhdp" % ptype))
+        cmd = [tool, "-p", str(ptype), "-v", out, "-l", asg, "-a", "6", "-n", "10", "-I", "100", "-t", "5", "-s", "40", "-e", "140",
+               "-k", "100", "--oneD", "-T", cases.MODEL_6MER, "-B", "1", "-L", "1"] + list(extra)
+        pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        head = open(out).read(64).split("\n")[:3] if pr.returncode == 0 and os.path.exists(out) else None
+        return pr, head
+    for ptype, alphabet in ((15, "ACFGT"), (16, "ACGTbp"), (20, "ACGTabc")):
+        pr, head = run(ptype)
+        assert pr.returncode == 0, pr.stderr[-1000:]
+        assert head == [str(len(alphabet)), alphabet, "6"], (ptype, head)
+    pr, head = run(15, ("-b", "ACGT"))           # a known type keeps its own alphabet
+    assert pr.returncode == 0 and head[1] == "ACFGT"
+    pr, head = run(33)                           # an unspecified type has none
+    assert pr.returncode != 0 and "alphabet" in pr.stderr
+    pr, head = run(33, ("-b", "ACGT"))
+    assert pr.returncode == 0 and head == ["4", "ACGT", "6"]

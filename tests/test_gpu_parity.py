@@ -737,6 +737,9 @@ def test_released_batches_keep_their_results_and_a_nan_event_is_reported(oracle,
     with pytest.raises(sa.SaError) as ei:
         b.run()
     assert ei.value.code == -7
+    with pytest.raises(sa.SaError) as ei:       # ... and sa_batch_start says so itself (not a thread that fails at sa_batch_wait)
+        b.start()
+    assert ei.value.code == -7
     mea_after = b.mea()
     for x, y in zip(mea_before, mea_after):
         assert np.array_equal(x[0], y[0]) and x[1] == y[1] and x[2] == y[2]

@@ -177,3 +177,17 @@ def test_assignment_tables_of_the_reference(tmp_path):
     kmers, events = sa.Hmm.load(p, sa.HMM_HDP).assignments()
     flat.pass_assignments(kmers, events)
     assert flat.info.n_data == 50 and np.allclose(flat.array("data"), [float(r[13]) for r in rows[:50]], atol=5e-7)
+
+
+def test_a_plain_tree_of_more_than_67_processes_round_trips(tmp_path):
+    # sa_hdp_state_new_tree writes its state under a placeholder header (alphabet "A", k = 1): the loader's bound on the number of
+    # processes (3 A^k + 64 for a NanoporeHDP) must not apply to it
+    parents = [-1] + [0] * 9 + [1 + (i % 9) for i in range(190)]
+    s = sa.HdpState.new_tree(parents, 3, (-10.0, 10.0, 50), NIG, gamma=[1, 1, 1])
+    assert s.info.num_dps == 200
+    a, b = str(tmp_path / "tree.hdp"), str(tmp_path / "tree2.hdp")
+    s.write(a)
+    t = sa.HdpState(a)
+    assert t.info.num_dps == 200 and t.array("dp_parent").tolist() == parents
+    t.write(b)
+    assert open(a).read() == open(b).read()

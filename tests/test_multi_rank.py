@@ -34,8 +34,11 @@ def test_the_scaling_job_is_dealt_completely_and_evenly():
         assert sum(len(p) for p in parts) == total and len(set(len(p) for p in parts)) == 1
         assert np.array_equal(np.sort(np.concatenate(parts)), np.arange(total))
         sizes = shard.slice_sizes(len(parts[0]), sl)
-        assert sum(sizes) == total // world and max(sizes) == sl and all(s_ > 0 for s_ in sizes)
-    assert shard.slice_sizes(12500, 2000) == [2000] * 6 + [500] and shard.slice_sizes(0, 5) == [] and shard.slice_sizes(3, 5) == [3]
+        assert sum(sizes) == total // world and max(sizes) <= sl and max(sizes) - min(sizes) <= 1
+        assert len(sizes) == -(-(total // world) // sl)   # no more batches than slices of `sl` reads would be
+    # equal slices (round 6): a rank's last batch is as large as its others
+    assert shard.slice_sizes(12500, 2000) == [1786] * 5 + [1785] * 2 and shard.slice_sizes(0, 5) == [] and shard.slice_sizes(3, 5) == [3]
+    assert shard.slice_sizes(100000, 2000) == [2000] * 50 and shard.slice_sizes(7, 2) == [2, 2, 2, 1]
 
 
 def test_two_rank_gloo_run():
