@@ -329,6 +329,39 @@ def bench_expectations(args, compact=False):
     return res
 
 
+def dense_nhdp():
+    """--workload hdp_dense: an .nhdp with a row of its own for most k-mers, built here by this repository's buildHdpUtil (a child
+    process) from the bundled assignments of an R9.4 read (tests/golden/hdp/d6160b0b-...: 17 350 template rows): flat ACGT 6-mer model,
+    3183 observed processes x 400 grid points -- no row that most k-mers share (the bundled templateSingleLevelFixed.nhdp has 352
+    observed processes of 46 657; the reference's own comment puts a real HDP at 200 MB, tests/stateMachineTests.c:904, and
+    dir_proc_density walks to the parent only for unobserved processes, impl/hdp.c:2588-2612).  Returns (nhdp path, path of a file
+    holding the random ACGT sequence the reads' references are cut from); built once per box."""
+    import gzip
+    import subprocess
+    import tempfile
+    d = os.path.join(os.environ.get("SA_SYNTH_CACHE") or tempfile.gettempdir(), "sa_hdp_dense")
+    os.makedirs(d, exist_ok=True)
+    path, pool = os.path.join(d, "dense_flat_acgt_6mer.nhdp"), os.path.join(d, "dense_ref_pool.txt")
+    if not (os.path.exists(path) and os.path.exists(pool)):
+        asg = os.path.join(d, "assignments.tsv")
+        src = os.path.join(ROOT, "tests", "golden", "hdp", "d6160b0b-a35e-43b5-947f-adaa1abade28.sm.assignments.tsv.gz")
+        with open(asg, "w") as f:
+            f.write(gzip.open(src, "rt").read())
+        tool = os.path.join(ROOT, "signalalign_amd", "bin", "buildHdpUtil")
+        tmp = path + ".tmp%d" % os.getpid()
+        cmd = [tool, "-p", "14", "-v", tmp, "-l", asg, "-a", "6", "-n", "200", "-I", "20000", "-t", "100", "-s", "40", "-e", "140", "-k", "400",
+               "--oneD", "-T", MODEL, "-B", "1", "-L", "1", "--seed", "7"]
+        pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        if pr.returncode != 0:
+            raise RuntimeError("buildHdpUtil failed: " + pr.stderr[-400:])
+        os.replace(tmp, path)
+        rng = np.random.Generator(np.random.PCG64(0x44454e5345))
+        with open(pool + ".tmp", "w") as f:
+            f.write("".join("ACGT"[i] for i in rng.integers(0, 4, size=200000)) + "\n")
+        os.replace(pool + ".tmp", pool)
+    return path, pool
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start N ranks, one per GPU, as children of this process --
     which itself never touches the GPU (no HIP call, no torch.cuda call before or after) -- through
@@ -389,6 +422,9 @@ def measure(args, ctx, compact=False):
                        "(not a BASELINE config)" % args.cpg_every)
     elif args.workload == "scaling":
         wl_name = "BASELINE configs[4], one GPU's slice of 8 (R9.4 6-mer Gaussian HMM)"
+    elif args.workload == "hdp_dense":
+        nhdp, dense_pool = dense_nhdp()
+        wl_name = "HDP emissions, dense .nhdp built by buildHdpUtil from the bundled assignments (3183 observed processes x 400 grid points)"
     elif args.workload in ("hdp", "hdp_cpg", "hdp_realistic"):
         model_path = os.path.join(gold, "testModelR73_acegot_template.model")
         nhdp = os.path.join(gold, "templateSingleLevelFixed.nhdp")
@@ -408,7 +444,7 @@ def measure(args, ctx, compact=False):
         # events drawn from the densities the aligner itself uses, over windows of the sequence the bundled .nhdp was trained
         # on (synth.make_read_hdp); the table's level means (after set_to_hdp_expected_values) enter the event normalisation
         spec = dict(kind="hdp", model=model_path, nhdp=nhdp, events=args.events, table5=np.array(pm.table5()),
-                    ref_pool=os.path.join(ROOT, "tests", "golden", "npReads", "ZymoRef.txt"))
+                    ref_pool=dense_pool if args.workload == "hdp_dense" else os.path.join(ROOT, "tests", "golden", "npReads", "ZymoRef.txt"))
     # spawned numpy-only workers; identical to the serial loop (several ranks on one host share its CPUs: fewer workers each)
     gen_workers = None if world == 1 else max(1, min(4, int(os.environ.get("SA_HOST_THREADS", "2"))))
     def mark_cpg(job_list):   # hdp_cpg: the C of every CG becomes X (the reads' references come from a pool of real sequence)
@@ -925,7 +961,7 @@ def measure(args, ctx, compact=False):
                 return js_
             out["cpu_baseline"] = cpu_baseline(om, op_, make_sample, args.events, args.cpu_reads_per_thread, 10 ** 6,
                                                ambig=oracle.ambig_map({"X": "CE"}) if args.workload in ("cpg", "hdp_cpg") else None,
-                                               what={"cpg": ", every CpG cytosine C/E", "hdp": ", HDP emissions",
+                                               what={"cpg": ", every CpG cytosine C/E", "hdp": ", HDP emissions", "hdp_dense": ", HDP emissions (dense .nhdp)",
                                                      "hdp_cpg": ", HDP emissions, every CpG cytosine C/E",
                                                      "hdp_realistic": ", HDP emissions, anchors of a guide alignment",
                                                      "realistic": ", anchors of a guide alignment"}.get(args.workload, ""))
@@ -1237,7 +1273,7 @@ def main():
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU (default: 2000 = BASELINE configs[1]; "
                                                              "scaling: 12500 = configs[4]'s 100k reads / 8 GPUs)")
     ap.add_argument("--events", type=int, default=None, help="events per read (default 5000; scaling: 10000)")
-    ap.add_argument("--workload", choices=["gaussian", "scaling", "scaling_job", "cpg", "hdp", "hdp_cpg", "hdp_realistic", "realistic", "event_align",
+    ap.add_argument("--workload", choices=["gaussian", "scaling", "scaling_job", "cpg", "hdp", "hdp_cpg", "hdp_realistic", "hdp_dense", "realistic", "event_align",
                                            "mea", "expectations", "expectations_cpg"],
                     default="gaussian",
                     help="gaussian = BASELINE configs[1] (the headline); scaling = configs[4]'s per-GPU slice (12500 "
@@ -1286,7 +1322,7 @@ def main():
     args = ap.parse_args()
     if args.reads is None:
         # the sizes BASELINE.json names: configs[2] (cpg) 10 000 reads, configs[3] (hdp) 5000, configs[4]'s slice 12 500
-        args.reads = {"scaling": 12500, "hdp": 5000, "hdp_cpg": 2000, "hdp_realistic": 2000, "cpg": 10000}.get(args.workload, 2000)
+        args.reads = {"scaling": 12500, "hdp": 5000, "hdp_dense": 5000, "hdp_cpg": 2000, "hdp_realistic": 2000, "cpg": 10000}.get(args.workload, 2000)
     if args.events is None:
         args.events = 10000 if args.workload == "scaling" else 5000
     if args.threshold is None:
@@ -1428,6 +1464,7 @@ def main():
             if r3 is not None:
                 sec["hdp_threshold_0.01"]["note"] = ("the bundled .nhdp is flat (every process: mean 59.8, sd 15.5 pA): 17.8 pairs "
                                                      "per event at 0.01, the step is their PCIe transfer")
+        leg("hdp_dense", "hdp_dense", 5000, 5000, 0.1, ks, max(5, args.in_flight + 3))
         if only is not None and "expectations" not in only:
             sec["expectations"] = {"skipped": "--legs"}
         elif time.perf_counter() - t_start <= args.secondary_budget_s:

@@ -674,7 +674,19 @@ typedef struct {
                                  * from the batch's packed records (sa_batch_pairs16) by the thread that renders the job */
     int64_t *const *all_n;      /* [strand][job], -s 1 only (SA_FLAG_VC_ROWS): number and prob_e7 sum of ALL pairs of the job -- the */
     int64_t *const *all_sum;    /* rows the variant-caller output does not print were dropped on the device                        */
+    const int *p8;              /* [strand]: the batch holds 8-byte records (SA_FLAG_PAIRS8): path 0, the reference's k-mer at x          */
 } out_job_t;
+
+/* kmer_id of the k letters at s (sorted alphabet, first letter most significant), -1 for a letter outside it */
+static int32_t kmer_id_of(const strand_model_t *sm, const char *s) {
+    int32_t id = 0;
+    for (int i = 0; i < sm->k; i++) {
+        const char *q = memchr(sm->alphabet, s[i], (size_t) sm->n_alpha);
+        if (!q || !s[i]) return -1;
+        id = id * sm->n_alpha + (int32_t) (q - sm->alphabet);
+    }
+    return id;
+}
 
 /* The rows of the full output that lie on the maximum-expected-accuracy path -- what mea_alignment_from_signal_align
  * (src/signalalign/mea_algorithm.py:323-341) returns as its final event table, here as a TSV next to the posteriors file.
@@ -724,7 +736,28 @@ static void output_one(int64_t j, void *ctx) {
     const sa_pair_t *pp[2] = {NULL, NULL};
     for (int s = 0; s < n_strands; s++) {
         pp[s] = c->pairs[s][j];
-        if (pp[s] == NULL && c->batch && c->batch[s]) {
+        if (pp[s] == NULL && c->batch && c->batch[s] && c->p8 && c->p8[s]) {
+            /* 8-byte records (round 6: -s 0 / 2 on reads without ambiguity letters -- half the bytes over PCIe where the pairs outweigh
+             * the kernels, e.g. --sm3Hdp -D 0.01): x, y, probability; the pair's k-mer is the reference's at x, its path 0 */
+            const sa_pair8_t *pk8 = NULL;
+            int64_t n = 0;
+            const strand_model_t *sm = s == 0 ? &R->smt : &R->smc;
+            const char *target = s == 0 ? rd->template_target : rd->complement_target;
+            if (sa_batch_pairs8(c->batch[s], j, &pk8, &n) != SA_OK || n != c->n_pairs[s][j]) {
+                fprintf(stderr, "[signalMachine] ERROR: read %s: results of the batch are not readable\n", rd->label);
+                rd->failed = 1;
+                free(mine[0]);
+                return;
+            }
+            mine[s] = malloc(sizeof(sa_pair_t) * (size_t) (n > 0 ? n : 1));
+            for (int64_t i = 0; i < n; i++) {
+                sa_pair_t *q = &mine[s][i];
+                sa_pair8_unpack(pk8[i], &q->prob_e7, &q->x, &q->y);
+                q->path = 0;
+                q->kmer_id = kmer_id_of(sm, target + q->x);
+            }
+            pp[s] = mine[s];
+        } else if (pp[s] == NULL && c->batch && c->batch[s]) {
             const sa_pair16_t *pk = NULL;
             int64_t n = 0;
             if (sa_batch_pairs16(c->batch[s], j, &pk, &n) != SA_OK || n != c->n_pairs[s][j]) {
@@ -813,6 +846,7 @@ typedef struct {
     int64_t *n_mea_s[2];
     sa_batch_t *batch[2];  /* alive until the slice is rendered (their packed records are what the rendering reads) */
     int64_t *all_n_s[2], *all_sum_s[2];   /* -s 1: see out_job_t */
+    int p8_s[2];          /* see out_job_t */
     int64_t n_failed;     /* out */
 } render_job_t;
 static void *render_slice(void *arg);
@@ -887,6 +921,11 @@ static render_job_t *run_slice(run_t *Rp, read_t *reads, int64_t n_reads, int ba
     /* -s 1 prints only the rows whose reference k-mer holds an X: the others stay on the device (SA_FLAG_VC_ROWS), the run's pair
      * count and score come from the totals the device kept */
     const unsigned vc_flag = (R.out_fmt == 1 && !R.mea && !getenv("SA_CLI_EXPAND_EARLY") && !getenv("SA_CLI_VC_ON_HOST")) ? SA_FLAG_VC_ROWS : 0u;
+    /* -s 0 / -s 2 without --mea: 8-byte result records where the batch allows them (one path per cell: no ambiguity letter in any
+     * read's reference; fewer than 2^20 positions and events per read) -- the planner says SA_EUNSUPPORTED otherwise and the strand's
+     * batch is made again with 16-byte records.  SA_CLI_PAIRS16=1: always 16-byte records (the test's checker). */
+    const unsigned p8_want = ((R.out_fmt == 0 || R.out_fmt == 2) && !R.mea && !getenv("SA_CLI_EXPAND_EARLY") && !getenv("SA_CLI_PAIRS16")) ? SA_FLAG_PAIRS8 : 0u;
+    int p8_used[2] = {0, 0};
     for (int s = 0; s < n_strands; s++) {
         pairs[s] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(sa_pair_t *));
         n_pairs[s] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(int64_t));
@@ -899,7 +938,10 @@ static render_job_t *run_slice(run_t *Rp, read_t *reads, int64_t n_reads, int ba
                                 n_pairs[s]);
         } else if (!R.mea) {   /* the batch stays alive for the rendering, which expands its packed records job by job */
             sa_batch_t *b = NULL;
-            rc = sa_batch_create(&b, R.two_dist ? reads[who[0]].model[s] : sms[s]->model, &R.p, bj, n_ok, R.ambig, device, vc_flag);
+            rc = sa_batch_create(&b, R.two_dist ? reads[who[0]].model[s] : sms[s]->model, &R.p, bj, n_ok, R.ambig, device, vc_flag | p8_want);
+            p8_used[s] = rc == SA_OK && p8_want != 0;
+            if (rc == SA_EUNSUPPORTED && p8_want)
+                rc = sa_batch_create(&b, R.two_dist ? reads[who[0]].model[s] : sms[s]->model, &R.p, bj, n_ok, R.ambig, device, vc_flag);
             if (rc == SA_OK) rc = sa_batch_run(b);
             for (int64_t j = 0; j < n_ok && rc == SA_OK; j++) rc = sa_batch_n_pairs(b, j, &n_pairs[s][j]);
             if (vc_flag && rc == SA_OK) {
@@ -962,7 +1004,7 @@ static render_job_t *run_slice(run_t *Rp, read_t *reads, int64_t n_reads, int ba
     g_t_gpu += now_s() - ts1;
     render_job_t *job = calloc(1, sizeof(*job));
     job->Rp = Rp; job->reads = reads; job->n_reads = n_reads; job->n_ok = n_ok; job->who = who; job->bj = bj;
-    for (int s = 0; s < 2; s++) { job->pairs_s[s] = pairs[s]; job->n_pairs_s[s] = n_pairs[s]; job->mea_s[s] = mea[s]; job->n_mea_s[s] = n_mea[s]; job->batch[s] = batches[s]; job->all_n_s[s] = all_n[s]; job->all_sum_s[s] = all_sum[s]; }
+    for (int s = 0; s < 2; s++) { job->pairs_s[s] = pairs[s]; job->n_pairs_s[s] = n_pairs[s]; job->mea_s[s] = mea[s]; job->n_mea_s[s] = n_mea[s]; job->batch[s] = batches[s]; job->all_n_s[s] = all_n[s]; job->all_sum_s[s] = all_sum[s]; job->p8_s[s] = p8_used[s]; }
     return job;
 #undef R
 }
@@ -984,7 +1026,7 @@ static void *render_slice(void *arg) {
     const double ts2 = now_s();
     double (*score)[2] = calloc((size_t) (n_ok > 0 ? n_ok : 1), sizeof(*score));
     {
-        out_job_t oc = {&R, reads, who, pairs, n_pairs, score, mea, n_mea, job->batch, job->all_n_s, job->all_sum_s};
+        out_job_t oc = {&R, reads, who, pairs, n_pairs, score, mea, n_mea, job->batch, job->all_n_s, job->all_sum_s, job->p8_s};
         if (outputs_distinct(reads, who, n_ok)) parallel_for(n_ok, output_one, &oc);
         else for (int64_t j = 0; j < n_ok; j++) output_one(j, &oc);
     }

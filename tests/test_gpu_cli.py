@@ -106,6 +106,12 @@ def test_signalmachine_full_tsv(oracle, tmp_path, npread, model):
     assert head[0] == "read1 %d" % n_anchors
     assert head[1].startswith("%d(" % n_pairs)
     assert abs(float(head[1][head[1].index("(") + 1:-1]) - score) < 1e-3
+    # round 6: -s 0 on a reference without ambiguity letters comes over PCIe as 8-byte records (SA_FLAG_PAIRS8: the k-mer of a pair is
+    # the reference's at x); with 16-byte records (SA_CLI_PAIRS16=1) the file is the same, byte for byte
+    out16 = str(tmp_path / "out16.tsv")
+    argv16 = [out16 if a == out else a for a in argv]
+    pr16 = subprocess.run(argv16, capture_output=True, text=True, timeout=300, env=dict(os.environ, SA_CLI_PAIRS16="1"))
+    assert pr16.returncode == 0 and open(out16, "rb").read() == open(out, "rb").read() and pr16.stdout == pr.stdout
     # appending, not truncating (fopen "a")
     pr = subprocess.run(argv, capture_output=True, text=True, timeout=300)
     assert pr.returncode == 0 and len(open(out).readlines()) == 2 * len(rows)
@@ -805,6 +811,15 @@ def test_signalmachine_hdp_model(oracle, tmp_path):
                          "-L", "rh", "-g", "100", "-D", "0.05"], capture_output=True, text=True, timeout=300)
     assert pr.returncode == 0, pr.stderr
     assert "Using threeStateHdp stateMachine since you pass in an HDP file" in pr.stderr
+    # the HDP path at the caller's default threshold is where the pairs outweigh the kernels (17.8 pairs per event on the bundled
+    # model): full and assignments output on 8-byte records (the default) and on 16-byte records give the same bytes
+    for fmt in ("0", "2"):
+        a8, a16 = str(tmp_path / ("p8_%s.tsv" % fmt)), str(tmp_path / ("p16_%s.tsv" % fmt))
+        for path, env in ((a8, dict(os.environ)), (a16, dict(os.environ, SA_CLI_PAIRS16="1"))):
+            q = subprocess.run([BIN, "-T", model, "-v", nhdp, "-q", npread_path, "-f", fasta, "-n", "chrH", "-p", cigar, "-u", path,
+                                "-L", "rh", "-g", "100", "-D", "0.01", "-s", fmt], capture_output=True, text=True, timeout=300, env=env)
+            assert q.returncode == 0, q.stderr
+        assert open(a8, "rb").read() == open(a16, "rb").read() and len(open(a8).readlines()) > 1000
     om = oracle.Model.from_file(model)
     ev = r["template_events"].copy()
     pr_ = oracle.estimate_params(om, r["template_strand_event_map"], ev, read)  # before the HDP means are installed

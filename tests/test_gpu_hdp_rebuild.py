@@ -265,6 +265,21 @@ def test_rebuilt_hdp_aligns(tmp_path):
         h_ = {(int(q["x"]), int(q["y"])) for q in bh.pairs(j)}
         g_ = {(int(q["x"]), int(q["y"])) for q in bg.pairs(j)}
         assert len(h_) > 600 and len(h_ & g_) >= 0.5 * len(g_), (j, len(h_), len(g_), len(h_ & g_))
+    # ... and the HIP path agrees with the CPU restatement on this DENSE model (3183 observed processes x 400 grid points: most k-mers
+    # read a row of their own, none is shared by a quarter of them -- bench.py --workload hdp_dense is this model): 1e-5 on a posterior
+    from oracle import sa_oracle_py as oracle
+    alpha, k, t10, tab = synth.parse_model_table(cases.MODEL_6MER)
+    om = oracle.Model(alpha, k, t10, tab)
+    om.load_hdp(out)
+    om.set_to_hdp_expected_values()
+    op = cases.oracle_params(oracle, p)
+    worst = 0
+    for j in range(2):
+        exp = cases.oracle_pairs(oracle, om, jobs[j], op)
+        w, lonely = cases.compare_pairs(bh.pairs(j), exp, 100, p.threshold)
+        worst = max(worst, w)
+        assert lonely <= 2 and cases.same_order(bh.pairs(j), exp), j
+    assert worst <= 100
     bh.close(); bg.close()
     # (2) the Zymo read under the bundled HDP -> its assignments -> the HDP updated from them
     r = z.read_fixture()
