@@ -824,7 +824,7 @@ def measure(args, ctx, compact=False):
         traffic = None
         profiles_meta = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        default_size = (args.reads == {"scaling": 12500, "hdp": 5000, "cpg": 10000}.get(args.workload, 2000) and   # (sizes of the counter passes)
+        default_size = (args.reads == {"scaling": 12500, "hdp": 5000, "hdp_dense": 5000, "cpg": 10000}.get(args.workload, 2000) and   # (sizes of the counter passes)
                         args.events == (10000 if args.workload == "scaling" else 5000))
         if os.path.exists(tp) and default_size:
             try:
