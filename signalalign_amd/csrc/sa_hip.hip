@@ -73,6 +73,8 @@ struct DevPlan {
     const sa_ck_t *cks;
     double *F;
     double *E;        // HDP models: emission plane of the register-kernel regions (k_emit_hdp), max_chunk_cellpaths doubles
+    const double *two;     // two-distribution emission on the register kernels (k_*_fast_two): the noise constants, else nullptr
+    long long two_xn_off;  // ... first entry (double4) of the per-position part (FastT.two_xn_off)
     double *vbuf;
     sa_cand_t *cands;
     int *cand_count;
@@ -1156,7 +1158,7 @@ __global__ __launch_bounds__(64) void k_gather_sorted(DevPlan P, int seg0, int n
 // library's log), so the values are bit-identical to the host's.
 __global__ __launch_bounds__(256) void k_fill_xc(const sa_region_t *__restrict__ regions, const int *__restrict__ poff_all,
                                                  const int *__restrict__ pid_all, const double *__restrict__ tab6,
-                                                 const int *__restrict__ hdp_slot, long long hdp_grid_length, double4 *xc) {
+                                                 const int *__restrict__ hdp_slot, long long hdp_grid_length, double4 *xc, int emission) {
     const sa_region_t *R = &regions[blockIdx.x];
     const int *poff = poff_all + R->poff_off;
     const int *pid = pid_all + R->pid_off;
@@ -1175,13 +1177,17 @@ __global__ __launch_bounds__(256) void k_fill_xc(const sa_region_t *__restrict__
             v.x = 0.0; v.y = 1.0; v.z = NEG_INF; v.w = NEG_INF;
         } else {
             const double mu = tab6[6ll * id], sd = tab6[6ll * id + 1], c = tab6[6ll * id + 2], cy = tab6[6ll * id + 4];
-            v.x = R->scale * mu + R->shift;
+            // (the two-distribution emissions carry no log(1 / var) -- impl/stateMachine.c:607-700 against :557-605 --, and the one on the
+            // scaled model, emission 2, takes the event as it is: scale 1, shift 0, var 1)
+            const double sc = emission == 2 ? 1.0 : R->scale, sh = emission == 2 ? 0.0 : R->shift, va = emission == 2 ? 1.0 : R->var;
+            const double lv = emission != 0 ? 0.0 : R->lvar;
+            v.x = sc * mu + sh;
             if (c == NEG_INF) {   // sd == 0: emissions_signal_logGaussPdf returns LOG_ZERO
                 v.y = 1.0; v.z = NEG_INF; v.w = NEG_INF;
             } else {
-                v.y = 1.0 / (R->var * sd);
-                v.z = R->lvar + c;
-                v.w = R->lvar + cy;
+                v.y = 1.0 / (va * sd);
+                v.z = lv + c;
+                v.w = lv + cy;
             }
         }
         o[i] = v;
@@ -1262,6 +1268,7 @@ struct sa_batch {
     unsigned seam_cap;
     unsigned seam_cap_bwd;   // records per seam array of the backward launches (a traceback segment is shorter than a region)
     long long seam_bwd_off;  // bytes: the forward launch's slots come first, then those of a pass's backward launches
+    double *d_two = nullptr; long long two_xn_off = 0;   // two-distribution emission on the register kernels (DevPlan.two)
     double *d_tab6; double *d_noise3; double *d_evn; int *d_hdp_slot; double *d_hdp_y, *d_hdp_slope, *d_hdp_grid, *d_hdp_tab, *d_hdp_coef;
     long long *d_prob; int *d_seg_pass; long long *d_seg_off; sa_pair16_t *d_out;
     int *d_ids;  // region / segment id lists per launch
@@ -1347,6 +1354,7 @@ static DevPlan make_devplan(const sa_batch *b) {
     P.segs = b->d_segs; P.cks = b->d_cks; P.F = b->d_F; P.E = b->d_E; P.vbuf = b->d_vbuf; P.cands = b->d_cands;
     P.cand_count = b->d_cand_count; P.overflow = b->h_overflow; P.totals = b->d_totals; P.bscratch = b->d_bscratch;
     P.gsum = b->d_gsum; P.gmc = b->d_gmc;
+    P.two = b->d_two; P.two_xn_off = b->two_xn_off;
     P.m.t_mm = m->t_mm; P.m.t_mx = m->t_mx; P.m.t_my = m->t_my; P.m.t_xm = m->t_xm; P.m.t_xx = m->t_xx;
     P.m.t_ym = m->t_ym; P.m.t_yy = m->t_yy;
     P.m.tab6 = b->d_tab6; P.m.emission = m->emission; P.m.noise3 = b->d_noise3; P.evn = b->d_evn; P.m.pow_km1 = m->pow_km1; P.m.n_alpha = m->n_alpha; P.m.hdp = m->hdp ? 1 : 0;
@@ -1693,7 +1701,7 @@ void sa_batch_destroy(sa_batch_t *b) {
     }
     const double td1 = now_ms_d();
     void *ptrs[] = {b->d_regions, b->d_rows, b->d_pk, b->d_poff, b->d_pid, b->d_px, b->d_xc, b->d_prec, b->d_ev, b->d_segs, b->d_cks, b->d_F, b->d_E,
-                    b->d_vbuf, b->d_cands, b->d_cand_count, b->d_overflow, b->d_totals, b->d_bscratch, b->d_tab6, b->d_noise3, b->d_evn,
+                    b->d_vbuf, b->d_cands, b->d_cand_count, b->d_overflow, b->d_totals, b->d_bscratch, b->d_tab6, b->d_noise3, b->d_evn, b->d_two,
                     b->d_hdp_slot, b->d_hdp_y, b->d_hdp_slope, b->d_hdp_grid, b->d_hdp_tab, b->d_hdp_coef, b->d_prob, b->d_seg_pass, b->d_seg_off,
                     b->d_out, b->d_ids, b->d_gsum, b->d_gmc, b->d_seam, b->d_ckxy, b->d_blk, b->d_spec, b->d_sortkey, b->d_sortidx,
                     b->d_vc_bits, b->d_vc_off, b->d_seg_all};
@@ -1764,8 +1772,13 @@ static int batch_create_impl(sa_batch_t **out, const sa_model_t *m, const sa_par
     // backward >= checkpoint maximum + log threshold) has no lower bound then and would pass lanes that hold no cell.  Such a
     // batch takes the reference-ordered kernels with host finalisation, which list a diagonal's cells explicitly.
     if (!(p->threshold > 0.0)) flags |= SA_FLAG_EXACT;
-    // the two-distribution emission (sa_model_set_emission) exists in the reference-ordered memory-resident kernels only
-    if (m->emission != 0) flags |= SA_FLAG_EXACT;
+    // The two-distribution emission (sa_model_set_emission) exists in the reference-ordered memory-resident kernels and, since round
+    // 6, in the register kernels (k_fwd_fast_two / k_bwd_fast_two: one path per cell; wide stretches through their in-kernel
+    // memory-resident path).  A batch whose regions are not ALL register-kernel regions (an ambiguity letter, a matrix that the
+    // planner splits beyond their limits) is planned again as with SA_FLAG_EXACT (batch_prepare_body); the expectation pass, 8-byte
+    // records and the variant-caller filter keep the reference-ordered kernels.
+    if (m->emission != 0 && ((flags & (SA_FLAG_EXPECT_INTERNAL | SA_FLAG_FORCE_GENERIC | SA_FLAG_PAIRS8 | SA_FLAG_VC_ROWS)) || getenv("SA_TWO_DIST_FAST_OFF")))
+        flags |= SA_FLAG_EXACT;
     const bool trace_c = getenv("SA_TRACE") != nullptr;
     auto now_ms_c = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double tc0 = now_ms_c();
@@ -1812,7 +1825,7 @@ static int batch_create_impl(sa_batch_t **out, const sa_model_t *m, const sa_par
         const double v_ = atof(ets);
         if (v_ > 0.0) b->spec_slack = v_;
     }
-    b->d_bscratch = nullptr; b->d_tab6 = nullptr; b->d_noise3 = nullptr; b->d_evn = nullptr; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr;
+    b->d_bscratch = nullptr; b->d_tab6 = nullptr; b->d_noise3 = nullptr; b->d_evn = nullptr; b->d_two = nullptr; b->two_xn_off = 0; b->d_hdp_slot = nullptr; b->d_hdp_y = nullptr;
     b->d_hdp_slope = nullptr; b->d_hdp_grid = nullptr; b->d_hdp_tab = nullptr; b->d_hdp_coef = nullptr; b->d_prob = nullptr; b->d_seg_pass = nullptr;
     b->d_seg_off = nullptr; b->d_out = nullptr; b->d_ids = nullptr; b->d_gsum = nullptr; b->d_gmc = nullptr;
     b->cand_alloc = 0; b->out_alloc = 0; b->cand_factor = 1; b->spec_repeats = 0;
@@ -2027,7 +2040,7 @@ static int batch_prepare_body(sa_batch *b) {
     const sa_job_t *jobs = b->c_jobs;
     const int64_t n_jobs = b->c_n;
     const char *const *ambig = b->c_ambig;
-    const unsigned flags = b->flags;
+    unsigned flags = b->flags;   // (gains SA_FLAG_EXACT when a two-distribution batch is planned again below)
     const long long budget = b->c_budget;
     const int device = b->device;
     const bool trace_c = getenv("SA_TRACE") != nullptr;
@@ -2053,6 +2066,14 @@ static int batch_prepare_body(sa_batch *b) {
         static std::atomic<int> batches_created(0);
         if (SaPool::enabled() && batches_created.fetch_add(1) >= 2) sa_plan_use_allocator(plan_pinned_alloc, plan_pinned_free);
         int rc = sa_plan_build(&pl, m, p, jobs, n_jobs, ambig, flags | SA_FLAG_DEVICE_XC_INTERNAL, budget);
+        if (rc == SA_OK && m->emission != 0 && !(flags & SA_FLAG_EXACT) && pl->n_fast_regions != pl->n_regions) {
+            // the two-distribution emission off the register kernels: the reference-ordered kernels for the whole batch
+            sa_plan_free(pl);
+            pl = nullptr;
+            b->flags |= SA_FLAG_EXACT;
+            flags = b->flags;
+            rc = sa_plan_build(&pl, m, p, jobs, n_jobs, ambig, flags | SA_FLAG_DEVICE_XC_INTERNAL, budget);
+        }
         sa_plan_use_allocator(nullptr, nullptr);
         if (rc) return rc;
         if (trace_c) fprintf(stderr, "[trace] create: planned at %.1f ms\n", now_ms_c() - tc0);
@@ -2184,6 +2205,27 @@ static int batch_prepare_body(sa_batch *b) {
                 }
             }
             TRY(upload(&b->d_evn, evn.data(), (long long) evn.size()));
+            if (!(flags & SA_FLAG_EXACT)) {
+                // the register kernels' form of the same numbers (FastT.two_xn_off): per event {n, 1 / n, 1.5 log n, 0}, then per
+                // path-space index {(log lambda - log 2 pi) / 2, 1 / noise mean, lambda / 2, 0} of the position's k-mer (zeros for the
+                // NULL entry, whose Gaussian part is -inf already)
+                const long long ne = pl->n_ev + 8, np_ = pl->n_pid > 0 ? pl->n_pid : 1;
+                std::vector<double> two((size_t) (4 * (ne + np_)), 0.0);
+                for (long long y = 0; y < ne; y++) {
+                    const double n = evn[(size_t) (2 * y)];
+                    two[(size_t) (4 * y)] = n; two[(size_t) (4 * y + 1)] = 1.0 / n; two[(size_t) (4 * y + 2)] = 1.5 * evn[(size_t) (2 * y + 1)];
+                }
+                for (long long i = 0; i < pl->n_pid; i++) {
+                    const int id = pl->pid[i];
+                    if (id < 0) continue;
+                    double *q = &two[(size_t) (4 * (ne + i))];
+                    q[0] = 0.5 * (nz[(size_t) (3 * id + 2)] - 1.8378770664093453);
+                    q[1] = 1.0 / nz[(size_t) (3 * id)];
+                    q[2] = 0.5 * nz[(size_t) (3 * id + 1)];
+                }
+                b->two_xn_off = ne;
+                TRY(upload(&b->d_two, two.data(), (long long) two.size()));
+            }
         }
         if (m->hdp) {
             const sa_hdp_t *h = m->hdp;
@@ -2258,7 +2300,7 @@ static int batch_prepare_body(sa_batch *b) {
         if (pl->n_regions > 0)
             hipLaunchKernelGGL(k_fill_xc, dim3((unsigned) pl->n_regions), dim3(256), 0, (*UPT).stream, b->d_regions, b->d_poff,
                                b->d_pid, b->d_tab6, m->hdp ? b->d_hdp_slot : (const int *) nullptr,
-                               m->hdp ? (long long) m->hdp->grid_length : 0ll, reinterpret_cast<double4 *>(b->d_xc));
+                               m->hdp ? (long long) m->hdp->grid_length : 0ll, reinterpret_cast<double4 *>(b->d_xc), m->emission);
         if (hipGetLastError() != hipSuccess) return SA_ENODEVICE;
     }
     TRY((*UPT).drain());
@@ -3081,7 +3123,7 @@ int sa_batch_release_device(sa_batch_t *b) {
     void **ptrs[] = {(void **) &b->d_regions, (void **) &b->d_rows, (void **) &b->d_pk, (void **) &b->d_poff, (void **) &b->d_pid, (void **) &b->d_px,
                      (void **) &b->d_xc, (void **) &b->d_prec, (void **) &b->d_ev, (void **) &b->d_segs, (void **) &b->d_cks, (void **) &b->d_F,
                      (void **) &b->d_E, (void **) &b->d_vbuf, (void **) &b->d_cands, (void **) &b->d_cand_count, (void **) &b->d_overflow,
-                     (void **) &b->d_totals, (void **) &b->d_bscratch, (void **) &b->d_tab6, (void **) &b->d_noise3, (void **) &b->d_evn,
+                     (void **) &b->d_totals, (void **) &b->d_bscratch, (void **) &b->d_tab6, (void **) &b->d_noise3, (void **) &b->d_evn, (void **) &b->d_two,
                      (void **) &b->d_hdp_slot, (void **) &b->d_hdp_y, (void **) &b->d_hdp_slope, (void **) &b->d_hdp_grid, (void **) &b->d_hdp_tab, (void **) &b->d_hdp_coef,
                      (void **) &b->d_prob, (void **) &b->d_seg_pass, (void **) &b->d_seg_off, (void **) &b->d_out, (void **) &b->d_ids,
                      (void **) &b->d_gsum, (void **) &b->d_gmc, (void **) &b->d_seam, (void **) &b->d_ckxy, (void **) &b->d_blk, (void **) &b->d_spec,

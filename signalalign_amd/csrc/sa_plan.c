@@ -719,7 +719,10 @@ static int add_region(sa_plan_t *pl, int64_t job, const sa_job_t *jb, rect_t rc,
     /* (the expectation pass: ring kernels for regions with several paths per cell under a Gaussian model -- k_bwd_ring<EXPECT> --,
      * never for one-path regions, which keep the register kernels' expectation variant) */
     const int expect_ = (pl->flags & SA_FLAG_EXPECT_INTERNAL) != 0;
-    int ring_ok = !(pl->flags & (SA_FLAG_EXACT | SA_FLAG_FORCE_GENERIC)) && hdp_plane_ok &&
+    /* (the two-distribution emission exists in the register kernels and the reference-ordered ones: a one-path region with a wide
+     * band stays a register-kernel region -- their in-kernel memory-resident path --, one with several paths per cell is not
+     * SA_KIND_FAST and sends the batch to the reference-ordered kernels, sa_hip.hip batch_prepare_body) */
+    int ring_ok = !(pl->flags & (SA_FLAG_EXACT | SA_FLAG_FORCE_GENERIC)) && hdp_plane_ok && m->emission == 0 &&
                   (!expect_ || (maxP > 1 && m->hdp == NULL)) &&
                   max_rowpaths <= SA_RING_MAX_ROWPATHS && foff + 1 <= SA_FAST_MAX_CELLS && ring_env_on() &&
                   (maxP == 1 || (maxP <= 255 && ambig_options_distinct(ambig)));

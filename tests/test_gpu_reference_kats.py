@@ -12,10 +12,12 @@ What the numbers are (paths relative to the upstream signalAlign tree):
   getAlignedPairsUsingAnchors(..., 0, 0) (inc/pairwiseAligner.h:406-414: both ends NOT ragged): 1076 / 1076 / 1076 / 7349.
 
 The ragged-end arguments are sa_job_t.ends (include/signalalign_hip.h); the emissions are SA_EMISSION_TWO_DIST (descaled events)
-and SA_EMISSION_TWO_DIST_SCALED_MODEL (scaled model).  Those emissions exist in the reference-ordered memory-resident kernels only
-(what SA_FLAG_EXACT selects), so flags 0 and SA_FLAG_EXACT run the same kernels here; the register / strip / ring kernels carry the
-emission signalMachine installs (MeanOnly) and meet non-ragged ends in tests/test_gpu_fuzz.py and tests/test_gpu_parity.py against
-the CPU restatement.  Inputs: the .npRead / reference / model files the reference ships (tests/golden), the committed cigar lines
+and SA_EMISSION_TWO_DIST_SCALED_MODEL (scaled model).  Round 6: with flags 0 a batch whose regions all hold one path per cell runs
+these emissions on the REGISTER kernels (k_fwd_fast_two / k_bwd_fast_two -- the kernels the bench times, with the noise term added:
+wide stretches through their in-kernel memory-resident path), so the 14 / 7 matrices and the whole-read 1076 below come out of that
+kernel family itself; SA_FLAG_EXACT, and any batch with several paths per cell (the degenerate-nucleotide test), takes the
+reference-ordered memory-resident kernels.  The strip / ring kernels carry the emission signalMachine installs (MeanOnly) and meet
+non-ragged ends in tests/test_gpu_fuzz.py and tests/test_gpu_parity.py against the CPU restatement.  Inputs: the .npRead / reference / model files the reference ships (tests/golden), the committed cigar lines
 of its lastz subprocess (tests/zymo_wholeread.py restates what follows the subprocess in plain Python).
 """
 import os
@@ -75,7 +77,10 @@ def test_literal_seven_event_matrices(model_file, ref, sy, n_pairs, allowed, fla
     p = sa.default_params(threshold=0.2, expansion=2, trace_back=40)
     job = dict(ref=ref, events=np.array(sy, dtype=np.float64).reshape(7, 4), ax=[], ay=[], ragged=(0, 0))
     got, st = _align(m, p, job, flags)
-    assert st.n_fast_regions == 0 and st.n_ring_regions == 0      # the reference-ordered kernels
+    if flags == 0 and "L" not in ref:
+        assert st.n_fast_regions == st.n_regions >= 1 and st.n_ring_regions == 0   # the register kernels (round 6)
+    else:   # (the first matrix holds the three-way code L: several paths per cell)
+        assert st.n_fast_regions == 0 and st.n_ring_regions == 0                   # the reference-ordered kernels
     assert len(got) == n_pairs
     assert {(int(q["x"]), int(q["y"])) for q in got} <= allowed
     assert got["prob_e7"].min() >= 2000000 and got["prob_e7"].max() <= 10000000
@@ -118,14 +123,16 @@ def test_zymo_whole_read_banded_1076_scaled_and_descaled_model(flags):
     lX, lY = len(r["ref"]) - (k - 1), r["template_events"].shape[0]
     scaled = sa.Model.create(alpha, k, t10, z.scaled_table(tab, tp))            # loadScaledStateMachine3 (:69-79)
     scaled.set_emission(EM_TWO_DIST_SCALED_MODEL)
-    got, _ = _align(scaled, p, dict(ref=r["ref"], events=r["template_events"], ax=ax, ay=ay, ragged=(1, 1)), flags)
+    got, st = _align(scaled, p, dict(ref=r["ref"], events=r["template_events"], ax=ax, ay=ay, ragged=(1, 1)), flags)
+    assert (st.n_fast_regions == st.n_regions >= 1) if flags == 0 else (st.n_fast_regions == 0)
     assert len(got) == z.N_PAIRS_GAUSS
     _check_pairs(got, lX, lY, True)
     descaled = sa.Model.create(alpha, k, t10, _noise_scaled(tab, tp))           # loadDescaledStateMachine3 (:81-88)
     descaled.set_emission(EM_TWO_DIST)
     job = dict(ref=r["ref"], events=r["template_events"], ax=ax, ay=ay, scale=tp["scale"], shift=tp["shift"], var=tp["var"],
                ragged=(1, 1))
-    got, _ = _align(descaled, p, job, flags)
+    got, st = _align(descaled, p, job, flags)
+    assert (st.n_fast_regions == st.n_regions >= 1) if flags == 0 else (st.n_fast_regions == 0)
     assert len(got) == z.N_PAIRS_GAUSS
     _check_pairs(got, lX, lY, True)
     scaled.close()
@@ -144,6 +151,7 @@ def test_zymo_whole_read_degenerate_nucleotides_not_ragged(flags):
                  var=tp["var"], ragged=(0, 0)) for letter in z.N_PAIRS_DEGENERATE]
     b = sa.Batch(m, p, jobs, flags=flags)       # (default ambiguity table: L -> C / E / O, impl/pairwiseAligner.c:32-65)
     b.run()
+    assert b.stats().n_fast_regions == 0        # several paths per cell somewhere in the batch: the reference-ordered kernels
     for j, (letter, want) in enumerate(z.N_PAIRS_DEGENERATE.items()):
         got = b.pairs(j)
         assert len(got) == want, (letter, len(got))
@@ -173,3 +181,47 @@ def test_ragged_ends_change_the_result_and_bad_bits_are_refused():
     rc = sa.lib().sa_batch_create(_capi.C.byref(h), m._h, _capi.C.byref(p), arr, 1, sa.default_ambig(), 0, 0)
     assert rc == -1     # SA_EINVAL
     m.close()
+
+
+@pytest.mark.parametrize("emission", [EM_TWO_DIST, EM_TWO_DIST_SCALED_MODEL])
+def test_two_distribution_emission_on_the_register_kernels_against_the_other_kernels_and_the_oracle(emission):
+    """Round 6: the two-distribution emissions on the register kernels against the reference-ordered kernels (SA_FLAG_EXACT) and
+    the CPU restatement on synthetic reads (dense anchors: the register loop; every 29th anchor: the in-kernel memory-resident
+    path), a read of 30 events, both ragged-end settings.  1e-5 on a posterior; rows on one side only within that of the threshold."""
+    from oracle import sa_oracle_py as oracle
+    import sa_cases as cases
+    alpha, k, t10, tab = synth.parse_model_table(cases.MODEL_6MER)
+    m = sa.Model.create(alpha, k, t10, tab)
+    m.set_emission(emission)
+    om = oracle.Model(alpha, k, t10, tab, emission={EM_TWO_DIST: oracle.EM_TWODIST_DESCALED, EM_TWO_DIST_SCALED_MODEL: oracle.EM_TWODIST}[emission])
+    p = sa.default_params(threshold=0.02)
+    op = cases.oracle_params(oracle, p)
+    jobs = cases.synthetic_jobs(cases.MODEL_6MER, 3, 1400, 4100) + cases.synthetic_jobs(cases.MODEL_6MER, 1, 30, 4200)
+    sparse = dict(jobs[1])
+    keep = np.zeros(len(sparse["ax"]), dtype=bool)
+    keep[::29] = True
+    sparse["ax"], sparse["ay"] = sparse["ax"][keep], sparse["ay"][keep]
+    jobs.append(sparse)
+    jobs[2] = dict(jobs[2], ragged=(0, 0))
+    if emission == EM_TWO_DIST_SCALED_MODEL:    # the model is not scaled to these reads: give them the identity scaling instead
+        jobs = [dict(j, scale=1.0, shift=0.0, var=1.0) for j in jobs]
+    fast = sa.Batch(m, p, jobs)
+    fast.run()
+    st = fast.stats()
+    assert st.n_fast_regions == st.n_regions == len(jobs)
+    exact = sa.Batch(m, p, jobs, flags=sa.FLAG_EXACT)
+    exact.run()
+    assert exact.stats().n_fast_regions == 0
+    worst = 0
+    for j, job in enumerate(jobs):
+        a, b = fast.pairs(j), exact.pairs(j)
+        w, lonely = cases.compare_pairs(a, b, 100, p.threshold)
+        worst = max(worst, w)
+        assert lonely <= 2 and cases.same_order(a, b), j
+        om.set_read_params(job["scale"], job["shift"], job["var"])
+        exp = oracle.align(om, job["ref"], job["events"], job["ax"], job["ay"], op, ragged=job.get("ragged", (1, 1)))
+        assert np.array_equal(b["prob_e7"], exp["prob_e7"]) and np.array_equal(b["x"], exp["x"])   # EXACT == oracle, bit for bit
+        assert len(a) > 0.5 * len(job["events"])
+    assert worst <= 10
+    fast.close(); exact.close(); m.close()
+

@@ -1,8 +1,10 @@
 """The HIP path against posteriors the reference itself wrote: the Zymo 2-D read's template strand (fixtures and background:
 tests/test_oracle_reference_outputs.py).  The file was written by a build whose state machine carried the two-distribution
-emission, which the reference-ordered memory-resident kernels offer behind sa_model_set_emission: the GPU's pairs are then
-bit-identical to the CPU restatement's, and both sit on the reference's printed posteriors (median |dp| <= 2e-6, nine rows in ten
-within 1e-4, the rest being the guide alignment bwa made and lastz did not)."""
+emission, which the reference-ordered memory-resident kernels (SA_FLAG_EXACT) and, since round 6, the register kernels (the
+default for a read with one path per cell: k_fwd_fast_two / k_bwd_fast_two) offer behind sa_model_set_emission: the
+reference-ordered kernels' pairs are bit-identical to the CPU restatement's, the register kernels' within 1e-5 of them, and all
+sit on the reference's printed posteriors (median |dp| <= 2e-6, nine rows in ten within 1e-4, the rest being the guide alignment
+bwa made and lastz did not)."""
 import json
 import os
 
@@ -40,11 +42,16 @@ def test_gpu_reproduces_the_reference_posteriors_of_the_zymo_read(oracle):
     pm.set_emission(1)                                   # SA_EMISSION_TWO_DIST
     job = dict(ref=ref[s1:e1], events=np.ascontiguousarray(ev[lo:hi]), ax=ax, ay=ay, scale=pr["scale"], shift=pr["shift"], var=pr["var"])
     p = sa.default_params(threshold=0.01, expansion=50, trace_back=100)
-    b = sa.Batch(pm, p, [job])
+    b = sa.Batch(pm, p, [job], flags=sa.FLAG_EXACT)
     b.run()
     got = b.pairs(0)
     assert b.stats().n_fast_regions == 0                 # the reference-ordered kernels
     b.close()
+    bf = sa.Batch(pm, p, [job])                          # ... and the register kernels (round 6), checked below
+    bf.run()
+    got_fast = bf.pairs(0)
+    assert bf.stats().n_fast_regions == bf.stats().n_regions >= 1
+    bf.close()
     # the CPU restatement with the same emission: bit-identical
     om = oracle.Model(alpha, k, t10, tab, emission=oracle.EM_TWODIST_DESCALED)
     ev_o = r["template_events"].copy()
@@ -61,6 +68,13 @@ def test_gpu_reproduces_the_reference_posteriors_of_the_zymo_read(oracle):
     assert len(common) >= 0.97 * len(gold) and np.median(d) <= 2e-6 and (d <= 1e-4).mean() >= 0.9
     found, _, within_rel, _, beyond = cases.reference_residual(mine, gold)   # (the residual is one factor per checkpoint group)
     assert within_rel >= 0.99 and all(row[0] <= 60 for row in beyond), (within_rel, beyond[:5])
+    # the register kernels: within 1e-5 of the reference-ordered ones, and on the reference's printed posteriors as well
+    w, lonely = cases.compare_pairs(got_fast, got, 100, p.threshold)
+    assert w <= 10 and lonely <= 2 and cases.same_order(got_fast, got)
+    mine_f = {(int(q["x"]) + s1, int(q["y"]) + lo): int(q["prob_e7"]) / 1e7 for q in got_fast}
+    common_f = set(mine_f) & set(gold)
+    d_f = np.array([abs(mine_f[k_] - gold[k_]) for k_ in common_f])
+    assert len(common_f) >= 0.97 * len(gold) and np.median(d_f) <= 2e-6 and (d_f <= 1e-4).mean() >= 0.9
     # a dense event vector cannot carry the noise
     with pytest.raises(sa.SaError):
         sa.Batch(pm, p, [dict(job, events=np.ascontiguousarray(job["events"][:, 0]))])
@@ -85,10 +99,17 @@ def test_gpu_reproduces_the_reference_posteriors_of_the_r9p4_read(oracle):
     pm.set_emission(1)
     p = sa.default_params(threshold=0.01, expansion=50, trace_back=100)
     job = dict(ref=window[s1:e1], events=np.ascontiguousarray(ev[lo:hi]), ax=ax, ay=ay, scale=pr["scale"], shift=pr["shift"], var=pr["var"])
-    b = sa.Batch(pm, p, [job])
+    b = sa.Batch(pm, p, [job], flags=sa.FLAG_EXACT)
     b.run()
     got = b.pairs(0)
     b.close()
+    bf = sa.Batch(pm, p, [job])                          # the register kernels (round 6)
+    bf.run()
+    got_fast = bf.pairs(0)
+    assert bf.stats().n_fast_regions == bf.stats().n_regions >= 1
+    bf.close()
+    w, lonely = cases.compare_pairs(got_fast, got, 100, p.threshold)
+    assert w <= 10 and lonely <= 4 and cases.same_order(got_fast, got)
     om = oracle.Model(alpha, k, t10, tab, emission=oracle.EM_TWODIST_DESCALED)
     ev_o = r["template_events"].copy()
     pr_o = oracle.estimate_params(om, em, ev_o, read)
