@@ -750,11 +750,19 @@ static void output_one(int64_t j, void *ctx) {
                 return;
             }
             mine[s] = malloc(sizeof(sa_pair_t) * (size_t) (n > 0 ? n : 1));
+            int bad_kmer = 0;
             for (int64_t i = 0; i < n; i++) {
                 sa_pair_t *q = &mine[s][i];
                 sa_pair8_unpack(pk8[i], &q->prob_e7, &q->x, &q->y);
                 q->path = 0;
                 q->kmer_id = kmer_id_of(sm, target + q->x);
+                bad_kmer |= q->kmer_id < 0;
+            }
+            if (bad_kmer) {   /* (cannot happen: the planner refuses a reference with a letter outside the model's alphabet) */
+                fprintf(stderr, "[signalMachine] ERROR: read %s: a pair names a k-mer outside the model's alphabet\n", rd->label);
+                rd->failed = 1;
+                free(mine[0]); free(mine[1]);
+                return;
             }
             pp[s] = mine[s];
         } else if (pp[s] == NULL && c->batch && c->batch[s]) {
