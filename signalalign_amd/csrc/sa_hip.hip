@@ -2632,31 +2632,8 @@ static int submit_group(sa_batch *b, const DevPlan &P, int g, int which_stream, 
         if (b->strip_one_pass) launch_bwd_strip1(P, b->d_ids + G.ids_ss, G.nss, st, b->d_seam + b->seam_bwd_off, ST);
         else launch_bwd_strip(P, b->d_ids + G.ids_ss, G.nss, st, b->d_seam + b->seam_bwd_off, b->d_ckxy, ST);
     }
-    {
-        // The expectation pass is ONE group (its sums are reduced on the host side of the pass), so nothing runs beside a class's
-        // launch -- and a launch lasts as long as its longest traceback's serial chain whatever its size: the second class of
-        // configs[2]'s reads (rows beyond 128 cell-paths: a few hundred tracebacks) held the chip for as long as the first (21 + 21
-        // ms per 2000 reads, profiles/r06_expectations_cpg_kernel_stats.csv).  Round 6: the classes of such a group alternate
-        // between the two compute streams (fork behind what is queued on `st`, join in front of the fold).
-        int n_cl = 0;
-        for (int cl = 0; cl < 16; cl++) n_cl += G.nrs[cl] > 0;
-        const bool fork = b->expect && n_cl > 1 && b->ev[6] && b->gev[4 * g + 3];
-        hipStream_t other = b->cstream[1 - which_stream];
-        if (fork) {
-            HIPCHK(hipEventRecord(b->ev[6], st));
-            HIPCHK(hipStreamWaitEvent(other, b->ev[6], 0));
-        }
-        int k_cl = 0;
-        for (int cl = 15; cl >= 0; cl--)   // widest (longest-running) classes first
-            if (G.nrs[cl]) {
-                launch_bwd_ring(P, b->d_ids + G.ids_rs[cl], G.nrs[cl], (fork && (k_cl & 1)) ? other : st, 64 * ((cl & 7) + 1), cl >= 8, b->expect);
-                k_cl++;
-            }
-        if (fork) {
-            HIPCHK(hipEventRecord(b->gev[4 * g + 3], other));
-            HIPCHK(hipStreamWaitEvent(st, b->gev[4 * g + 3], 0));
-        }
-    }
+    for (int cl = 15; cl >= 0; cl--)   // widest (longest-running) classes first
+        if (G.nrs[cl]) launch_bwd_ring(P, b->d_ids + G.ids_rs[cl], G.nrs[cl], st, 64 * ((cl & 7) + 1), cl >= 8, b->expect);
     if (G.nfs) { const int rcl = launch_bwd_fast(P, b->d_ids + G.ids_fs, G.nfs, st, b->expect); if (rcl) return rcl; }
     HIPCHK(hipEventRecord(b->gev[4 * g + 1], st));
     if (G.ck1 > G.ck0)
