@@ -525,3 +525,26 @@ def test_ring_kernel_routing_and_path_records(oracle):
     # (e) an ambiguity code with a repeated option: the index form of legality does not hold -> memory-resident kernels
     info, _ = sa.plan_digest(pmc, p, cpg, ambig=sa.default_ambig({"X": "CC"}))
     assert info.n_ring_regions == 0
+
+
+def test_two_distribution_emission_keeps_one_path_regions_on_the_register_kernels():
+    # round 6: the two-distribution emissions exist in the register kernels (k_fwd_fast_two / k_bwd_fast_two) and in the
+    # reference-ordered ones, not in the strip / ring kernels: the planner leaves a one-path region with a wide band a register-kernel
+    # region (their in-kernel memory-resident path), and a region with several paths per cell is no register-kernel region at all
+    # (sa_batch_create then plans the batch again as with SA_FLAG_EXACT)
+    alpha, k, t10, tab = synth.parse_model_table(cases.MODEL_6MER)
+    p = sa.default_params()
+    wide = cases.realistic_anchor_jobs(cases.MODEL_6MER, 1, 1500, 31)[0]
+    amb = dict(cases.synthetic_jobs(cases.MODEL_6MER, 1, 600, 32)[0])
+    amb["ref"] = amb["ref"][:100] + "X" + amb["ref"][101:]
+    for emission in (0, 1, 2):
+        m = sa.Model.create(alpha, k, t10, tab)
+        m.set_emission(emission)
+        info = sa.plan_describe(m, p, wide)[0]
+        if emission == 0:
+            assert info.n_ring_regions == info.n_regions >= 1 and info.n_fast_regions == 0      # the strip kernels' region
+        else:
+            assert info.n_fast_regions == info.n_regions >= 1 and info.n_ring_regions == 0
+        info = sa.plan_describe(m, p, amb, ambig=sa.default_ambig({"X": "CT"}))[0]
+        assert info.n_fast_regions == 0 and (info.n_ring_regions == info.n_regions) == (emission == 0)
+        m.close()
