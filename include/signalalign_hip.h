@@ -230,8 +230,8 @@ int64_t sa_kmer_id(const sa_model_t *m, const char *kmer); /* impl/nanopore_hdp.
  *   SA_EMISSION_TWO_DIST   emissions_signal_strawManGetKmerEventMatchProbWithDescaling (:607-650): Gaussian on the descaled mean
  *                          x inverse Gaussian on the event noise -- what the reference's shipped output files were written with
  *                          (tests/test_oracle_reference_outputs.py).  Register kernels (round 6: k_fwd_fast_two / k_bwd_fast_two) when
- *                          every region of the batch holds one path per cell and the batch is a plain alignment with 16-byte
- *                          records; otherwise, and with SA_FLAG_EXACT, the reference-ordered memory-resident kernels (the batch then
+ *                          every region of the batch holds one path per cell (sa_align_batch / sa_batch_*; not the expectation
+ *                          pass); otherwise, and with SA_FLAG_EXACT, the reference-ordered memory-resident kernels (the batch then
  *                          behaves as with SA_FLAG_EXACT); jobs must hand over event records (event_stride >= 2: the
  *                          noise is a record's second value); the noise columns are the MODEL's, so the reads of a batch share
  *                          one noise scaling (the reference rescales them per read, emissions_signal_scaleNoise: create the

@@ -1775,9 +1775,9 @@ static int batch_create_impl(sa_batch_t **out, const sa_model_t *m, const sa_par
     // The two-distribution emission (sa_model_set_emission) exists in the reference-ordered memory-resident kernels and, since round
     // 6, in the register kernels (k_fwd_fast_two / k_bwd_fast_two: one path per cell; wide stretches through their in-kernel
     // memory-resident path).  A batch whose regions are not ALL register-kernel regions (an ambiguity letter, a matrix that the
-    // planner splits beyond their limits) is planned again as with SA_FLAG_EXACT (batch_prepare_body); the expectation pass, 8-byte
-    // records and the variant-caller filter keep the reference-ordered kernels.
-    if (m->emission != 0 && ((flags & (SA_FLAG_EXPECT_INTERNAL | SA_FLAG_FORCE_GENERIC | SA_FLAG_PAIRS8 | SA_FLAG_VC_ROWS)) || getenv("SA_TWO_DIST_FAST_OFF")))
+    // planner splits beyond their limits) is planned again as with SA_FLAG_EXACT (batch_prepare_body); the expectation pass keeps the
+    // reference-ordered kernels.  (SA_TWO_DIST_FAST_OFF=1: always the reference-ordered kernels, as up to round 5.)
+    if (m->emission != 0 && ((flags & (SA_FLAG_EXPECT_INTERNAL | SA_FLAG_FORCE_GENERIC)) || getenv("SA_TWO_DIST_FAST_OFF")))
         flags |= SA_FLAG_EXACT;
     const bool trace_c = getenv("SA_TRACE") != nullptr;
     auto now_ms_c = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
